@@ -1,0 +1,718 @@
+// C-ABI of the engine (include/hxv.h): handle management, host/device products, device
+// Lanczos.  Everything here runs on one HIP device and one stream per handle
+// (SURVEY.md 8b "Threading / re-entrancy": one open sector at a time per rank).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "hxv_internal.hpp"
+#include "hxv_tiles.hpp"
+
+using namespace hxv;
+
+namespace {
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIPCHK(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t _e = (expr);                                                                            \
+    if (_e != hipSuccess)                                                                              \
+      return fail(HXV_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));                     \
+  } while (0)
+}  // namespace
+
+struct hxv_handle {
+  SectorHost host;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::vector<void*> allocs;
+  DevSector dev{};
+  TilePlan plan;
+  // staging for hxv_apply_host
+  double2* d_stage_v = nullptr;
+  double2* d_stage_hv = nullptr;
+  // lanczos scratch
+  double* d_partials = nullptr;  // [2][RED_BLOCKS]
+  double* d_scalars = nullptr;   // [8]
+  double2* d_lz[3] = {nullptr, nullptr, nullptr};
+  int kernel = 1;
+  int64_t n_apply = 0;
+  int64_t device_bytes = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+  template <typename T>
+  hipError_t alloc(T** p, size_t n) {
+    size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    hipError_t e = hipMalloc((void**)p, bytes);
+    if (e == hipSuccess) {
+      allocs.push_back((void*)*p);
+      device_bytes += (int64_t)bytes;
+    }
+    return e;
+  }
+  template <typename T>
+  hipError_t upload(T** p, const std::vector<T>& src) {
+    hipError_t e = alloc(p, src.size());
+    if (e != hipSuccess) return e;
+    if (!src.empty()) e = hipMemcpy(*p, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice);
+    return e;
+  }
+};
+
+namespace {
+
+constexpr int RED_BLOCKS = 1024;
+
+int finish_create(hxv_handle* h, int device, hxv_handle** out) {
+  int ndev = 0;
+  hipError_t e0 = hipGetDeviceCount(&ndev);
+  if (e0 != hipSuccess || ndev == 0) {
+    delete h;
+    return fail(HXV_ERR_HIP, std::string("no HIP device available (hipGetDeviceCount: ") + hipGetErrorString(e0) + ", count " +
+                                 std::to_string(ndev) + "): the HxV engine has no CPU fallback");
+  }
+  if (device < 0 || device >= ndev) {
+    delete h;
+    return fail(HXV_ERR_ARG, "device index out of range");
+  }
+  h->device = device;
+  auto cleanup = [&](int code, const std::string& m) {
+    hxv_destroy(h);
+    return fail(code, m);
+  };
+#define HC(expr)                                                                                       \
+  do {                                                                                                 \
+    hipError_t _e = (expr);                                                                            \
+    if (_e != hipSuccess) return cleanup(HXV_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+  HC(hipSetDevice(device));
+  HC(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  HC(hipEventCreate(&h->ev0));
+  HC(hipEventCreate(&h->ev1));
+  SectorHost& s = h->host;
+  uint32_t *ell_up, *ell_dw, *map_up = nullptr, *map_dw = nullptr;
+  double2 *coef_up, *coef_dw;
+  double *a_up = nullptr, *a_dw = nullptr, *stored = nullptr;
+  HC(h->upload(&ell_up, s.up.ell));
+  HC(h->upload(&ell_dw, s.dw.ell));
+  std::vector<double2> cu(s.up.coef.size()), cd(s.dw.coef.size());
+  for (size_t i = 0; i < cu.size(); ++i) cu[i] = make_double2(s.up.coef[i].real(), s.up.coef[i].imag());
+  for (size_t i = 0; i < cd.size(); ++i) cd[i] = make_double2(s.dw.coef[i].real(), s.dw.coef[i].imag());
+  HC(h->upload(&coef_up, cu));
+  HC(h->upload(&coef_dw, cd));
+  if (s.separable_diag) {
+    HC(h->upload(&map_up, s.map_up));
+    HC(h->upload(&map_dw, s.map_dw));
+    HC(h->upload(&a_up, s.a_up));
+    HC(h->upload(&a_dw, s.a_dw));
+  } else {
+    HC(h->upload(&stored, s.diag_stored));
+  }
+  DevSector& d = h->dev;
+  d.up = DevSpin{ell_up, coef_up, s.up.K, s.up.dim};
+  d.dw = DevSpin{ell_dw, coef_dw, s.dw.K, s.dw.dim};
+  d.diag.mode = s.separable_diag ? 0 : 1;
+  d.diag.a_up = a_up;
+  d.diag.a_dw = a_dw;
+  d.diag.map_up = map_up;
+  d.diag.map_dw = map_dw;
+  d.diag.stored = stored;
+  d.diag.cross = s.cross;
+  d.dimup = s.dimup;
+  d.dimdw = s.dimdw;
+  d.qdw = s.qdw;
+  d.dw0 = s.dw0;
+  d.real_h = (s.up.real_vals && s.dw.real_vals) ? 1 : 0;
+  HC(h->alloc(&h->d_partials, 2 * RED_BLOCKS));
+  HC(h->alloc(&h->d_scalars, 8));
+  std::string perr = make_tile_plan(s, h->plan, [&](const std::vector<uint32_t>& v, uint32_t** p) { return h->upload(p, v); });
+  if (!perr.empty()) return cleanup(HXV_ERR_HIP, perr);
+#undef HC
+  *out = h;
+  return HXV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* hxv_last_error(void) { return g_err.c_str(); }
+const char* hxv_version(void) { return "hxv-mi355x 0.1 (gfx950)"; }
+
+int hxv_create_from_model(const hxv_model* model, int32_t nup, int32_t ndw, int32_t rank, int32_t nranks, int32_t device,
+                          hxv_handle** out) {
+  if (!model || !out) return fail(HXV_ERR_ARG, "NULL model/out");
+  *out = nullptr;
+  hxv_handle* h = new hxv_handle();
+  std::string e = build_sector_from_model(*model, nup, ndw, rank, nranks, h->host);
+  if (!e.empty()) {
+    delete h;
+    bool unsup = e.find("not implemented") != std::string::npos;
+    return fail(unsup ? HXV_ERR_UNSUPPORTED : HXV_ERR_ARG, "hxv_create_from_model: " + e);
+  }
+  return finish_create(h, device, out);
+}
+
+int hxv_create_from_csr(int32_t dimup, int32_t dimdw, const int64_t* up_rowptr, const int32_t* up_cols, const double* up_vals,
+                        const int64_t* dw_rowptr, const int32_t* dw_cols, const double* dw_vals, const double* diag, int32_t rank,
+                        int32_t nranks, int32_t device, hxv_handle** out) {
+  if (!out) return fail(HXV_ERR_ARG, "NULL out");
+  *out = nullptr;
+  hxv_handle* h = new hxv_handle();
+  std::string e = build_sector_from_csr(dimup, dimdw, up_rowptr, up_cols, up_vals, dw_rowptr, dw_cols, dw_vals, diag, rank, nranks,
+                                        h->host);
+  if (!e.empty()) {
+    delete h;
+    return fail(HXV_ERR_ARG, "hxv_create_from_csr: " + e);
+  }
+  return finish_create(h, device, out);
+}
+
+int hxv_destroy(hxv_handle* h) {
+  if (!h) return HXV_OK;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (void* p : h->allocs) (void)hipFree(p);
+  if (h->d_stage_v) (void)hipFree(h->d_stage_v);
+  if (h->d_stage_hv) (void)hipFree(h->d_stage_hv);
+  for (auto& p : h->d_lz)
+    if (p) (void)hipFree(p);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return HXV_OK;
+}
+
+int64_t hxv_vecdim(const hxv_handle* h) { return h ? (int64_t)h->host.qdw * h->host.dimup : -1; }
+
+int hxv_dims(const hxv_handle* h, int32_t* dimup, int32_t* dimdw, int64_t* dim, int32_t* qdw, int64_t* ishift) {
+  if (!h) return fail(HXV_ERR_ARG, "NULL handle");
+  if (dimup) *dimup = h->host.dimup;
+  if (dimdw) *dimdw = h->host.dimdw;
+  if (dim) *dim = h->host.dim;
+  if (qdw) *qdw = h->host.qdw;
+  if (ishift) *ishift = h->host.ishift;
+  return HXV_OK;
+}
+
+int hxv_apply_device(hxv_handle* h, const void* d_v_full, void* d_hv_local, void* stream) {
+  if (!h || !d_v_full || !d_hv_local) return fail(HXV_ERR_ARG, "hxv_apply_device: NULL argument");
+  hipStream_t st = (hipStream_t)stream;  // NULL = the legacy default stream, as everywhere in HIP
+  hipError_t e;
+  if (h->kernel == 0)
+    e = launch_hxv_naive(h->dev, (const double2*)d_v_full, (double2*)d_hv_local, st);
+  else
+    e = launch_hxv_tiled(h->dev, h->plan, (const double2*)d_v_full, (double2*)d_hv_local, st);
+  if (e != hipSuccess) return fail(HXV_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+  h->n_apply++;
+  return HXV_OK;
+}
+
+int hxv_apply_host(hxv_handle* h, int64_t nloc, const void* v, void* hv) {
+  if (!h || !v || !hv) return fail(HXV_ERR_ARG, "hxv_apply_host: NULL argument");
+  if (h->host.nranks != 1)
+    return fail(HXV_ERR_STATE, "hxv_apply_host needs nranks==1; a split sector exchanges slabs first (hxv_apply_device)");
+  if (nloc != h->host.dim) return fail(HXV_ERR_ARG, "hxv_apply_host: Nloc != Dim of the open sector");
+  HIPCHK(hipSetDevice(h->device));
+  size_t bytes = (size_t)nloc * sizeof(double2);
+  if (!h->d_stage_v) {
+    HIPCHK(hipMalloc((void**)&h->d_stage_v, bytes));
+    HIPCHK(hipMalloc((void**)&h->d_stage_hv, bytes));
+    h->device_bytes += 2 * (int64_t)bytes;
+  }
+  HIPCHK(hipMemcpyAsync(h->d_stage_v, v, bytes, hipMemcpyHostToDevice, h->stream));
+  int rc = hxv_apply_device(h, h->d_stage_v, h->d_stage_hv, h->stream);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(hv, h->d_stage_hv, bytes, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return HXV_OK;
+}
+
+int hxv_time_apply(hxv_handle* h, const void* d_v_full, void* d_hv_local, int32_t nrep, float* ms_per_apply) {
+  if (!h || nrep < 1 || !ms_per_apply) return fail(HXV_ERR_ARG, "hxv_time_apply: bad argument");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipEventRecord(h->ev0, h->stream));
+  for (int i = 0; i < nrep; ++i) {
+    int rc = hxv_apply_device(h, d_v_full, d_hv_local, h->stream);
+    if (rc) return rc;
+  }
+  HIPCHK(hipEventRecord(h->ev1, h->stream));
+  HIPCHK(hipEventSynchronize(h->ev1));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  *ms_per_apply = ms / (float)nrep;
+  return HXV_OK;
+}
+
+int hxv_get_maps(const hxv_handle* h, int32_t* map_up, int32_t* map_dw) {
+  if (!h) return fail(HXV_ERR_ARG, "NULL handle");
+  if (h->host.map_up.empty()) return fail(HXV_ERR_STATE, "handle built from CSR has no basis maps");
+  if (map_up) std::copy(h->host.map_up.begin(), h->host.map_up.end(), map_up);
+  if (map_dw) std::copy(h->host.map_dw.begin(), h->host.map_dw.end(), map_dw);
+  return HXV_OK;
+}
+
+int64_t hxv_nnz(const hxv_handle* h, int32_t which) {
+  if (!h || which < 0 || which > 1) return -1;
+  const SpinOp& op = which == 0 ? h->host.up : h->host.dw;
+  return op.rowptr.empty() ? 0 : op.rowptr.back();
+}
+
+int hxv_get_csr(const hxv_handle* h, int32_t which, int64_t* rowptr, int32_t* cols, double* vals) {
+  if (!h || which < 0 || which > 1 || !rowptr || !cols || !vals) return fail(HXV_ERR_ARG, "hxv_get_csr: bad argument");
+  const SpinOp& op = which == 0 ? h->host.up : h->host.dw;
+  std::copy(op.rowptr.begin(), op.rowptr.end(), rowptr);
+  for (size_t p = 0; p < op.cols.size(); ++p) {
+    cols[p] = op.cols[p] + 1;
+    vals[2 * p] = op.vals[p].real();
+    vals[2 * p + 1] = op.vals[p].imag();
+  }
+  return HXV_OK;
+}
+
+int hxv_get_diag(const hxv_handle* h, double* diag) {
+  if (!h || !diag) return fail(HXV_ERR_ARG, "hxv_get_diag: bad argument");
+  const SectorHost& s = h->host;
+  for (int c = 0; c < s.qdw; ++c)
+    for (int i = 0; i < s.dimup; ++i) diag[(size_t)i + (size_t)c * s.dimup] = host_diag_element(s, i, c + s.dw0);
+  return HXV_OK;
+}
+
+int hxv_set_option(hxv_handle* h, const char* name, int64_t value) {
+  if (!h || !name) return fail(HXV_ERR_ARG, "hxv_set_option: NULL");
+  if (!strcmp(name, "kernel")) {
+    if (value < 0 || value > 1) return fail(HXV_ERR_ARG, "kernel must be 0 or 1");
+    h->kernel = (int)value;
+    return HXV_OK;
+  }
+  if (!strcmp(name, "passes")) {
+    if (value < 1 || value > 3) return fail(HXV_ERR_ARG, "passes must be 1, 2 or 3");
+    h->plan.opt.passes = (int)value;
+    return HXV_OK;
+  }
+  // tiling knobs: rebuild the plan (old tables stay allocated until hxv_destroy)
+  TileOptions o = h->plan.opt;
+  if (!strcmp(name, "cols_per_tile")) o.cols_per_tile = (int)value;
+  else if (!strcmp(name, "rows_per_tile")) o.rows_per_tile = (int)value;
+  else if (!strcmp(name, "lds_budget_kb")) o.lds_budget_kb = (int)value;
+  else if (!strcmp(name, "tile_bits_up")) o.force_bits_up = (int)value;
+  else if (!strcmp(name, "tile_bits_dw")) o.force_bits_dw = (int)value;
+  else if (!strcmp(name, "threads_up")) o.threads_up = (int)value;
+  else if (!strcmp(name, "threads_dw")) o.threads_dw = (int)value;
+  else return fail(HXV_ERR_ARG, std::string("unknown option ") + name);
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  TilePlan np;
+  np.opt = o;
+  std::string perr = make_tile_plan(h->host, np, [&](const std::vector<uint32_t>& v, uint32_t** p) { return h->upload(p, v); });
+  if (!perr.empty()) return fail(HXV_ERR_ARG, perr);
+  h->plan = np;
+  return HXV_OK;
+}
+
+int64_t hxv_get_option(const hxv_handle* h, const char* name) {
+  if (!h || !name) return -1;
+  if (!strcmp(name, "kernel")) return h->kernel;
+  if (!strcmp(name, "tile_bits_up")) return h->plan.up.lowbits;
+  if (!strcmp(name, "tile_bits_dw")) return h->plan.dw.lowbits;
+  if (!strcmp(name, "cols_per_tile")) return h->plan.opt.cols_per_tile;
+  if (!strcmp(name, "rows_per_tile")) return h->plan.opt.rows_per_tile;
+  if (!strcmp(name, "lds_budget_kb")) return h->plan.opt.lds_budget_kb;
+  if (!strcmp(name, "k_in_up")) return h->plan.up.k_in;
+  if (!strcmp(name, "k_out_up")) return h->plan.up.k_out;
+  if (!strcmp(name, "k_in_dw")) return h->plan.dw.k_in;
+  if (!strcmp(name, "k_out_dw")) return h->plan.dw.k_out;
+  if (!strcmp(name, "n_in_up")) return h->plan.up.n_in;
+  if (!strcmp(name, "n_out_up")) return h->plan.up.n_out;
+  if (!strcmp(name, "n_in_dw")) return h->plan.dw.n_in;
+  if (!strcmp(name, "n_out_dw")) return h->plan.dw.n_out;
+  if (!strcmp(name, "nblocks_up")) return h->plan.up.nblocks;
+  if (!strcmp(name, "nblocks_dw")) return h->plan.dw.nblocks;
+  return -1;
+}
+
+int hxv_get_stats(const hxv_handle* h, hxv_stats* out) {
+  if (!h || !out) return fail(HXV_ERR_ARG, "hxv_get_stats: NULL");
+  out->n_apply = h->n_apply;
+  out->algorithmic_bytes = 32 * (int64_t)h->host.qdw * h->host.dimup;
+  out->device_bytes = h->device_bytes;
+  out->kernel = h->kernel;
+  out->real_h = h->dev.real_h;
+  out->k_up = h->host.up.K;
+  out->k_dw = h->host.dw.K;
+  out->n_hops_up = (int)h->host.up.coef.size();
+  out->n_hops_dw = (int)h->host.dw.coef.size();
+  return HXV_OK;
+}
+
+}  // extern "C"
+
+// ===========================================================================================
+// Device Lanczos
+// ===========================================================================================
+namespace {
+
+// w -= b*qm ; partial sums of Re<q,w>
+__global__ void __launch_bounds__(256) lz_sub_dot(int64_t n, double2* __restrict__ w, const double2* __restrict__ qm,
+                                                  const double2* __restrict__ q, const double* __restrict__ scal, int ib,
+                                                  double* __restrict__ partial) {
+  const double b = ib >= 0 ? scal[ib] : 0.0;
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double2 x = w[i];
+    if (ib >= 0) {
+      double2 p = qm[i];
+      x.x -= b * p.x;
+      x.y -= b * p.y;
+      w[i] = x;
+    }
+    double2 y = q[i];
+    acc += y.x * x.x + y.y * x.y;
+  }
+  __shared__ double red[256];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+// w -= a*q ; partial sums of |w|^2
+__global__ void __launch_bounds__(256) lz_sub_nrm(int64_t n, double2* __restrict__ w, const double2* __restrict__ q,
+                                                  const double* __restrict__ scal, int ia, double* __restrict__ partial) {
+  const double a = scal[ia];
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double2 x = w[i], y = q[i];
+    x.x -= a * y.x;
+    x.y -= a * y.y;
+    w[i] = x;
+    acc += x.x * x.x + x.y * x.y;
+  }
+  __shared__ double red[256];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+// partial sums of |x|^2
+__global__ void __launch_bounds__(256) lz_nrm(int64_t n, const double2* __restrict__ x, double* __restrict__ partial) {
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double2 a = x[i];
+    acc += a.x * a.x + a.y * a.y;
+  }
+  __shared__ double red[256];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+// scal[io] = op(sum partial[0..np))   op: 0 identity, 1 sqrt
+__global__ void __launch_bounds__(256) lz_final(const double* __restrict__ partial, int np, double* __restrict__ scal, int io, int op) {
+  __shared__ double red[256];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < np; i += 256) acc += partial[i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) scal[io] = op ? sqrt(red[0]) : red[0];
+}
+
+// q = w / scal[ib]
+__global__ void __launch_bounds__(256) lz_scale(int64_t n, double2* q, const double2* w,
+                                                const double* __restrict__ scal, int ib) {
+  const double r = 1.0 / scal[ib];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double2 x = w[i];
+    q[i] = make_double2(x.x * r, x.y * r);
+  }
+}
+
+// y += c * q   (c real, host scalar)
+__global__ void __launch_bounds__(256) lz_axpy(int64_t n, double2* __restrict__ y, const double2* __restrict__ q, double c) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double2 x = q[i], z = y[i];
+    y[i] = make_double2(z.x + c * x.x, z.y + c * x.y);
+  }
+}
+
+// deterministic start vector: splitmix64 hash of the global index -> uniform(-0.5,0.5) re and im
+__global__ void __launch_bounds__(256) lz_init(int64_t n, double2* __restrict__ q, uint64_t seed) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    uint64_t z = (uint64_t)i * 2 + seed;
+    double r[2];
+    for (int k = 0; k < 2; ++k) {
+      uint64_t x = z + (uint64_t)k + 0x9E3779B97F4A7C15ull;
+      x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+      x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+      x = x ^ (x >> 31);
+      r[k] = (double)(x >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+    }
+    q[i] = make_double2(r[0], r[1]);
+  }
+}
+
+int grid_for(int64_t n) { return (int)std::min<int64_t>((n + 255) / 256, RED_BLOCKS); }
+
+// Symmetric tridiagonal eigen-solver (implicit QL with Wilkinson shifts): d[n] diagonal,
+// e[n] sub-diagonal in e[1..n-1] (e[0] unused).  On exit d = eigenvalues (unsorted) and, if z,
+// z (n x n, column-major, initialised to identity by the caller) = eigenvectors.
+bool tridiag_ql(int n, std::vector<double>& d, std::vector<double>& e, std::vector<double>* z) {
+  for (int i = 1; i < n; ++i) e[i - 1] = e[i];
+  e[n - 1] = 0.0;
+  for (int l = 0; l < n; ++l) {
+    int iter = 0, m;
+    do {
+      for (m = l; m < n - 1; ++m) {
+        double dd = std::fabs(d[m]) + std::fabs(d[m + 1]);
+        if (std::fabs(e[m]) <= 2.3e-16 * dd) break;
+      }
+      if (m != l) {
+        if (iter++ == 200) return false;
+        double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+        double r = std::hypot(g, 1.0);
+        g = d[m] - d[l] + e[l] / (g + (g >= 0 ? std::fabs(r) : -std::fabs(r)));
+        double s = 1.0, c = 1.0, p = 0.0;
+        int i;
+        for (i = m - 1; i >= l; --i) {
+          double f = s * e[i], b = c * e[i];
+          r = std::hypot(f, g);
+          e[i + 1] = r;
+          if (r == 0.0) {
+            d[i + 1] -= p;
+            e[m] = 0.0;
+            break;
+          }
+          s = f / r;
+          c = g / r;
+          g = d[i + 1] - p;
+          r = (d[i] - g) * s + 2.0 * c * b;
+          p = s * r;
+          d[i + 1] = g + p;
+          g = c * r - b;
+          if (z)
+            for (int k = 0; k < n; ++k) {
+              double* zz = z->data();
+              f = zz[k + (size_t)(i + 1) * n];
+              zz[k + (size_t)(i + 1) * n] = s * zz[k + (size_t)i * n] + c * f;
+              zz[k + (size_t)i * n] = c * zz[k + (size_t)i * n] - s * f;
+            }
+        }
+        if (r == 0.0 && i >= l) continue;
+        d[l] -= p;
+        e[l] = g;
+        e[m] = 0.0;
+      }
+    } while (m != l);
+  }
+  return true;
+}
+
+struct LzBuf {
+  double2 *q, *qm, *w;
+};
+
+// One Lanczos step on device: w = H q - beta qm; alpha = <q,w>; w -= alpha q; beta' = |w|.
+// scal[0]=alpha, scal[1]=beta' (sqrt), scal[2]=previous beta.
+int lanczos_step(hxv_handle* h, LzBuf& b, bool first, double* alpha, double* beta) {
+  const int64_t n = h->host.dim;
+  const int g = grid_for(n);
+  int rc = hxv_apply_device(h, b.q, b.w, h->stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(lz_sub_dot, dim3(g), dim3(256), 0, h->stream, n, b.w, b.qm, b.q, h->d_scalars, first ? -1 : 2, h->d_partials);
+  hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_partials, g, h->d_scalars, 0, 0);
+  hipLaunchKernelGGL(lz_sub_nrm, dim3(g), dim3(256), 0, h->stream, n, b.w, b.q, h->d_scalars, 0, h->d_partials + RED_BLOCKS);
+  hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_partials + RED_BLOCKS, g, h->d_scalars, 1, 1);
+  double host[2];
+  HIPCHK(hipMemcpyAsync(host, h->d_scalars, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  *alpha = host[0];
+  *beta = host[1];
+  return HXV_OK;
+}
+
+// rotate: qm <- q, q <- w/beta  (scal[2] <- beta)
+int lanczos_advance(hxv_handle* h, LzBuf& b) {
+  const int64_t n = h->host.dim;
+  HIPCHK(hipMemcpyAsync(h->d_scalars + 2, h->d_scalars + 1, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  std::swap(b.q, b.qm);
+  hipLaunchKernelGGL(lz_scale, dim3(grid_for(n)), dim3(256), 0, h->stream, n, b.q, b.w, h->d_scalars, 2);
+  return HXV_OK;
+}
+
+int ensure_lz(hxv_handle* h) {
+  if (h->host.nranks != 1) return fail(HXV_ERR_STATE, "device Lanczos needs nranks==1 (global dots belong to the caller's communicator)");
+  HIPCHK(hipSetDevice(h->device));
+  for (auto& p : h->d_lz)
+    if (!p) {
+      HIPCHK(hipMalloc((void**)&p, (size_t)h->host.dim * sizeof(double2)));
+      h->device_bytes += h->host.dim * (int64_t)sizeof(double2);
+    }
+  return HXV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hxv_lanczos_tridiag(hxv_handle* h, const void* d_vin, int32_t nlanc, double* alanc, double* blanc, double threshold,
+                        int32_t* nsteps) {
+  if (!h || !d_vin || nlanc < 1 || !alanc || !blanc) return fail(HXV_ERR_ARG, "hxv_lanczos_tridiag: bad argument");
+  int rc = ensure_lz(h);
+  if (rc) return rc;
+  const int64_t n = h->host.dim;
+  LzBuf b{h->d_lz[0], h->d_lz[1], h->d_lz[2]};
+  HIPCHK(hipMemcpyAsync(b.q, d_vin, (size_t)n * sizeof(double2), hipMemcpyDeviceToDevice, h->stream));
+  for (int k = 0; k < nlanc; ++k) {
+    alanc[k] = 0;
+    blanc[k] = 0;
+  }
+  int k = 0;
+  for (; k < nlanc; ++k) {
+    double a, bt;
+    rc = lanczos_step(h, b, k == 0, &a, &bt);
+    if (rc) return rc;
+    alanc[k] = a;
+    if (k + 1 < nlanc) blanc[k + 1] = bt;
+    if (std::fabs(bt) < threshold) {
+      ++k;
+      break;
+    }
+    if (k + 1 < nlanc) {
+      rc = lanczos_advance(h, b);
+      if (rc) return rc;
+    }
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (nsteps) *nsteps = k;
+  return HXV_OK;
+}
+
+int hxv_lanczos_eigh(hxv_handle* h, int32_t nitermax, double threshold, double* egs, void* d_vect, int32_t* niter) {
+  if (!h || nitermax < 1 || !egs) return fail(HXV_ERR_ARG, "hxv_lanczos_eigh: bad argument");
+  int rc = ensure_lz(h);
+  if (rc) return rc;
+  const int64_t n = h->host.dim;
+  const int g = grid_for(n);
+  const int nmax = (int)std::min<int64_t>(nitermax, n);
+  LzBuf b{h->d_lz[0], h->d_lz[1], h->d_lz[2]};
+  const uint64_t seed = 0x5EED5EEDull;
+  auto start = [&]() -> int {
+    hipLaunchKernelGGL(lz_init, dim3(g), dim3(256), 0, h->stream, n, b.w, seed);
+    // normalise: scal[1] = |w|, then q = w/scal[1] via advance-like scale
+    HIPCHK(hipMemsetAsync(h->d_scalars, 0, 8 * sizeof(double), h->stream));
+    hipLaunchKernelGGL(lz_nrm, dim3(g), dim3(256), 0, h->stream, n, b.w, h->d_partials + RED_BLOCKS);
+    hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_partials + RED_BLOCKS, g, h->d_scalars, 1, 1);
+    hipLaunchKernelGGL(lz_scale, dim3(g), dim3(256), 0, h->stream, n, b.q, b.w, h->d_scalars, 1);
+    return HXV_OK;
+  };
+  rc = start();
+  if (rc) return rc;
+  std::vector<double> al, be(1, 0.0);
+  double e_old = 1e300, e_new = 0;
+  int k = 0;
+  std::vector<double> d, e;
+  for (; k < nmax; ++k) {
+    double a, bt;
+    rc = lanczos_step(h, b, k == 0, &a, &bt);
+    if (rc) return rc;
+    al.push_back(a);
+    d = al;
+    e = be;
+    if (!tridiag_ql((int)d.size(), d, e, nullptr)) return fail(HXV_ERR_STATE, "tridiagonal QL did not converge");
+    e_new = *std::min_element(d.begin(), d.end());
+    bool conv = std::fabs(e_new - e_old) < threshold;
+    e_old = e_new;
+    if (conv || std::fabs(bt) < 1e-14 || k + 1 == nmax) {
+      ++k;
+      break;
+    }
+    be.push_back(bt);
+    rc = lanczos_advance(h, b);
+    if (rc) return rc;
+  }
+  *egs = e_new;
+  if (niter) *niter = k;
+  if (d_vect) {
+    // second pass: re-run the recurrence and accumulate the Ritz vector y_j q_j
+    const int m = (int)al.size();
+    d = al;
+    e = be;
+    e.resize(m, 0.0);
+    std::vector<double> z((size_t)m * m, 0.0);
+    for (int i = 0; i < m; ++i) z[i + (size_t)i * m] = 1.0;
+    if (!tridiag_ql(m, d, e, &z)) return fail(HXV_ERR_STATE, "tridiagonal QL did not converge");
+    int jmin = (int)(std::min_element(d.begin(), d.end()) - d.begin());
+    const double* y = &z[(size_t)jmin * m];
+    double2* out = (double2*)d_vect;
+    b = LzBuf{h->d_lz[0], h->d_lz[1], h->d_lz[2]};
+    rc = start();
+    if (rc) return rc;
+    HIPCHK(hipMemsetAsync(out, 0, (size_t)n * sizeof(double2), h->stream));
+    for (int j = 0; j < m; ++j) {
+      hipLaunchKernelGGL(lz_axpy, dim3(g), dim3(256), 0, h->stream, n, out, b.q, y[j]);
+      if (j + 1 == m) break;
+      double a, bt;
+      rc = lanczos_step(h, b, j == 0, &a, &bt);
+      if (rc) return rc;
+      rc = lanczos_advance(h, b);
+      if (rc) return rc;
+    }
+    // normalise the Ritz vector
+    hipLaunchKernelGGL(lz_nrm, dim3(g), dim3(256), 0, h->stream, n, out, h->d_partials + RED_BLOCKS);
+    hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_partials + RED_BLOCKS, g, h->d_scalars, 1, 1);
+    hipLaunchKernelGGL(lz_scale, dim3(g), dim3(256), 0, h->stream, n, out, out, h->d_scalars, 1);
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  return HXV_OK;
+}
+
+int hxv_time_lanczos(hxv_handle* h, void* d_work3, int32_t nrep, float* ms_per_iter) {
+  if (!h || !d_work3 || nrep < 1 || !ms_per_iter) return fail(HXV_ERR_ARG, "hxv_time_lanczos: bad argument");
+  if (h->host.nranks != 1) return fail(HXV_ERR_STATE, "hxv_time_lanczos needs nranks==1");
+  HIPCHK(hipSetDevice(h->device));
+  const int64_t n = h->host.dim;
+  LzBuf b{(double2*)d_work3, (double2*)d_work3 + n, (double2*)d_work3 + 2 * n};
+  const int g = grid_for(n);
+  hipLaunchKernelGGL(lz_init, dim3(g), dim3(256), 0, h->stream, n, b.w, 0x1234ull);
+  HIPCHK(hipMemsetAsync(h->d_scalars, 0, 8 * sizeof(double), h->stream));
+  hipLaunchKernelGGL(lz_nrm, dim3(g), dim3(256), 0, h->stream, n, b.w, h->d_partials + RED_BLOCKS);
+  hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_partials + RED_BLOCKS, g, h->d_scalars, 1, 1);
+  hipLaunchKernelGGL(lz_scale, dim3(g), dim3(256), 0, h->stream, n, b.q, b.w, h->d_scalars, 1);
+  HIPCHK(hipMemsetAsync(b.qm, 0, (size_t)n * sizeof(double2), h->stream));
+  HIPCHK(hipEventRecord(h->ev0, h->stream));
+  for (int k = 0; k < nrep; ++k) {
+    double a, bt;
+    int rc = lanczos_step(h, b, k == 0, &a, &bt);
+    if (rc) return rc;
+    rc = lanczos_advance(h, b);
+    if (rc) return rc;
+  }
+  HIPCHK(hipEventRecord(h->ev1, h->stream));
+  HIPCHK(hipEventSynchronize(h->ev1));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  *ms_per_iter = ms / (float)nrep;
+  return HXV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,104 @@
+// Internal declarations shared by the host-side sector builder, the HIP kernels and the C-ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <complex>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/hxv.h"
+
+namespace hxv {
+
+using cplx = std::complex<double>;
+
+// ---------------------------------------------------------------------------------------
+// ELL entry of a one-spin hopping matrix: 32 bits per stored element instead of the
+// reference's 16 B value + 4 B column (ED_SPARSE_MATRIX.f90:13-30).
+//   bits  0..19  source index (column of H_sigma), 0-based        (dim <= 2^20)
+//   bits 20..29  coefficient id into coef[] (|amplitude| table)   (<= 1023 ids)
+//   bit  31      sign: element = sign ? -coef[id] : coef[id]
+// 0xFFFFFFFF = empty slot.  Layout [k][row] so consecutive rows are consecutive words.
+// ---------------------------------------------------------------------------------------
+constexpr uint32_t ELL_EMPTY = 0xFFFFFFFFu;
+constexpr int ELL_SRC_BITS = 20;
+constexpr uint32_t ELL_SRC_MASK = (1u << ELL_SRC_BITS) - 1u;
+constexpr uint32_t ELL_COEF_MASK = 0x3FFu;
+constexpr int MAX_COEF = 1023;
+
+struct SpinOp {                 // H_up or H_dw on one spin sector
+  int dim = 0;
+  std::vector<int64_t> rowptr;  // CSR in the reference's row-list order
+  std::vector<int32_t> cols;    // 0-based
+  std::vector<cplx> vals;
+  int K = 0;                    // ELL width
+  std::vector<uint32_t> ell;    // [K][dim]
+  std::vector<cplx> coef;       // coefficient table
+  bool real_vals = true;
+};
+
+struct CrossParams {            // non-separable part of the diagonal (H_local.f90:35-50)
+  int32_t norb = 1, nlat = 0;
+  double uloc[5] = {0, 0, 0, 0, 0};
+  double ust = 0;
+  uint32_t orbmask[5] = {0, 0, 0, 0, 0};
+  uint32_t sitemask[16] = {0};
+};
+
+struct SectorHost {
+  int ns = 0, nup = 0, ndw = 0;
+  int dimup = 0, dimdw = 0;
+  int64_t dim = 0;
+  int rank = 0, nranks = 1, qdw = 0, dw0 = 0;
+  int64_t ishift = 0;
+  std::vector<uint32_t> map_up, map_dw;
+  SpinOp up, dw;
+  bool separable_diag = true;
+  std::vector<double> a_up, a_dw;  // separable diagonal tables
+  CrossParams cross;
+  std::vector<double> diag_stored; // from_csr path: explicit local diagonal
+};
+
+// host builders (hxv_sector.cpp); return "" on success, else an error message
+std::string build_sector_from_model(const hxv_model& m, int nup, int ndw, int rank, int nranks, SectorHost& out);
+std::string build_sector_from_csr(int dimup, int dimdw, const int64_t* up_rp, const int32_t* up_cols, const double* up_vals,
+                                  const int64_t* dw_rp, const int32_t* dw_cols, const double* dw_vals, const double* diag, int rank,
+                                  int nranks, SectorHost& out);
+std::string build_ell(SpinOp& op);
+void dw_split(int dimdw, int rank, int nranks, int& qdw, int& dw0);
+double host_diag_element(const SectorHost& s, int iup, int idw);
+
+// ---------------------------------------------------------------------------------------
+// device-side views (plain structs passed by value to kernels)
+// ---------------------------------------------------------------------------------------
+struct DevSpin {
+  const uint32_t* ell;   // [K][dim]
+  const double2* coef;   // [ncoef]
+  int K;
+  int dim;
+};
+
+struct DevDiag {
+  int mode;               // 0 separable (on the fly), 1 stored
+  const double* a_up;
+  const double* a_dw;
+  const uint32_t* map_up;
+  const uint32_t* map_dw;
+  const double* stored;   // local rows
+  CrossParams cross;
+};
+
+struct DevSector {
+  DevSpin up, dw;
+  DevDiag diag;
+  int dimup, dimdw;
+  int qdw, dw0;           // local columns [dw0, dw0+qdw)
+  int real_h;
+};
+
+// kernel launchers (hxv_kernels.hip)
+struct TilePlan;  // opaque tiling data for the two-pass kernels
+hipError_t launch_hxv_naive(const DevSector& s, const double2* v_full, double2* hv_local, hipStream_t st);
+
+}  // namespace hxv

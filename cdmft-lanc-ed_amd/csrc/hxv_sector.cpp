@@ -1,0 +1,344 @@
+// Host-side construction of a sector operator: basis maps, one-spin hopping tables (CSR in the
+// reference's row order + compact ELL for the device), separable diagonal.
+//
+// Semantics follow the reference's stored-sparse path (never its buggy "direct" path,
+// SURVEY.md 0.6):
+//   basis            ED_SETUP.f90:720-775        orbital p <-> bit p-1, ascending integers
+//   fermionic sign   ED_SETUP.f90:807-833        (-1)^(# occupied orbitals below pos)
+//   one-spin hops    ED_HAMILTONIAN/sparse/H_up.f90:1-89, H_dw.f90:1-89
+//   diagonal         ED_HAMILTONIAN/sparse/H_local.f90:1-102
+//   DimDw split      ED_HAMILTONIAN.f90:93-105
+// The construction itself is our own: the one-body part is first reduced to a list of directed
+// orbital hops (a <- b, amplitude), then applied to every basis state with bit arithmetic.
+#include <algorithm>
+#include <cmath>
+#include <map>
+
+#include "hxv_internal.hpp"
+
+namespace hxv {
+
+namespace {
+
+int64_t binom(int n, int k) {
+  if (k < 0 || k > n) return 0;
+  k = std::min(k, n - k);
+  int64_t r = 1;
+  for (int i = 1; i <= k; ++i) r = r * (n - k + i) / i;
+  return r;
+}
+
+// ascending list of ns-bit integers with popcount n (Gosper's hack)
+std::vector<uint32_t> make_map(int ns, int n) {
+  std::vector<uint32_t> map;
+  map.reserve((size_t)binom(ns, n));
+  if (n == 0) {
+    map.push_back(0);
+    return map;
+  }
+  uint64_t x = (1ull << n) - 1, lim = 1ull << ns;
+  while (x < lim) {
+    map.push_back((uint32_t)x);
+    uint64_t c = x & (~x + 1), r = x + c;
+    x = (((r ^ x) >> 2) / c) | r;
+  }
+  return map;
+}
+
+struct Hop {
+  int a, b;  // a <- b (0-based orbitals)
+  cplx t;
+};
+
+// Fortran-order accessors of the model arrays (0-based arguments)
+struct ModelView {
+  const hxv_model& m;
+  int L, S, O, B;
+  explicit ModelView(const hxv_model& mm) : m(mm), L(mm.nlat), S(mm.nspin), O(mm.norb), B(mm.nbath) {}
+  size_t i6(int il, int jl, int is, int js, int io, int jo) const {
+    return (size_t)il + (size_t)L * (jl + (size_t)L * (is + (size_t)S * (js + (size_t)S * (io + (size_t)O * jo))));
+  }
+  cplx hloc(int il, int jl, int s, int io, int jo) const {
+    size_t k = i6(il, jl, s, s, io, jo);
+    return cplx(m.imphloc[2 * k], m.imphloc[2 * k + 1]);
+  }
+  cplx hbath(int il, int jl, int s, int io, int jo, int ib) const {
+    size_t k = i6(il, jl, s, s, io, jo) + (size_t)L * L * S * S * O * O * ib;
+    return cplx(m.hbath[2 * k], m.hbath[2 * k + 1]);
+  }
+  double v(int il, int s, int io, int ib) const { return m.vbath[(size_t)il + (size_t)L * (s + (size_t)S * (io + (size_t)O * ib))]; }
+  int imp(int il, int io) const { return io + il * O; }                         // ED_SETUP.f90:563-568
+  int bath(int il, int io, int ib) const { return L * O + imp(il, io) + ib * L * O; }  // ED_SETUP.f90:367-375
+};
+
+// One-spin hop list in the reference's loop order (H_up.f90:8-28, :31-56, :60-87) and the
+// orbital energies that enter the diagonal (H_local.f90:22-28, :85-93).
+std::string one_body(const ModelView& mv, int spin, std::vector<Hop>& hops, std::vector<double>& eps) {
+  int ns = mv.L * mv.O * (mv.B + 1);
+  eps.assign(ns, 0.0);
+  hops.clear();
+  for (int il = 0; il < mv.L; ++il)
+    for (int jl = 0; jl < mv.L; ++jl)
+      for (int io = 0; io < mv.O; ++io)
+        for (int jo = 0; jo < mv.O; ++jo) {
+          cplx t = mv.hloc(il, jl, spin, io, jo);
+          int a = mv.imp(il, io), b = mv.imp(jl, jo);
+          if (a == b) {
+            if (t.imag() != 0.0) return "impHloc has a complex diagonal element: not Hermitian";
+            eps[a] = t.real();
+          } else if (t != cplx(0, 0)) {
+            hops.push_back({a, b, t});
+          }
+        }
+  for (int ib = 0; ib < mv.B; ++ib)
+    for (int il = 0; il < mv.L; ++il)
+      for (int jl = 0; jl < mv.L; ++jl)
+        for (int io = 0; io < mv.O; ++io)
+          for (int jo = 0; jo < mv.O; ++jo) {
+            cplx t = mv.hbath(il, jl, spin, io, jo, ib);
+            int a = mv.bath(il, io, ib), b = mv.bath(jl, jo, ib);
+            if (a == b)
+              eps[a] = t.real();  // bath_diag = DREAL(...), ED_HAMILTONIAN_SPARSE_HxV.f90:71
+            else if (t != cplx(0, 0))
+              hops.push_back({a, b, t});
+          }
+  for (int il = 0; il < mv.L; ++il)
+    for (int io = 0; io < mv.O; ++io)
+      for (int ib = 0; ib < mv.B; ++ib) {
+        double V = mv.v(il, spin, io, ib);
+        if (V == 0.0) continue;
+        int i = mv.imp(il, io), a = mv.bath(il, io, ib);
+        hops.push_back({a, i, cplx(V, 0)});  // imp occupied, bath empty -> bath
+        hops.push_back({i, a, cplx(V, 0)});  // bath occupied, imp empty -> imp
+      }
+  return "";
+}
+
+inline int parity_below(uint32_t m, int pos) { return __builtin_popcount(m & ((1u << pos) - 1u)) & 1; }
+
+// H_sigma(i,j) for all basis states: rows collect (j, value) in ascending j, i.e. the
+// reference's row-list order (it loops over the source state j outermost).
+void apply_hops(const std::vector<uint32_t>& map, const std::vector<Hop>& hops, SpinOp& op) {
+  int dim = (int)map.size();
+  op.dim = dim;
+  std::vector<std::vector<std::pair<int32_t, cplx>>> rows(dim);
+  for (int j = 0; j < dim; ++j) {
+    uint32_t m = map[j];
+    for (const Hop& h : hops) {
+      if (!((m >> h.b) & 1u) || ((m >> h.a) & 1u)) continue;
+      uint32_t m1 = m & ~(1u << h.b);
+      int sgn = parity_below(m, h.b) ^ parity_below(m1, h.a);
+      uint32_t m2 = m1 | (1u << h.a);
+      int i = (int)(std::lower_bound(map.begin(), map.end(), m2) - map.begin());
+      cplx val = sgn ? -h.t : h.t;
+      auto& r = rows[i];
+      bool dup = false;
+      for (auto& e : r)
+        if (e.first == j) {  // ED_SPARSE_MATRIX.f90:267-273: same (row,col) -> summed
+          e.second += val;
+          dup = true;
+          break;
+        }
+      if (!dup) r.emplace_back(j, val);
+    }
+  }
+  op.rowptr.assign(dim + 1, 0);
+  for (int i = 0; i < dim; ++i) op.rowptr[i + 1] = op.rowptr[i] + (int64_t)rows[i].size();
+  op.cols.resize((size_t)op.rowptr[dim]);
+  op.vals.resize((size_t)op.rowptr[dim]);
+  for (int i = 0; i < dim; ++i) {
+    int64_t p = op.rowptr[i];
+    for (auto& e : rows[i]) {
+      op.cols[p] = e.first;
+      op.vals[p] = e.second;
+      ++p;
+    }
+  }
+}
+
+}  // namespace
+
+void dw_split(int dimdw, int rank, int nranks, int& qdw, int& dw0) {
+  // ED_HAMILTONIAN.f90:93-105
+  int q = dimdw / nranks, rem = dimdw % nranks;
+  qdw = q + (rank < rem ? 1 : 0);
+  dw0 = rank * q + std::min(rank, rem);
+}
+
+std::string build_ell(SpinOp& op) {
+  if (op.dim > (1 << ELL_SRC_BITS)) return "spin-sector dimension exceeds 2^20 (ELL source index)";
+  std::map<std::pair<double, double>, int> ids;
+  op.coef.clear();
+  op.real_vals = true;
+  int K = 0;
+  for (int i = 0; i < op.dim; ++i) K = std::max<int>(K, (int)(op.rowptr[i + 1] - op.rowptr[i]));
+  op.K = K;
+  op.ell.assign((size_t)std::max(K, 1) * op.dim, ELL_EMPTY);
+  for (int i = 0; i < op.dim; ++i) {
+    int k = 0;
+    for (int64_t p = op.rowptr[i]; p < op.rowptr[i + 1]; ++p, ++k) {
+      cplx c = op.vals[p];
+      uint32_t sign = 0;
+      if (c.real() < 0 || (c.real() == 0 && c.imag() < 0)) {
+        c = -c;
+        sign = 1;
+      }
+      if (c.imag() != 0.0) op.real_vals = false;
+      auto key = std::make_pair(c.real(), c.imag());
+      auto it = ids.find(key);
+      int id;
+      if (it == ids.end()) {
+        id = (int)op.coef.size();
+        if (id >= MAX_COEF) return "more than 1023 distinct hopping amplitudes";
+        ids.emplace(key, id);
+        op.coef.push_back(c);
+      } else {
+        id = it->second;
+      }
+      op.ell[(size_t)k * op.dim + i] = (uint32_t)op.cols[p] | ((uint32_t)id << ELL_SRC_BITS) | (sign << 31);
+    }
+  }
+  if (op.coef.empty()) op.coef.push_back(cplx(0, 0));
+  return "";
+}
+
+std::string build_sector_from_model(const hxv_model& m, int nup, int ndw, int rank, int nranks, SectorHost& s) {
+  if (m.nlat < 1 || m.norb < 1 || m.nspin < 1 || m.nspin > 2 || m.nbath < 0) return "bad Nlat/Norb/Nspin/Nbath";
+  if (m.norb > 5) return "Norb > 5 (Uloc has 5 entries)";
+  if (m.nlat > 16) return "Nlat > 16";
+  if (!m.imphloc) return "imphloc is NULL";
+  if (m.nbath > 0 && (!m.hbath || !m.vbath)) return "hbath/vbath is NULL with Nbath>0";
+  int ns = m.nlat * m.norb * (m.nbath + 1);
+  if (ns > 24) return "Ns > 24";
+  if (nup < 0 || nup > ns || ndw < 0 || ndw > ns) return "nup/ndw outside [0,Ns]";
+  if (nranks < 1 || rank < 0 || rank >= nranks) return "bad rank/nranks";
+  if (m.norb > 1 && (m.jx != 0.0 || m.jp != 0.0))
+    return "spin-exchange / pair-hopping block spH0nd (Jx,Jp != 0 with Norb>1) is not implemented yet";
+  ModelView mv(m);
+  s.ns = ns; s.nup = nup; s.ndw = ndw;
+  s.map_up = make_map(ns, nup);
+  s.map_dw = make_map(ns, ndw);
+  s.dimup = (int)s.map_up.size();
+  s.dimdw = (int)s.map_dw.size();
+  s.dim = (int64_t)s.dimup * s.dimdw;
+  if (nranks > s.dimdw) return "nranks > DimDw: shrink the communicator first (ED_HAMILTONIAN.f90:63-89)";
+  s.rank = rank; s.nranks = nranks;
+  dw_split(s.dimdw, rank, nranks, s.qdw, s.dw0);
+  s.ishift = (int64_t)s.dw0 * s.dimup;
+
+  std::vector<Hop> hops_up, hops_dw;
+  std::vector<double> eps_up, eps_dw;
+  std::string e = one_body(mv, 0, hops_up, eps_up);          // spin index 1       (H_up.f90:14)
+  if (!e.empty()) return e;
+  e = one_body(mv, m.nspin - 1, hops_dw, eps_dw);            // spin index Nspin   (H_dw.f90:14)
+  if (!e.empty()) return e;
+  apply_hops(s.map_up, hops_up, s.up);
+  apply_hops(s.map_dw, hops_dw, s.dw);
+  e = build_ell(s.up);
+  if (!e.empty()) return e;
+  e = build_ell(s.dw);
+  if (!e.empty()) return e;
+
+  // ---- diagonal: D(iup,idw) = a_up[iup] + a_dw[idw] + cross(mup,mdw)   (H_local.f90:21-93)
+  const int L = m.nlat, O = m.norb, nimp = L * O;
+  const double Ust = m.ust, Upp = m.ust - m.jh;
+  double cst = 0.0;
+  if (m.hfmode) {
+    for (int il = 0; il < L; ++il)
+      for (int io = 0; io < O; ++io) cst += 0.25 * m.uloc[io];
+    if (O > 1)
+      for (int il = 0; il < L; ++il)
+        for (int io = 0; io < O; ++io)
+          for (int jo = io + 1; jo < O; ++jo) cst += 0.25 * Ust + 0.25 * Upp;
+  }
+  auto one_spin_diag = [&](uint32_t mm, const std::vector<double>& eps) {
+    double d = 0.0;
+    for (int p = 0; p < ns; ++p)
+      if ((mm >> p) & 1u) d += eps[p] - (p < nimp ? m.xmu : 0.0);
+    for (int il = 0; il < L; ++il) {
+      for (int io = 0; io < O; ++io) {
+        double ni = (mm >> mv.imp(il, io)) & 1u;
+        if (m.hfmode) d -= 0.5 * m.uloc[io] * ni;
+        for (int jo = io + 1; jo < O; ++jo) {
+          double nj = (mm >> mv.imp(il, jo)) & 1u;
+          d += Upp * ni * nj;
+          if (m.hfmode) d -= 0.5 * (Ust + Upp) * (ni + nj);
+        }
+      }
+    }
+    return d;
+  };
+  s.separable_diag = true;
+  s.a_up.resize(s.dimup);
+  s.a_dw.resize(s.dimdw);
+  for (int i = 0; i < s.dimup; ++i) s.a_up[i] = one_spin_diag(s.map_up[i], eps_up) + cst;
+  for (int i = 0; i < s.dimdw; ++i) s.a_dw[i] = one_spin_diag(s.map_dw[i], eps_dw);
+  s.cross = CrossParams();
+  s.cross.norb = O;
+  s.cross.nlat = L;
+  s.cross.ust = (O > 1) ? Ust : 0.0;
+  for (int io = 0; io < O; ++io) {
+    s.cross.uloc[io] = m.uloc[io];
+    for (int il = 0; il < L; ++il) s.cross.orbmask[io] |= 1u << mv.imp(il, io);
+  }
+  for (int il = 0; il < L; ++il)
+    for (int io = 0; io < O; ++io) s.cross.sitemask[il] |= 1u << mv.imp(il, io);
+  return "";
+}
+
+double host_diag_element(const SectorHost& s, int iup, int idw) {
+  if (!s.separable_diag) return s.diag_stored[(size_t)iup + (size_t)(idw - s.dw0) * s.dimup];
+  uint32_t mu = s.map_up[iup], md = s.map_dw[idw], both = mu & md;
+  double d = s.a_up[iup] + s.a_dw[idw];
+  for (int io = 0; io < s.cross.norb; ++io) d += s.cross.uloc[io] * __builtin_popcount(both & s.cross.orbmask[io]);
+  if (s.cross.norb > 1)
+    for (int il = 0; il < s.cross.nlat; ++il) {
+      uint32_t sm = s.cross.sitemask[il];
+      d += s.cross.ust * (__builtin_popcount(mu & sm) * __builtin_popcount(md & sm) - __builtin_popcount(both & sm));
+    }
+  return d;
+}
+
+std::string build_sector_from_csr(int dimup, int dimdw, const int64_t* up_rp, const int32_t* up_cols, const double* up_vals,
+                                  const int64_t* dw_rp, const int32_t* dw_cols, const double* dw_vals, const double* diag, int rank,
+                                  int nranks, SectorHost& s) {
+  if (dimup < 1 || dimdw < 1) return "bad DimUp/DimDw";
+  if (!up_rp || !dw_rp || !diag) return "NULL CSR/diag pointer";
+  if (nranks < 1 || rank < 0 || rank >= nranks || nranks > dimdw) return "bad rank/nranks";
+  s.ns = 0; s.nup = s.ndw = -1;
+  s.dimup = dimup; s.dimdw = dimdw;
+  s.dim = (int64_t)dimup * dimdw;
+  s.rank = rank; s.nranks = nranks;
+  dw_split(dimdw, rank, nranks, s.qdw, s.dw0);
+  s.ishift = (int64_t)s.dw0 * dimup;
+  auto load = [](int dim, const int64_t* rp, const int32_t* cols, const double* vals, SpinOp& op) -> std::string {
+    op.dim = dim;
+    op.rowptr.assign(rp, rp + dim + 1);
+    if (op.rowptr[0] != 0) return "rowptr[0] != 0";
+    int64_t nnz = op.rowptr[dim];
+    op.cols.resize((size_t)nnz);
+    op.vals.resize((size_t)nnz);
+    for (int i = 0; i < dim; ++i)
+      if (op.rowptr[i + 1] < op.rowptr[i]) return "rowptr not monotone";
+    for (int64_t p = 0; p < nnz; ++p) {
+      if (cols[p] < 1 || cols[p] > dim) return "column index outside [1,dim]";
+      op.cols[p] = cols[p] - 1;
+      op.vals[p] = cplx(vals[2 * p], vals[2 * p + 1]);
+    }
+    return build_ell(op);
+  };
+  std::string e = load(dimup, up_rp, up_cols, up_vals, s.up);
+  if (!e.empty()) return "H_up: " + e;
+  e = load(dimdw, dw_rp, dw_cols, dw_vals, s.dw);
+  if (!e.empty()) return "H_dw: " + e;
+  s.separable_diag = false;
+  size_t nloc = (size_t)s.qdw * dimup;
+  s.diag_stored.resize(nloc);
+  for (size_t i = 0; i < nloc; ++i) {
+    if (diag[2 * i + 1] != 0.0) return "complex diagonal element: not Hermitian";
+    s.diag_stored[i] = diag[2 * i];
+  }
+  return "";
+}
+
+}  // namespace hxv

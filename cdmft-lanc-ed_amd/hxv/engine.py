@@ -1,0 +1,263 @@
+"""ctypes binding of libhxv.so (include/hxv.h) -- the only compute path of this package.
+
+There is deliberately no CPU fallback: if the HIP library is missing or no GPU is present,
+every entry point raises.  PyTorch is used only as plumbing (device buffers, streams,
+torch.distributed); the arithmetic lives in csrc/*.hip.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+_PKG = Path(__file__).resolve().parent.parent
+LIB_PATH = _PKG / "lib" / "libhxv.so"
+
+
+class HxvError(RuntimeError):
+    pass
+
+
+class _Model(C.Structure):
+    _fields_ = [
+        ("nlat", C.c_int32), ("norb", C.c_int32), ("nspin", C.c_int32), ("nbath", C.c_int32),
+        ("hfmode", C.c_int32), ("reserved", C.c_int32),
+        ("uloc", C.c_double * 5),
+        ("ust", C.c_double), ("jh", C.c_double), ("jx", C.c_double), ("jp", C.c_double), ("xmu", C.c_double),
+        ("imphloc", C.c_void_p), ("hbath", C.c_void_p), ("vbath", C.c_void_p),
+    ]
+
+
+class _Stats(C.Structure):
+    _fields_ = [
+        ("n_apply", C.c_int64), ("algorithmic_bytes", C.c_int64), ("device_bytes", C.c_int64),
+        ("kernel", C.c_int32), ("real_h", C.c_int32), ("k_up", C.c_int32), ("k_dw", C.c_int32),
+        ("n_hops_up", C.c_int32), ("n_hops_dw", C.c_int32),
+    ]
+
+
+# every symbol include/hxv.h declares (tests check that the library exports all of them)
+EXPORTS = [
+    "hxv_create_from_model", "hxv_create_from_csr", "hxv_destroy", "hxv_vecdim", "hxv_dims", "hxv_apply_host",
+    "hxv_apply_device", "hxv_time_apply", "hxv_lanczos_tridiag", "hxv_lanczos_eigh", "hxv_time_lanczos", "hxv_get_maps",
+    "hxv_nnz", "hxv_get_csr", "hxv_get_diag", "hxv_set_option", "hxv_get_option", "hxv_get_stats", "hxv_last_error",
+    "hxv_version",
+]
+
+_lib = None
+
+
+def load_library():
+    """Load libhxv.so; raises HxvError (never falls back) if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    # torch first: it bundles its own ROCm runtime (same SONAMEs as /opt/rocm); loading it first
+    # guarantees one HIP runtime per process whichever order the caller imports things in.
+    import torch  # noqa: F401
+
+    if not LIB_PATH.exists():
+        raise HxvError(f"{LIB_PATH} not found: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950); "
+                       "this package has no CPU fallback")
+    L = C.CDLL(str(LIB_PATH))
+    vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    pd, pi32, pi64 = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+    L.hxv_create_from_model.argtypes = [C.POINTER(_Model), i32, i32, i32, i32, i32, C.POINTER(vp)]
+    L.hxv_create_from_csr.argtypes = [i32, i32, pi64, pi32, pd, pi64, pi32, pd, pd, i32, i32, i32, C.POINTER(vp)]
+    L.hxv_destroy.argtypes = [vp]
+    L.hxv_vecdim.argtypes = [vp]
+    L.hxv_vecdim.restype = i64
+    L.hxv_dims.argtypes = [vp, pi32, pi32, pi64, pi32, pi64]
+    L.hxv_apply_host.argtypes = [vp, i64, vp, vp]
+    L.hxv_apply_device.argtypes = [vp, vp, vp, vp]
+    L.hxv_time_apply.argtypes = [vp, vp, vp, i32, C.POINTER(C.c_float)]
+    L.hxv_lanczos_tridiag.argtypes = [vp, vp, i32, pd, pd, dbl, pi32]
+    L.hxv_lanczos_eigh.argtypes = [vp, i32, dbl, pd, vp, pi32]
+    L.hxv_time_lanczos.argtypes = [vp, vp, i32, C.POINTER(C.c_float)]
+    L.hxv_get_maps.argtypes = [vp, pi32, pi32]
+    L.hxv_nnz.argtypes = [vp, i32]
+    L.hxv_nnz.restype = i64
+    L.hxv_get_csr.argtypes = [vp, i32, pi64, pi32, pd]
+    L.hxv_get_diag.argtypes = [vp, pd]
+    L.hxv_set_option.argtypes = [vp, C.c_char_p, i64]
+    L.hxv_get_option.argtypes = [vp, C.c_char_p]
+    L.hxv_get_option.restype = i64
+    L.hxv_get_stats.argtypes = [vp, C.POINTER(_Stats)]
+    L.hxv_last_error.restype = C.c_char_p
+    L.hxv_version.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def _chk(rc: int, what: str):
+    if rc != 0:
+        msg = load_library().hxv_last_error().decode()
+        raise HxvError(f"{what} failed (status {rc}): {msg}")
+
+
+def _p(a: np.ndarray, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+class HxvSector:
+    """An open sector on one GPU: the device-side replacement of the state that
+    build_Hv_sector leaves in ED_HAMILTONIAN_COMMON.f90:11-20 + spH0d/spH0ups/spH0dws."""
+
+    def __init__(self, handle, keep=None):
+        self._h = handle
+        self._keep = keep
+        L = load_library()
+        du, dd, q = C.c_int32(), C.c_int32(), C.c_int32()
+        dim, ish = C.c_int64(), C.c_int64()
+        _chk(L.hxv_dims(self._h, C.byref(du), C.byref(dd), C.byref(dim), C.byref(q), C.byref(ish)), "hxv_dims")
+        self.DimUp, self.DimDw, self.Dim, self.mpiQdw, self.mpiIshift = du.value, dd.value, dim.value, q.value, ish.value
+        self.vecDim = L.hxv_vecdim(self._h)
+
+    # -- constructors ---------------------------------------------------------------------
+    @classmethod
+    def from_model(cls, model, nup: int, ndw: int, rank: int = 0, nranks: int = 1, device: int = 0) -> "HxvSector":
+        L = load_library()
+        m = _Model()
+        m.nlat, m.norb, m.nspin, m.nbath = model.Nlat, model.Norb, model.Nspin, model.Nbath
+        m.hfmode = int(bool(model.hfmode))
+        for i in range(5):
+            m.uloc[i] = float(model.Uloc[i])
+        m.ust, m.jh, m.jx, m.jp, m.xmu = float(model.Ust), float(model.Jh), float(model.Jx), float(model.Jp), float(model.xmu)
+        h = np.ascontiguousarray(model.impHloc.ravel(order="F")).view(np.float64)
+        hb = np.ascontiguousarray(model.Hbath.ravel(order="F")).view(np.float64)
+        vb = np.ascontiguousarray(model.Vbath.ravel(order="F"))
+        m.imphloc = h.ctypes.data
+        m.hbath = hb.ctypes.data if model.Nbath > 0 else None
+        m.vbath = vb.ctypes.data if model.Nbath > 0 else None
+        out = C.c_void_p()
+        _chk(L.hxv_create_from_model(C.byref(m), nup, ndw, rank, nranks, device, C.byref(out)), "hxv_create_from_model")
+        return cls(out, keep=(h, hb, vb))
+
+    @classmethod
+    def from_csr(cls, DimUp, DimDw, up, dw, diag, rank: int = 0, nranks: int = 1, device: int = 0) -> "HxvSector":
+        """up/dw = (rowptr int64, cols int32 1-based, vals complex128) as dumped from spH0ups(1)/spH0dws(1);
+        diag = local rows of spH0d (complex128)."""
+        L = load_library()
+        arrs = []
+        for rp, cols, vals in (up, dw):
+            arrs += [np.ascontiguousarray(rp, dtype=np.int64), np.ascontiguousarray(cols, dtype=np.int32),
+                     np.ascontiguousarray(vals, dtype=np.complex128).view(np.float64)]
+        dg = np.ascontiguousarray(diag, dtype=np.complex128).view(np.float64)
+        out = C.c_void_p()
+        _chk(L.hxv_create_from_csr(DimUp, DimDw, _p(arrs[0], C.c_int64), _p(arrs[1], C.c_int32), _p(arrs[2], C.c_double),
+                                   _p(arrs[3], C.c_int64), _p(arrs[4], C.c_int32), _p(arrs[5], C.c_double), _p(dg, C.c_double),
+                                   rank, nranks, device, C.byref(out)), "hxv_create_from_csr")
+        return cls(out)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load_library().hxv_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- the product ----------------------------------------------------------------------
+    def apply_host(self, v: np.ndarray, hv: np.ndarray | None = None) -> np.ndarray:
+        """spHtimesV_p(Nloc,v,Hv) on host arrays (two PCIe copies per call)."""
+        v = np.ascontiguousarray(v, dtype=np.complex128)
+        if hv is None:
+            hv = np.empty_like(v)
+        assert hv.dtype == np.complex128 and hv.flags.c_contiguous
+        _chk(load_library().hxv_apply_host(self._h, v.size, v.ctypes.data, hv.ctypes.data), "hxv_apply_host")
+        return hv
+
+    def apply_device(self, v_full, hv_local=None, stream=None):
+        """Device-resident product on torch complex128 CUDA tensors. v_full: Dim elements
+        (all-gathered for nranks>1), hv_local: vecDim elements.  Runs on torch's current stream."""
+        import torch
+
+        assert v_full.is_cuda and v_full.dtype == torch.complex128 and v_full.is_contiguous() and v_full.numel() == self.Dim
+        if hv_local is None:
+            hv_local = torch.empty(self.vecDim, dtype=torch.complex128, device=v_full.device)
+        assert hv_local.is_cuda and hv_local.dtype == torch.complex128 and hv_local.is_contiguous() and hv_local.numel() == self.vecDim
+        st = torch.cuda.current_stream(v_full.device).cuda_stream if stream is None else stream
+        _chk(load_library().hxv_apply_device(self._h, v_full.data_ptr(), hv_local.data_ptr(), st), "hxv_apply_device")
+        return hv_local
+
+    def time_apply(self, v_full, hv_local, nrep: int) -> float:
+        """Mean ms per product over nrep launches, HIP events on the launch stream."""
+        import torch
+
+        torch.cuda.synchronize()
+        ms = C.c_float()
+        _chk(load_library().hxv_time_apply(self._h, v_full.data_ptr(), hv_local.data_ptr(), nrep, C.byref(ms)), "hxv_time_apply")
+        return ms.value
+
+    # -- Lanczos ---------------------------------------------------------------------------
+    def lanczos_tridiag(self, vin, nlanc: int, threshold: float = 1e-12):
+        """sp_lanc_tridiag(MatVec, vin, alanc, blanc): vin = normalised torch CUDA vector."""
+        import torch
+
+        assert vin.is_cuda and vin.dtype == torch.complex128 and vin.numel() == self.Dim
+        torch.cuda.synchronize()
+        a = np.zeros(nlanc)
+        b = np.zeros(nlanc)
+        n = C.c_int32()
+        _chk(load_library().hxv_lanczos_tridiag(self._h, vin.data_ptr(), nlanc, _p(a, C.c_double), _p(b, C.c_double), threshold,
+                                                C.byref(n)), "hxv_lanczos_tridiag")
+        return a, b, n.value
+
+    def lanczos_eigh(self, nitermax: int = 512, threshold: float = 1e-12, want_vector: bool = True):
+        """sp_lanc_eigh(MatVec, egs, vect, Nitermax, threshold): lowest eigenpair."""
+        import torch
+
+        torch.cuda.synchronize()
+        e = C.c_double()
+        n = C.c_int32()
+        vec = torch.empty(self.Dim, dtype=torch.complex128, device="cuda") if want_vector else None
+        _chk(load_library().hxv_lanczos_eigh(self._h, nitermax, threshold, C.byref(e), vec.data_ptr() if want_vector else None,
+                                             C.byref(n)), "hxv_lanczos_eigh")
+        return e.value, vec, n.value
+
+    def time_lanczos(self, nrep: int) -> float:
+        import torch
+
+        work = torch.empty(3 * self.Dim, dtype=torch.complex128, device="cuda")
+        torch.cuda.synchronize()
+        ms = C.c_float()
+        _chk(load_library().hxv_time_lanczos(self._h, work.data_ptr(), nrep, C.byref(ms)), "hxv_time_lanczos")
+        return ms.value
+
+    # -- introspection ---------------------------------------------------------------------
+    def maps(self):
+        mu = np.zeros(self.DimUp, dtype=np.int32)
+        md = np.zeros(self.DimDw, dtype=np.int32)
+        _chk(load_library().hxv_get_maps(self._h, _p(mu, C.c_int32), _p(md, C.c_int32)), "hxv_get_maps")
+        return mu, md
+
+    def csr(self, which: str):
+        w = {"up": 0, "dw": 1}[which]
+        n = self.DimUp if w == 0 else self.DimDw
+        nnz = load_library().hxv_nnz(self._h, w)
+        rp = np.zeros(n + 1, dtype=np.int64)
+        cols = np.zeros(max(nnz, 1), dtype=np.int32)
+        vals = np.zeros(2 * max(nnz, 1))
+        _chk(load_library().hxv_get_csr(self._h, w, _p(rp, C.c_int64), _p(cols, C.c_int32), _p(vals, C.c_double)), "hxv_get_csr")
+        return rp, cols[:nnz], vals.view(np.complex128)[:nnz]
+
+    def diag(self) -> np.ndarray:
+        d = np.zeros(self.vecDim)
+        _chk(load_library().hxv_get_diag(self._h, _p(d, C.c_double)), "hxv_get_diag")
+        return d
+
+    def set_option(self, name: str, value: int):
+        _chk(load_library().hxv_set_option(self._h, name.encode(), int(value)), f"hxv_set_option({name})")
+
+    def get_option(self, name: str) -> int:
+        return load_library().hxv_get_option(self._h, name.encode())
+
+    def stats(self) -> dict:
+        s = _Stats()
+        _chk(load_library().hxv_get_stats(self._h, C.byref(s)), "hxv_get_stats")
+        return {f: getattr(s, f) for f, _ in _Stats._fields_}

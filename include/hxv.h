@@ -1,0 +1,137 @@
+/*
+ * hxv.h -- C-ABI of the MI355X-native sector Hamiltonian x vector engine.
+ *
+ * This is the drop-in boundary for ONE path of QcmPlab/CDMFT-LANC-ED: the procedure
+ * pointer  spHtimesV_p  (abstract interface cc_sparse_HxV, ED_VARS_GLOBAL.f90:72-78,146)
+ * and the routines that open/close the sector it acts on (ED_HAMILTONIAN.f90:39-221).
+ * Plain pointers and sizes only; no C++/torch types.  Every entry returns 0 on success
+ * and a non-zero hxv_status otherwise (the reference's convention is `stop "..."`,
+ * e.g. ED_HAMILTONIAN_SPARSE_HxV.f90:57,247; the Fortran glue turns non-zero into stop).
+ *
+ * Vector layout (identical to the reference): element (iup,idw), 0-based, lives at
+ *   i = iup + idw*DimUp            (ED_HAMILTONIAN/sparse/H_local.f90:2-3)
+ * as complex(8) = two doubles (re,im).  A rank of an nranks-way split owns the contiguous
+ * columns idw in [dw0, dw0+qdw), qdw = DimDw/nranks (+1 for rank < mod(DimDw,nranks))
+ * (ED_HAMILTONIAN.f90:93-105), i.e. qdw*DimUp contiguous elements = vecDim_Hv_sector.
+ */
+#ifndef HXV_H
+#define HXV_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hxv_handle hxv_handle;
+
+enum hxv_status {
+  HXV_OK = 0,
+  HXV_ERR_ARG = 1,        /* bad argument / inconsistent sizes                          */
+  HXV_ERR_HIP = 2,        /* a HIP runtime call failed (no device, OOM, launch failure) */
+  HXV_ERR_STATE = 3,      /* handle not in the right state                              */
+  HXV_ERR_UNSUPPORTED = 4 /* valid input the engine does not implement                  */
+};
+
+/* Operator inputs = the reference's module globals visible at bind time.
+ * Complex arrays are interleaved (re,im) doubles in the reference's Fortran array order, so
+ * the Fortran glue passes c_loc() of the reference arrays themselves.                      */
+typedef struct {
+  int32_t nlat, norb, nspin, nbath; /* ED_INPUT_VARS.f90:13-16                            */
+  int32_t hfmode;                   /* ED_INPUT_VARS.f90:164 (logical -> 0/1)             */
+  int32_t reserved;
+  double uloc[5];                   /* ED_INPUT_VARS.f90:129                              */
+  double ust, jh, jx, jp, xmu;      /* ED_INPUT_VARS.f90:130-135                          */
+  const double *imphloc; /* complex (Nlat,Nlat,Nspin,Nspin,Norb,Norb)        ED_VARS_GLOBAL.f90:119 */
+  const double *hbath;   /* complex (Nlat,Nlat,Nspin,Nspin,Norb,Norb,Nbath)  = Hbath_build(lambda_ib),
+                            ED_HAMILTONIAN_SPARSE_HxV.f90:65; may be NULL if nbath==0      */
+  const double *vbath;   /* real (Nlat,Nspin,Norb,Nbath) = diag_hybr, ED_HAMILTONIAN_SPARSE_HxV.f90:70 */
+} hxv_model;
+
+/* ---- open / close a sector -------------------------------------------------------------
+ * Replaces build_Hv_sector(isector) (ED_HAMILTONIAN.f90:39-143) + ed_buildh_main
+ * (ED_HAMILTONIAN_SPARSE_HxV.f90:40-110): builds the sector maps, the one-spin hopping
+ * tables and the separable diagonal on the host, uploads them to HIP device `device`.
+ * (nup,ndw) = get_Nup/get_Ndw(isector) (ED_SETUP.f90:477-500). rank/nranks = the DimDw
+ * split of ED_HAMILTONIAN.f90:93-105 (nranks=1: serial, MpiStatus=F).                   */
+int hxv_create_from_model(const hxv_model *model, int32_t nup, int32_t ndw, int32_t rank, int32_t nranks, int32_t device,
+                          hxv_handle **out);
+
+/* Same, from the reference's own stored matrices (spH0ups(1), spH0dws(1), spH0d of
+ * ED_VARS_GLOBAL.f90:142-144) flattened to CSR: rowptr[n+1] (0-based offsets), cols (1-based,
+ * as stored by sp_insert_element ED_SPARSE_MATRIX.f90:254-322), vals interleaved complex.
+ * diag = the local rows of spH0d (qdw*DimUp complex values, one per row).                */
+int hxv_create_from_csr(int32_t dimup, int32_t dimdw, const int64_t *up_rowptr, const int32_t *up_cols, const double *up_vals,
+                        const int64_t *dw_rowptr, const int32_t *dw_cols, const double *dw_vals, const double *diag,
+                        int32_t rank, int32_t nranks, int32_t device, hxv_handle **out);
+
+/* delete_Hv_sector (ED_HAMILTONIAN.f90:149-190). NULL is a no-op. */
+int hxv_destroy(hxv_handle *h);
+
+/* vecDim_Hv_sector (ED_HAMILTONIAN.f90:197-221): local vector length DimUp*qdw. */
+int64_t hxv_vecdim(const hxv_handle *h);
+/* DimUp, DimDw, Dim, mpiQdw, mpiIshift (ED_HAMILTONIAN.f90:58-60,93-105); any out may be NULL */
+int hxv_dims(const hxv_handle *h, int32_t *dimup, int32_t *dimdw, int64_t *dim, int32_t *qdw, int64_t *ishift);
+
+/* ---- the product -----------------------------------------------------------------------
+ * spHtimesV_p(Nloc,v,Hv) with HOST arrays (cc_sparse_HxV, ED_VARS_GLOBAL.f90:72-78):
+ * Hv is overwritten (ED_HAMILTONIAN_SPARSE_HxV.f90:175,250); synchronous.  nranks==1 only
+ * (the MPI form needs the exchange, which lives with the caller's communicator: see
+ * hxv_apply_device and INTEGRATION.md).  Pays two PCIe copies per call.                 */
+int hxv_apply_host(hxv_handle *h, int64_t nloc, const void *v, void *hv);
+
+/* Device-resident product.  d_v_full: the FULL vector (Dim elements: for nranks>1 the
+ * all-gathered slabs in rank order = global column order), d_hv_local: this rank's slab
+ * (vecdim elements), overwritten.  Asynchronous on `stream` (a hipStream_t; NULL = the legacy
+ * default stream, as in every HIP API), so it orders with the caller's other work on that
+ * stream.  d_v_full and d_hv_local must not overlap.                                     */
+int hxv_apply_device(hxv_handle *h, const void *d_v_full, void *d_hv_local, void *stream);
+
+/* Time `nrep` back-to-back device products with HIP events recorded on the stream the
+ * kernels are launched on; returns the mean milliseconds per product.                    */
+int hxv_time_apply(hxv_handle *h, const void *d_v_full, void *d_hv_local, int32_t nrep, float *ms_per_apply);
+
+/* ---- Lanczos on device (SciFortran sp_lanc_tridiag / sp_lanc_eigh call shapes,
+ * ED_GF_NORMAL.f90:215-220, ED_DIAG.f90:176-184).  nranks==1.
+ * tridiag: d_vin = caller-normalised start vector (device, Dim); alanc[nlanc], blanc[nlanc]
+ *   filled as alanc(k)=<q_k|H|q_k>, blanc(k+1)=beta_{k+1}, blanc(1)=0 (ED_GF_NORMAL.f90:949-951);
+ *   *nsteps = iterations done (early exit when beta < threshold).
+ * eigh: lowest eigenvalue *egs and eigenvector d_vect (device, Dim, written) from a
+ *   deterministic start vector; stops when |dE| < threshold or at nitermax (ED_DIAG.f90:176). */
+int hxv_lanczos_tridiag(hxv_handle *h, const void *d_vin, int32_t nlanc, double *alanc, double *blanc, double threshold,
+                        int32_t *nsteps);
+int hxv_lanczos_eigh(hxv_handle *h, int32_t nitermax, double threshold, double *egs, void *d_vect, int32_t *niter);
+/* Time nrep full Lanczos iterations (HxV + recurrence + 2 reductions) on device. */
+int hxv_time_lanczos(hxv_handle *h, void *d_work3 /* 3*Dim complex */, int32_t nrep, float *ms_per_iter);
+
+/* ---- introspection (parity tests against spH0ups/spH0dws/spH0d) ------------------------ */
+int hxv_get_maps(const hxv_handle *h, int32_t *map_up, int32_t *map_dw); /* Hs(1)%map, Hs(2)%map */
+int64_t hxv_nnz(const hxv_handle *h, int32_t which);                      /* 0: H_up, 1: H_dw */
+/* CSR of the one-spin matrix in the reference's row-list order; cols 1-based */
+int hxv_get_csr(const hxv_handle *h, int32_t which, int64_t *rowptr, int32_t *cols, double *vals);
+/* local diagonal (vecdim doubles; the engine requires a real diagonal) */
+int hxv_get_diag(const hxv_handle *h, double *diag);
+
+/* options: "kernel" (0 naive one-pass, 1 tiled two-pass [default]), "tile_bits" ... */
+int hxv_set_option(hxv_handle *h, const char *name, int64_t value);
+int64_t hxv_get_option(const hxv_handle *h, const char *name);
+
+typedef struct {
+  int64_t n_apply;          /* products since creation                     */
+  int64_t algorithmic_bytes; /* 32 B x local rows per product   */
+  int64_t device_bytes;     /* bytes of device memory held by the handle   */
+  int32_t kernel;           /* active kernel variant                       */
+  int32_t real_h;           /* 1 if all hopping amplitudes are real        */
+  int32_t k_up, k_dw;       /* max stored entries per row of H_up / H_dw   */
+  int32_t n_hops_up, n_hops_dw;
+} hxv_stats;
+int hxv_get_stats(const hxv_handle *h, hxv_stats *out);
+
+/* last error message of the calling thread ("" if none) */
+const char *hxv_last_error(void);
+/* library version string */
+const char *hxv_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HXV_H */

@@ -1,0 +1,163 @@
+"""Pins of the CPU oracle (oracle/hxv_oracle.c).  The reference ships no tests or fixtures
+ and cannot be built under this round's rules, so the oracle is pinned by
+  (1) numbers the survey recorded from the reference itself,
+  (2) the literature value of the 4-site Hubbard ring,
+  (3) an independent second-quantised construction (Jordan-Wigner on the full Fock space),
+  (4) internal consistency: sparse == dense-Kronecker == MPI-emulated product."""
+import itertools
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from hxv import models
+from oracle.oracle import OracleSector, spMatVec_mpi_main
+
+GOLD = json.loads((Path(__file__).parent / "golden" / "survey_known_answers.json").read_text())
+
+
+def test_c1_plaquette_reference_dense_spectrum():
+    g = GOLD["C1_plaquette_2x2_U4_t1_hfF_sector_2_2"]
+    s = OracleSector(models.plaquette_2x2_nobath(U=4.0, t=1.0, hfmode=False), 2, 2)
+    assert s.Dim == g["Dim"] and len(s.csr("up")[1]) == g["nnz_up"]
+    H = s.dense()
+    assert np.abs(H - H.conj().T).max() == 0.0
+    ev = np.linalg.eigvalsh(H)
+    assert np.allclose(ev[:4], g["lowest"], atol=5e-9)
+    assert abs(ev[0] - g["literature_E0"]) < 1e-5
+
+
+def test_bhz_complex_path_reference_values():
+    m = models.bhz_2d(Nbath=0)
+    g = GOLD["BHZ_2x2_Norb2_Nspin2_Nbath0_sector_4_4"]
+    s = OracleSector(m, 4, 4)
+    assert s.Dim == g["Dim"]
+    assert len(s.csr("up")[1]) == g["nnz_up"] and len(s.csr("dw")[1]) == g["nnz_dw"]
+    H = s.dense()
+    assert np.abs(H - H.conj().T).max() == 0.0
+    assert abs(np.abs(H.imag).max() - g["max_abs_imag"]) < 1e-12
+    assert np.allclose(np.linalg.eigvalsh(H)[:4], g["lowest"], atol=5e-9)
+    v = models.deterministic_vector(s.Dim)
+    assert np.abs(s.spMatVec_main(v) - H @ v).max() < 1e-13 * np.abs(H @ v).max() * 10
+    g = GOLD["BHZ_2x2_Norb2_Nspin2_Nbath0_sector_3_5"]
+    s = OracleSector(m, 3, 5)
+    assert s.Dim == g["Dim"]
+    assert np.allclose(np.linalg.eigvalsh(s.dense())[:4], g["lowest"], atol=5e-9)
+
+
+def test_nnz_counts_recorded_by_survey():
+    g = GOLD["nnz_up"]
+    assert len(OracleSector(models.plaquette_2x2_nobath(), 2, 2).csr("up")[1]) == g["C1"]
+    assert len(OracleSector(models.hm_1dchain(), 6, 6).csr("up")[1]) == g["C2"]
+
+
+@pytest.mark.slow
+def test_nnz_c3():
+    s = OracleSector(models.hm_2dsquare(Nbath=3), 8, 8, rank=0, size=12870)  # one column: the diagonal slab stays tiny
+    assert len(s.csr("up")[1]) == GOLD["nnz_up"]["C3"]
+
+
+# ---- (3) independent construction ---------------------------------------------------------
+def _jw_ops(n):
+    """c_p on the 2^n Fock space, p=0..n-1, Jordan-Wigner with orbital 0 as the first factor."""
+    sm = np.array([[0, 1], [0, 0]], dtype=float)  # |1> -> |0>
+    sz = np.diag([1.0, -1.0])
+    ops = []
+    for p in range(n):
+        mats = [sz] * p + [sm] + [np.eye(2)] * (n - p - 1)
+        o = mats[0]
+        for x in mats[1:]:
+            o = np.kron(o, x)
+        ops.append(o)
+    return ops
+
+
+def _fock_hamiltonian(m):
+    """Full many-body H of `m` from c/c^dagger matrices: orbitals 0..Ns-1 spin up, Ns..2Ns-1 spin down."""
+    Ns, L, O, B = m.Ns, m.Nlat, m.Norb, m.Nbath
+    c = _jw_ops(2 * Ns)
+    cd = [x.T for x in c]
+    nop = [cd[p] @ c[p] for p in range(2 * Ns)]
+    imp = lambda il, io: io + il * O
+    bath = lambda il, io, ib: L * O + imp(il, io) + ib * L * O
+    H = np.zeros((4**Ns, 4**Ns), dtype=complex)
+    for sp, soff in ((0, 0), (m.Nspin - 1, Ns)):
+        for il, jl, io, jo in itertools.product(range(L), range(L), range(O), range(O)):
+            a, b = imp(il, io), imp(jl, jo)
+            H += m.impHloc[il, jl, sp, sp, io, jo] * cd[soff + a] @ c[soff + b]
+            for ib in range(B):
+                a, b = bath(il, io, ib), bath(jl, jo, ib)
+                t = m.Hbath[il, jl, sp, sp, io, jo, ib]
+                H += (t.real if a == b else t) * cd[soff + a] @ c[soff + b]
+        for il, io, ib in itertools.product(range(L), range(O), range(B)):
+            a, b = imp(il, io), bath(il, io, ib)
+            H += m.Vbath[il, sp, io, ib] * (cd[soff + a] @ c[soff + b] + cd[soff + b] @ c[soff + a])
+    I = np.eye(4**Ns)
+    for il in range(L):
+        for io in range(O):
+            u, d = nop[imp(il, io)], nop[Ns + imp(il, io)]
+            H += -m.xmu * (u + d) + m.Uloc[io] * u @ d
+            if m.hfmode:
+                H += -0.5 * m.Uloc[io] * (u + d) + 0.25 * m.Uloc[io] * I
+            for jo in range(io + 1, O):
+                u2, d2 = nop[imp(il, jo)], nop[Ns + imp(il, jo)]
+                H += m.Ust * (u @ d2 + u2 @ d) + (m.Ust - m.Jh) * (u @ u2 + d @ d2)
+                if m.hfmode:
+                    H += (-0.5 * m.Ust - 0.5 * (m.Ust - m.Jh)) * (u + d + u2 + d2) + (0.25 * m.Ust + 0.25 * (m.Ust - m.Jh)) * I
+    Nup = sum(nop[:Ns])
+    Ndw = sum(nop[Ns:])
+    return H, np.rint(np.diag(Nup)).astype(int), np.rint(np.diag(Ndw)).astype(int)
+
+
+@pytest.mark.parametrize("model", [
+    models.plaquette_2x2_nobath(U=4.0, t=1.0, hfmode=False),
+    models.plaquette_2x2_nobath(U=3.0, t=0.7, hfmode=True, xmu=0.2),
+    models.hm_1dchain(Nlat=2, Nbath=1, eps_bath=[0.4]),
+    models.bhz_2d(Nx=2, Ny=1, Nbath=0, Ust=0.5, Jh=0.1, xmu=0.3),
+    models.bhz_2d(Nx=1, Ny=1, Nbath=1, Ust=0.5, Jh=0.1),
+], ids=lambda m: m.name)
+def test_oracle_vs_independent_second_quantisation(model):
+    """Every (nup,ndw) sector spectrum of the oracle's dense H equals the spectrum of the same sector of an
+    H built from explicit fermion matrices (sign conventions differ by a diagonal unitary only)."""
+    H, nu, nd = _fock_hamiltonian(model)
+    assert np.abs(H - H.conj().T).max() < 1e-14
+    Ns = model.Ns
+    for nup in range(Ns + 1):
+        for ndw in range(Ns + 1):
+            idx = np.where((nu == nup) & (nd == ndw))[0]
+            ev_ind = np.linalg.eigvalsh(H[np.ix_(idx, idx)])
+            s = OracleSector(model, nup, ndw)
+            ev_orc = np.linalg.eigvalsh(s.dense())
+            assert s.Dim == len(idx)
+            assert np.abs(ev_ind - ev_orc).max() < 1e-12, (nup, ndw)
+            s.close()
+
+
+# ---- (4) internal consistency --------------------------------------------------------------
+@pytest.mark.parametrize("P", [1, 2, 3, 5])
+def test_mpi_emulation_equals_serial(P):
+    m = models.hm_1dchain(Nlat=2, Nbath=2, eps_bath=[0.3, 0.6])
+    s = OracleSector(m, 3, 2)
+    v = models.deterministic_vector(s.Dim)
+    ref = s.spMatVec_main(v)
+    hv, _ = spMatVec_mpi_main(m, 3, 2, P, v)
+    assert np.abs(hv - ref).max() < 1e-14
+
+
+def test_sparse_equals_dense_kronecker_with_bath_energies():
+    m = models.hm_1dchain(Nlat=2, Nbath=2, eps_bath=[0.3, 0.6])  # non-zero bath levels
+    s = OracleSector(m, 3, 3)
+    H = s.dense()
+    v = models.deterministic_vector(s.Dim)
+    assert np.abs(s.spMatVec_main(v) - H @ v).max() < 1e-14
+
+
+def test_lanczos_tridiag_reproduces_dense_ground_state():
+    m = models.hm_1dchain(Nlat=2, Nbath=2, eps_bath=[0.3, 0.6])
+    s = OracleSector(m, 3, 3)
+    e0 = np.linalg.eigvalsh(s.dense())[0]
+    v = models.deterministic_vector(s.Dim)
+    a, b = s.lanc_tridiag(v / np.linalg.norm(v), 120)
+    T = np.diag(a) + np.diag(b[1:], 1) + np.diag(b[1:], -1)
+    assert abs(np.linalg.eigvalsh(T)[0] - e0) < 1e-10
