@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""bench.py -- sector HxV throughput on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+A "step" = one full product Hv = H v of the BASELINE C3 sector (cdn_hm_2dsquare: 2x2 cluster +
+3 replica baths, Ns=16, sector (8,8), Dim = 165 636 900, complex fp64), vectors resident in HBM.
+With N>1 ranks the sector is split along DimDw exactly like the reference (ED_HAMILTONIAN.f90:93-105):
+each step all-gathers the N slabs over RCCL and every rank computes its slab (strong scaling: the
+sector is fixed).  value = algorithmic GB/s of the whole job = 32 B x Dim / step time
+(read v once + write Hv once per basis state).
+
+Rank 0 prints ONE JSON line.  It also carries
+  roofline     : achieved/peak HBM GB/s of the product's kernels, timed with HIP events on the launch stream
+  cpu_baseline : the reference algorithm (oracle spMatVec_mpi_main, thread-ranks) on the host cores, N=1 only
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT / "cdmft-lanc-ed_amd"))
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def cpu_baseline(model, nup, ndw, budget_s=25.0):
+    """Reference algorithm on the host: oracle spMatVec_mpi_main with one thread-rank per core."""
+    import numpy as np
+    from oracle.oracle import OracleSector, spMatVec_mpi_main
+
+    cores = len(os.sched_getaffinity(0))
+    P = max(1, min(cores, 16))
+    t0 = time.time()
+    secs = [OracleSector(model, nup, ndw, r, P) for r in range(P)]
+    build_s = time.time() - t0
+    dim = secs[0].Dim
+    rng = np.random.default_rng(0)
+    v = rng.standard_normal(dim) + 1j * rng.standard_normal(dim)
+    _, _ = spMatVec_mpi_main(model, nup, ndw, P, v, repeat=1, sectors=secs)  # warm-up
+    t0 = time.time()
+    n = 0
+    while True:
+        spMatVec_mpi_main(model, nup, ndw, P, v, repeat=1, sectors=secs)
+        n += 1
+        if time.time() - t0 > budget_s / 2 or n >= 5:
+            break
+    dt = (time.time() - t0) / n
+    for s in secs:
+        s.close()
+    return {"value": 32.0 * dim / dt / 1e9, "unit": "GB/s", "cores": P, "kind": "port",
+            "sample": f"{n} full products of the same sector, {P} thread-ranks (reference spMatVec_mpi_main restated in oracle/hxv_oracle.c; "
+                      f"matrix build {build_s:.1f}s untimed)", "s_per_matvec": dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="C3", choices=["C2", "C3", "C4", "C5"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lanczos", action="store_true", help="also time full Lanczos iterations (N=1)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import hxv
+    from hxv import models
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    if args.workload == "C2":
+        model, (nup, ndw) = models.hm_1dchain(), (6, 6)
+    elif args.workload == "C3":
+        model, (nup, ndw) = models.hm_2dsquare(Nbath=3), (8, 8)
+    elif args.workload == "C4":
+        model, (nup, ndw) = models.bhz_2d(Nbath=1), (8, 8)
+    else:
+        model, (nup, ndw) = models.hm_ring(6, 2), (9, 9)
+
+    sec = hxv.HxvSector.from_model(model, nup, ndw, rank=rank, nranks=world, device=local_rank)
+    Dim, Nloc = sec.Dim, sec.vecDim
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    v_local = torch.randn(Nloc, dtype=torch.float64, device=dev, generator=g) + 1j * torch.randn(Nloc, dtype=torch.float64, device=dev, generator=g)
+    hv_local = torch.empty(Nloc, dtype=torch.complex128, device=dev)
+    sh = hxv.ShardedHxv(sec.DimUp, sec.DimDw, rank, world, sec.apply_device)
+
+    def step():
+        sh(Nloc, v_local, hv_local)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_step = dt / args.steps * 1e3
+    value = 32.0 * Dim / (ms_step * 1e-3) / 1e9
+
+    # roofline of the product's kernels on this rank: HIP events on the stream they are launched on
+    vfull = sh.gather(v_local)
+    torch.cuda.synchronize()
+    k_ms = sec.time_apply(vfull, hv_local, max(5, min(args.steps, 20)))
+    achieved = 32.0 * Nloc / (k_ms * 1e-3) / 1e9
+    traffic = None
+    tf = ROOT / "profiles" / "traffic.json"
+    if tf.exists():
+        try:
+            tj = json.loads(tf.read_text())
+            if tj.get("workload") == args.workload and tj.get("n_gpus", 1) == world:
+                traffic = tj.get("hbm_bytes_per_product")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": traffic, "kernel": "hxv_pass_up + hxv_pass_dw (one product)", "kernel_ms": round(k_ms, 4),
+                "algorithmic_bytes": 32 * Nloc}
+
+    out = {"metric": "sector-HxV achieved HBM GB/s (algorithmic 32 B x Dim per product), Ns=16 half-filled sector", "value": round(value, 1),
+           "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "complex128 (f64)", "data": "synthetic",
+           "config": {"workload": f"{args.workload}: {model.name} sector ({nup},{ndw}) Dim={Dim}", "DimUp": sec.DimUp, "DimDw": sec.DimDw,
+                      "parallelism": f"DimDw split x{world}" + (" + RCCL allgather per product" if world > 1 else ""),
+                      "matvecs_per_s": round(1e3 / ms_step, 2)},
+           "roofline": roofline}
+    if args.lanczos and world == 1:
+        lz_ms = sec.time_lanczos(10)
+        out["config"]["lanczos_ms_per_iter"] = round(lz_ms, 4)
+        out["config"]["lanczos_matvecs_per_s"] = round(1e3 / lz_ms, 2)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sec.close()
+        del vfull, v_local, hv_local, sh
+        torch.cuda.empty_cache()
+        try:
+            out["cpu_baseline"] = cpu_baseline(model, nup, ndw)
+        except Exception as e:  # the baseline is context, never the product: report, do not fail the bench
+            out["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -299,7 +299,9 @@ int hxv_set_option(hxv_handle* h, const char* name, int64_t value) {
   TileOptions o = h->plan.opt;
   if (!strcmp(name, "cols_per_tile")) o.cols_per_tile = (int)value;
   else if (!strcmp(name, "rows_per_tile")) o.rows_per_tile = (int)value;
-  else if (!strcmp(name, "lds_budget_kb")) o.lds_budget_kb = (int)value;
+  else if (!strcmp(name, "lds_budget_kb")) o.lds_budget_kb_up = o.lds_budget_kb_dw = (int)value;
+  else if (!strcmp(name, "lds_budget_kb_up")) o.lds_budget_kb_up = (int)value;
+  else if (!strcmp(name, "lds_budget_kb_dw")) o.lds_budget_kb_dw = (int)value;
   else if (!strcmp(name, "tile_bits_up")) o.force_bits_up = (int)value;
   else if (!strcmp(name, "tile_bits_dw")) o.force_bits_dw = (int)value;
   else if (!strcmp(name, "threads_up")) o.threads_up = (int)value;
@@ -322,7 +324,8 @@ int64_t hxv_get_option(const hxv_handle* h, const char* name) {
   if (!strcmp(name, "tile_bits_dw")) return h->plan.dw.lowbits;
   if (!strcmp(name, "cols_per_tile")) return h->plan.opt.cols_per_tile;
   if (!strcmp(name, "rows_per_tile")) return h->plan.opt.rows_per_tile;
-  if (!strcmp(name, "lds_budget_kb")) return h->plan.opt.lds_budget_kb;
+  if (!strcmp(name, "lds_budget_kb_up")) return h->plan.opt.lds_budget_kb_up;
+  if (!strcmp(name, "lds_budget_kb_dw")) return h->plan.opt.lds_budget_kb_dw;
   if (!strcmp(name, "k_in_up")) return h->plan.up.k_in;
   if (!strcmp(name, "k_out_up")) return h->plan.up.k_out;
   if (!strcmp(name, "k_in_dw")) return h->plan.dw.k_in;

@@ -371,14 +371,16 @@ std::string make_tile_plan(const SectorHost& s, TilePlan& plan, const UploadU32&
   TileOptions& o = plan.opt;
   if (o.cols_per_tile != 2 && o.cols_per_tile != 4 && o.cols_per_tile != 8) return "cols_per_tile must be 2, 4 or 8";
   if (o.rows_per_tile != 4 && o.rows_per_tile != 8 && o.rows_per_tile != 16) return "rows_per_tile must be 4, 8 or 16";
-  if (o.lds_budget_kb < 8 || o.lds_budget_kb > 160) return "lds_budget_kb must be in [8,160]";
+  if (o.lds_budget_kb_up < 8 || o.lds_budget_kb_up > 144 || o.lds_budget_kb_dw < 8 || o.lds_budget_kb_dw > 144)
+    return "lds_budget_kb must be in [8,144]";
   if (o.threads_up != 256 && o.threads_up != 512) return "threads_up must be 256 or 512";
   if (o.threads_dw != 256 && o.threads_dw != 512) return "threads_dw must be 256 or 512";
   plan.ncoef_up = (int)s.up.coef.size();
   plan.ncoef_dw = (int)s.dw.coef.size();
-  const int budget = o.lds_budget_kb * 1024 - 16 * std::max(plan.ncoef_up, plan.ncoef_dw);
   std::vector<uint32_t> ein, eout;
-  auto one = [&](const SpinOp& op, const std::vector<uint32_t>& map, int npart, int width, int force, SpinTiles& t) -> std::string {
+  auto one = [&](const SpinOp& op, const std::vector<uint32_t>& map, int npart, int width, int force, int budget_kb,
+                 SpinTiles& t) -> std::string {
+    const int budget = budget_kb * 1024 - 16 * std::max(plan.ncoef_up, plan.ncoef_dw);
     int L = 32, chunk = std::max(1, budget / (16 * width));
     if (!map.empty()) {
       L = force >= 0 ? std::min(force, s.ns) : choose_lowbits(s.ns, npart, width, budget);
@@ -391,9 +393,9 @@ std::string make_tile_plan(const SectorHost& s, TilePlan& plan, const UploadU32&
     if (upload(eout, &t.d_ell_out) != hipSuccess) return "upload of outer ELL failed";
     return "";
   };
-  std::string e = one(s.up, s.map_up, s.nup, o.cols_per_tile, o.force_bits_up, plan.up);
+  std::string e = one(s.up, s.map_up, s.nup, o.cols_per_tile, o.force_bits_up, o.lds_budget_kb_up, plan.up);
   if (!e.empty()) return e;
-  return one(s.dw, s.map_dw, s.ndw, o.rows_per_tile, o.force_bits_dw, plan.dw);
+  return one(s.dw, s.map_dw, s.ndw, o.rows_per_tile, o.force_bits_dw, o.lds_budget_kb_dw, plan.dw);
 }
 
 hipError_t launch_hxv_tiled(const DevSector& s, const TilePlan& plan, const double2* v, double2* hv, hipStream_t st) {

@@ -26,9 +26,10 @@ struct SpinTiles {
 struct TileOptions {
   int cols_per_tile = 4;    // pass A (up hops): columns per workgroup tile
   int rows_per_tile = 8;    // pass B (dw hops): rows per workgroup tile
-  int lds_budget_kb = 64;   // LDS per workgroup tile
+  int lds_budget_kb_up = 64;  // LDS per workgroup tile, pass A
+  int lds_budget_kb_dw = 16;  // LDS per workgroup tile, pass B (small tiles keep one row group per XCD in flight)
   int force_bits_up = -1, force_bits_dw = -1;
-  int threads_up = 256, threads_dw = 256;
+  int threads_up = 512, threads_dw = 256;
   int passes = 3;  // bit 0: pass A (diag + up hops), bit 1: pass B (dw hops); timing experiments only
 };
 

@@ -1,0 +1,58 @@
+"""DimDw-sharded HxV across the GPUs of one node: one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI) as the plumbing.
+
+Partition = the reference's own (ED_HAMILTONIAN.f90:93-105): rank r owns mpiQdw consecutive dw
+columns.  The reference reassembles with two MPI_AllToAllV transposes per product
+(ED_HAMILTONIAN_SPARSE_HxV.f90:279,294); here every product all-gathers the slabs into a full
+replica of v on each GPU (the exchange BASELINE.json mandates) and then computes its slab of Hv
+locally with no second exchange.  Unequal slabs (DimDw % P != 0) are gathered straight into the
+contiguous full vector through per-rank views of different length."""
+from __future__ import annotations
+
+from math import comb
+
+
+def dw_split(DimDw: int, rank: int, size: int):
+    """(mpiQdw, first column) of `rank` -- ED_HAMILTONIAN.f90:93-105."""
+    q, rem = divmod(DimDw, size)
+    return q + (1 if rank < rem else 0), rank * q + min(rank, rem)
+
+
+class ShardedHxv:
+    """spHtimesV_p for MpiStatus=T on device tensors: Hv_local = (H v)_slab.
+
+    apply_local(v_full, hv_local) is the per-rank slab product (HxvSector.apply_device on the GPU
+    box; tests inject a CPU stand-in to exercise the exchange with gloo)."""
+
+    def __init__(self, DimUp: int, DimDw: int, rank: int, size: int, apply_local, group=None):
+        import torch.distributed as dist
+
+        self.dist = dist
+        self.DimUp, self.DimDw, self.rank, self.size, self.group = DimUp, DimDw, rank, size, group
+        self.qdw, self.dw0 = dw_split(DimDw, rank, size)
+        self.counts = [dw_split(DimDw, r, size)[0] * DimUp for r in range(size)]
+        self.offsets = [dw_split(DimDw, r, size)[1] * DimUp for r in range(size)]
+        self.Nloc = self.qdw * DimUp
+        self.apply_local = apply_local
+        self._vfull = None
+
+    def gather(self, v_local):
+        """allgather_vector_MPI (ED_SETUP.f90:672-708) into the contiguous full vector."""
+        import torch
+
+        assert v_local.numel() == self.Nloc
+        if self.size == 1:
+            return v_local  # the slab is the whole vector: no exchange, no copy
+        if self._vfull is None or self._vfull.device != v_local.device or self._vfull.dtype != v_local.dtype:
+            self._vfull = torch.empty(self.DimUp * self.DimDw, dtype=v_local.dtype, device=v_local.device)
+        views = [self._vfull[o:o + c] for o, c in zip(self.offsets, self.counts)]
+        if len(set(self.counts)) == 1:
+            self.dist.all_gather_into_tensor(self._vfull, v_local.contiguous(), group=self.group)
+        else:
+            self.dist.all_gather(views, v_local.contiguous(), group=self.group)
+        return self._vfull
+
+    def __call__(self, Nloc: int, v_local, hv_local):
+        if Nloc != self.Nloc:
+            raise ValueError("spMatVec_mpi_cc ERROR: Nloc /= DimUp*mpiQdw")
+        return self.apply_local(self.gather(v_local), hv_local)
