@@ -98,7 +98,9 @@ int finish_create(hxv_handle* h, int device, hxv_handle** out) {
   double2 *coef_up, *coef_dw;
   double *a_up = nullptr, *a_dw = nullptr, *stored = nullptr;
   HC(h->upload(&ell_up, s.up.ell));
-  HC(h->upload(&ell_dw, s.dw.ell));
+  HC(h->upload(&ell_dw, translate_ell_src(s.dw.ell, s.vcol)));
+  uint32_t* vcol;
+  HC(h->upload(&vcol, s.vcol));
   std::vector<double2> cu(s.up.coef.size()), cd(s.dw.coef.size());
   for (size_t i = 0; i < cu.size(); ++i) cu[i] = make_double2(s.up.coef[i].real(), s.up.coef[i].imag());
   for (size_t i = 0; i < cd.size(); ++i) cd[i] = make_double2(s.dw.coef[i].real(), s.dw.coef[i].imag());
@@ -126,6 +128,8 @@ int finish_create(hxv_handle* h, int device, hxv_handle** out) {
   d.dimdw = s.dimdw;
   d.qdw = s.qdw;
   d.dw0 = s.dw0;
+  d.slab0 = s.rank * s.cmax;
+  d.vcol = vcol;
   d.real_h = (s.up.real_vals && s.dw.real_vals) ? 1 : 0;
   HC(h->alloc(&h->d_partials, 2 * RED_BLOCKS));
   HC(h->alloc(&h->d_scalars, 8));
@@ -189,6 +193,7 @@ int hxv_destroy(hxv_handle* h) {
 }
 
 int64_t hxv_vecdim(const hxv_handle* h) { return h ? (int64_t)h->host.qdw * h->host.dimup : -1; }
+int64_t hxv_fullvec_elems(const hxv_handle* h) { return h ? (int64_t)h->host.nranks * h->host.cmax * h->host.dimup : -1; }
 
 int hxv_dims(const hxv_handle* h, int32_t* dimup, int32_t* dimdw, int64_t* dim, int32_t* qdw, int64_t* ishift) {
   if (!h) return fail(HXV_ERR_ARG, "NULL handle");
@@ -645,6 +650,18 @@ int hxv_lanczos_eigh(hxv_handle* h, int32_t nitermax, double threshold, double* 
     e_new = *std::min_element(d.begin(), d.end());
     bool conv = std::fabs(e_new - e_old) < threshold;
     e_old = e_new;
+    if (conv && d_vect) {
+      // the energy converges quadratically faster than the vector: before accepting, require the Ritz
+      // residual estimate |beta_{k+1} * y_k| (last component of the tridiagonal eigenvector) to be small too
+      const int m = (int)al.size();
+      std::vector<double> dd = al, ee = be, zz((size_t)m * m, 0.0);
+      ee.resize(m, 0.0);
+      for (int i = 0; i < m; ++i) zz[i + (size_t)i * m] = 1.0;
+      if (!tridiag_ql(m, dd, ee, &zz)) return fail(HXV_ERR_STATE, "tridiagonal QL did not converge");
+      int jm = (int)(std::min_element(dd.begin(), dd.end()) - dd.begin());
+      const double resid = std::fabs(bt * zz[(size_t)(m - 1) + (size_t)jm * m]);
+      conv = resid < 1e-11 * std::max(1.0, std::fabs(e_new));
+    }
     if (conv || std::fabs(bt) < 1e-14 || k + 1 == nmax) {
       ++k;
       break;

@@ -51,6 +51,8 @@ struct SectorHost {
   int dimup = 0, dimdw = 0;
   int64_t dim = 0;
   int rank = 0, nranks = 1, qdw = 0, dw0 = 0;
+  int cmax = 0;                     // columns per rank in the padded all-gather layout
+  std::vector<uint32_t> vcol;       // [dimdw] column -> column slot in the padded layout
   int64_t ishift = 0;
   std::vector<uint32_t> map_up, map_dw;
   SpinOp up, dw;
@@ -67,6 +69,8 @@ std::string build_sector_from_csr(int dimup, int dimdw, const int64_t* up_rp, co
                                   int nranks, SectorHost& out);
 std::string build_ell(SpinOp& op);
 void dw_split(int dimdw, int rank, int nranks, int& qdw, int& dw0);
+void make_vcol(SectorHost& s);
+std::vector<uint32_t> translate_ell_src(const std::vector<uint32_t>& ell, const std::vector<uint32_t>& vcol);
 double host_diag_element(const SectorHost& s, int iup, int idw);
 
 // ---------------------------------------------------------------------------------------
@@ -94,6 +98,8 @@ struct DevSector {
   DevDiag diag;
   int dimup, dimdw;
   int qdw, dw0;           // local columns [dw0, dw0+qdw)
+  int slab0;              // column slot of local column 0 in the padded all-gather layout (= rank*cmax)
+  const uint32_t* vcol;   // [dimdw] column -> column slot (identity when nranks==1)
   int real_h;
 };
 

@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(256) hxv_naive_kernel(DevSector s, const doubl
     const int cl = (int)(t / s.dimup);
     const int i = (int)(t - (int64_t)cl * s.dimup);
     const int c = cl + s.dw0;
-    const double2* __restrict__ vcol = v + (int64_t)c * s.dimup;
+    const double2* __restrict__ vcol = v + (int64_t)(s.slab0 + cl) * s.dimup;
     const double d = diag_at(s.diag, i, c, t);
     const double2 x = vcol[i];
     double2 acc = make_double2(d * x.x, d * x.y);
@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(512) hxv_pass_up(DevSector s, DevTiles t, cons
   const int c0 = g * C;  // local column
   const int nc = min(C, s.qdw - c0);
   double2* lcoef = lds + C * n;
-  const double2* __restrict__ vcol0 = v + (int64_t)(s.dw0 + c0) * s.dimup;
+  const double2* __restrict__ vcol0 = v + (int64_t)(s.slab0 + c0) * s.dimup;
 #pragma unroll
   for (int cc = 0; cc < C; ++cc) {
     if (cc < nc)
@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(512) hxv_pass_dw(DevSector s, DevTiles t, cons
   const bool row_ok = (i0 + r) < s.dimup;
   const int CSTEP = blockDim.x / R;
   double2* lcoef = lds + R * n;
-  for (int col = threadIdx.x / R; col < n; col += CSTEP) lds[col * R + r] = v[(int64_t)(cb0 + col) * s.dimup + irow];
+  for (int col = threadIdx.x / R; col < n; col += CSTEP) lds[col * R + r] = v[(int64_t)s.vcol[cb0 + col] * s.dimup + irow];
   for (int q = threadIdx.x; q < t.ncoef; q += blockDim.x) lcoef[q] = s.dw.coef[q];
   __syncthreads();
   for (int col = threadIdx.x / R; col < n; col += CSTEP) {
@@ -279,8 +279,8 @@ int64_t binom64(int n, int k) {
 // Split one spin sector into prefix blocks of `lowbits` low orbitals and split its ELL table.
 // Works from the index structure alone when no basis map is available (from_csr): then a
 // single block (lowbits = all) or fixed-size chunks are used.
-void build_spin_tiles(const SpinOp& op, const std::vector<uint32_t>& map, int lowbits, int chunk, SpinTiles& t,
-                      std::vector<uint32_t>& ell_in, std::vector<uint32_t>& ell_out) {
+void build_spin_tiles(const SpinOp& op, const std::vector<uint32_t>& map, int lowbits, int chunk, const std::vector<uint32_t>* vcol,
+                      SpinTiles& t, std::vector<uint32_t>& ell_in, std::vector<uint32_t>& ell_out) {
   const int dim = op.dim;
   t.start.clear();
   if (!map.empty()) {
@@ -327,7 +327,7 @@ void build_spin_tiles(const SpinOp& op, const std::vector<uint32_t>& map, int lo
       if (block_of[src] == block_of[i])
         ell_in[(size_t)(a++) * dim + i] = (e & ~ELL_SRC_MASK) | (src - t.start[block_of[i]]);
       else
-        ell_out[(size_t)(b++) * dim + i] = e;
+        ell_out[(size_t)(b++) * dim + i] = vcol ? ((e & ~ELL_SRC_MASK) | (*vcol)[src]) : e;
     }
   }
 }
@@ -379,13 +379,13 @@ std::string make_tile_plan(const SectorHost& s, TilePlan& plan, const UploadU32&
   plan.ncoef_dw = (int)s.dw.coef.size();
   std::vector<uint32_t> ein, eout;
   auto one = [&](const SpinOp& op, const std::vector<uint32_t>& map, int npart, int width, int force, int budget_kb,
-                 SpinTiles& t) -> std::string {
+                 const std::vector<uint32_t>* vcol, SpinTiles& t) -> std::string {
     const int budget = budget_kb * 1024 - 16 * std::max(plan.ncoef_up, plan.ncoef_dw);
     int L = 32, chunk = std::max(1, budget / (16 * width));
     if (!map.empty()) {
       L = force >= 0 ? std::min(force, s.ns) : choose_lowbits(s.ns, npart, width, budget);
     }
-    build_spin_tiles(op, map, L, chunk, t, ein, eout);
+    build_spin_tiles(op, map, L, chunk, vcol, t, ein, eout);
     if ((int64_t)t.max_block * width * 16 + 16 * 1024 > 160 * 1024) return "tile does not fit the 160 KB LDS";
     std::vector<uint32_t> st(t.start.begin(), t.start.end());
     if (upload(st, &t.d_start) != hipSuccess) return "upload of tile table failed";
@@ -393,9 +393,9 @@ std::string make_tile_plan(const SectorHost& s, TilePlan& plan, const UploadU32&
     if (upload(eout, &t.d_ell_out) != hipSuccess) return "upload of outer ELL failed";
     return "";
   };
-  std::string e = one(s.up, s.map_up, s.nup, o.cols_per_tile, o.force_bits_up, o.lds_budget_kb_up, plan.up);
+  std::string e = one(s.up, s.map_up, s.nup, o.cols_per_tile, o.force_bits_up, o.lds_budget_kb_up, nullptr, plan.up);
   if (!e.empty()) return e;
-  return one(s.dw, s.map_dw, s.ndw, o.rows_per_tile, o.force_bits_dw, o.lds_budget_kb_dw, plan.dw);
+  return one(s.dw, s.map_dw, s.ndw, o.rows_per_tile, o.force_bits_dw, o.lds_budget_kb_dw, &s.vcol, plan.dw);
 }
 
 hipError_t launch_hxv_tiled(const DevSector& s, const TilePlan& plan, const double2* v, double2* hv, hipStream_t st) {

@@ -165,6 +165,26 @@ void dw_split(int dimdw, int rank, int nranks, int& qdw, int& dw0) {
   dw0 = rank * q + std::min(rank, rem);
 }
 
+// Padded all-gather layout (include/hxv.h, hxv_apply_device): every rank contributes cmax =
+// ceil(DimDw/nranks) column slots, so rank r's slab starts at slot r*cmax; ranks that own one
+// column less (ED_HAMILTONIAN.f90:93-98) leave their last slot unused.
+void make_vcol(SectorHost& s) {
+  s.cmax = (s.dimdw + s.nranks - 1) / s.nranks;
+  s.vcol.resize(s.dimdw);
+  for (int r = 0; r < s.nranks; ++r) {
+    int q, c0;
+    dw_split(s.dimdw, r, s.nranks, q, c0);
+    for (int c = 0; c < q; ++c) s.vcol[c0 + c] = (uint32_t)(r * s.cmax + c);
+  }
+}
+
+std::vector<uint32_t> translate_ell_src(const std::vector<uint32_t>& ell, const std::vector<uint32_t>& vcol) {
+  std::vector<uint32_t> out(ell);
+  for (auto& e : out)
+    if (e != ELL_EMPTY) e = (e & ~ELL_SRC_MASK) | vcol[e & ELL_SRC_MASK];
+  return out;
+}
+
 std::string build_ell(SpinOp& op) {
   if (op.dim > (1 << ELL_SRC_BITS)) return "spin-sector dimension exceeds 2^20 (ELL source index)";
   std::map<std::pair<double, double>, int> ids;
@@ -225,6 +245,7 @@ std::string build_sector_from_model(const hxv_model& m, int nup, int ndw, int ra
   s.rank = rank; s.nranks = nranks;
   dw_split(s.dimdw, rank, nranks, s.qdw, s.dw0);
   s.ishift = (int64_t)s.dw0 * s.dimup;
+  make_vcol(s);
 
   std::vector<Hop> hops_up, hops_dw;
   std::vector<double> eps_up, eps_dw;
@@ -311,6 +332,7 @@ std::string build_sector_from_csr(int dimup, int dimdw, const int64_t* up_rp, co
   s.rank = rank; s.nranks = nranks;
   dw_split(dimdw, rank, nranks, s.qdw, s.dw0);
   s.ishift = (int64_t)s.dw0 * dimup;
+  make_vcol(s);
   auto load = [](int dim, const int64_t* rp, const int32_t* cols, const double* vals, SpinOp& op) -> std::string {
     op.dim = dim;
     op.rowptr.assign(rp, rp + dim + 1);

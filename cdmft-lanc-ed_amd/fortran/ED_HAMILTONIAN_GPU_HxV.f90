@@ -1,0 +1,168 @@
+!> ISO_C_BINDING glue between the reference's Fortran host and the HIP engine (include/hxv.h).
+!!
+!! It provides a module procedure with EXACTLY the abstract interface cc_sparse_HxV
+!! (ED_VARS_GLOBAL.f90:72-78), so that the reference's pointer can be bound to it,
+!!     spHtimesV_p => gpuMatVec_main            (ED_HAMILTONIAN.f90:129-141)
+!! and ED_DIAG / ED_GF_NORMAL (the SciFortran Lanczos callers) stay untouched, plus the
+!! open/close hooks that build_Hv_sector / delete_Hv_sector call (ED_HAMILTONIAN.f90:39-190).
+!! Errors follow the reference's convention: a non-zero status from the C side becomes `stop`.
+!! INTEGRATION.md shows the few lines added to ED_HAMILTONIAN.f90.
+module ED_HAMILTONIAN_GPU_HXV
+  use, intrinsic :: iso_c_binding
+  implicit none
+  private
+
+  public :: gpu_build_Hv_sector
+  public :: gpu_delete_Hv_sector
+  public :: gpu_vecDim_Hv_sector
+  public :: gpuMatVec_main
+  public :: gpu_lanc_tridiag_host
+
+  !> mirrors struct hxv_model of include/hxv.h
+  type, bind(C) :: hxv_model
+     integer(c_int32_t) :: nlat, norb, nspin, nbath
+     integer(c_int32_t) :: hfmode, reserved
+     real(c_double)     :: uloc(5)
+     real(c_double)     :: ust, jh, jx, jp, xmu
+     type(c_ptr)        :: imphloc, hbath, vbath
+  end type hxv_model
+
+  interface
+     integer(c_int) function hxv_create_from_model(model,nup,ndw,rank,nranks,device,out) bind(C,name="hxv_create_from_model")
+       import :: c_int, c_int32_t, c_ptr, hxv_model
+       type(hxv_model),intent(in)    :: model
+       integer(c_int32_t),value      :: nup,ndw,rank,nranks,device
+       type(c_ptr),intent(out)       :: out
+     end function hxv_create_from_model
+     integer(c_int) function hxv_destroy(h) bind(C,name="hxv_destroy")
+       import :: c_int, c_ptr
+       type(c_ptr),value :: h
+     end function hxv_destroy
+     integer(c_int64_t) function hxv_vecdim(h) bind(C,name="hxv_vecdim")
+       import :: c_int64_t, c_ptr
+       type(c_ptr),value :: h
+     end function hxv_vecdim
+     integer(c_int) function hxv_apply_host(h,nloc,v,hv) bind(C,name="hxv_apply_host")
+       import :: c_int, c_int64_t, c_ptr, c_double_complex
+       type(c_ptr),value                    :: h
+       integer(c_int64_t),value             :: nloc
+       complex(c_double_complex),intent(in) :: v(*)
+       complex(c_double_complex)            :: hv(*)
+     end function hxv_apply_host
+     type(c_ptr) function hxv_last_error() bind(C,name="hxv_last_error")
+       import :: c_ptr
+     end function hxv_last_error
+  end interface
+
+  type(c_ptr),save :: handle = c_null_ptr   !one open sector at a time (ED_HAMILTONIAN_COMMON.f90:17-18)
+
+contains
+
+  subroutine check(ierr,where)
+    integer(c_int)   :: ierr
+    character(len=*) :: where
+    character(kind=c_char),pointer :: msg(:)
+    integer :: n
+    if(ierr==0)return
+    call c_f_pointer(hxv_last_error(),msg,[512])
+    n=1
+    do while(n<512.and.msg(n)/=c_null_char)
+       n=n+1
+    enddo
+    write(*,"(A)")trim(where)//" ERROR: "//transfer(msg(1:n-1),repeat(" ",n-1))
+    stop "hxv engine error"
+  end subroutine check
+
+  !> Device-side part of build_Hv_sector(isector): arguments are the module globals the reference
+  !! has in scope at ED_HAMILTONIAN.f90:129 (Nlat..Nbath ED_INPUT_VARS.f90:13-16; impHloc
+  !! ED_VARS_GLOBAL.f90:119; Hbath_reconstructed / diag_hybr as built at
+  !! ED_HAMILTONIAN_SPARSE_HxV.f90:62-76; Uloc..xmu,hfmode ED_INPUT_VARS.f90:129-135,164;
+  !! nup,ndw = get_Nup/get_Ndw(isector); MpiRank,MpiSize after the communicator shrink).
+  subroutine gpu_build_Hv_sector(Nlat,Norb,Nspin,Nbath,nup,ndw,impHloc,Hbath,Vbath,Uloc,Ust,Jh,Jx,Jp,xmu,hfmode,MpiRank,MpiSize,device)
+    integer,intent(in)                   :: Nlat,Norb,Nspin,Nbath,nup,ndw
+    complex(8),intent(in),target,contiguous :: impHloc(:,:,:,:,:,:)   ![Nlat,Nlat,Nspin,Nspin,Norb,Norb]
+    complex(8),intent(in),target,contiguous :: Hbath(:,:,:,:,:,:,:)   ![Nlat,Nlat,Nspin,Nspin,Norb,Norb,Nbath]
+    real(8),intent(in),target,contiguous    :: Vbath(:,:,:,:)         ![Nlat,Nspin,Norb,Nbath]
+    real(8),intent(in)                   :: Uloc(5),Ust,Jh,Jx,Jp,xmu
+    logical,intent(in)                   :: hfmode
+    integer,intent(in)                   :: MpiRank,MpiSize
+    integer,intent(in),optional          :: device
+    type(hxv_model)                      :: m
+    integer                              :: dev
+    if(c_associated(handle))stop "gpu_build_Hv_sector ERROR: a sector is already open"
+    dev=0;if(present(device))dev=device
+    m%nlat=Nlat; m%norb=Norb; m%nspin=Nspin; m%nbath=Nbath
+    m%hfmode=0; if(hfmode)m%hfmode=1
+    m%reserved=0
+    m%uloc=Uloc
+    m%ust=Ust; m%jh=Jh; m%jx=Jx; m%jp=Jp; m%xmu=xmu
+    m%imphloc=c_loc(impHloc)
+    m%hbath=c_null_ptr; m%vbath=c_null_ptr
+    if(Nbath>0)then
+       m%hbath=c_loc(Hbath)
+       m%vbath=c_loc(Vbath)
+    endif
+    call check(hxv_create_from_model(m,int(nup,c_int32_t),int(ndw,c_int32_t),int(MpiRank,c_int32_t),&
+         int(MpiSize,c_int32_t),int(dev,c_int32_t),handle),"gpu_build_Hv_sector")
+  end subroutine gpu_build_Hv_sector
+
+  !> delete_Hv_sector hook (ED_HAMILTONIAN.f90:149-190)
+  subroutine gpu_delete_Hv_sector()
+    if(c_associated(handle))call check(hxv_destroy(handle),"gpu_delete_Hv_sector")
+    handle=c_null_ptr
+  end subroutine gpu_delete_Hv_sector
+
+  !> vecDim_Hv_sector of the open sector (ED_HAMILTONIAN.f90:197-221)
+  function gpu_vecDim_Hv_sector() result(vecDim)
+    integer :: vecDim
+    if(.not.c_associated(handle))stop "gpu_vecDim_Hv_sector ERROR: Hsector NOT set"
+    vecDim=int(hxv_vecdim(handle))
+  end function gpu_vecDim_Hv_sector
+
+  !> The product, with the cc_sparse_HxV interface (ED_VARS_GLOBAL.f90:72-78): Hv = H*v.
+  subroutine gpuMatVec_main(Nloc,v,Hv)
+    integer                    :: Nloc
+    complex(8),dimension(Nloc) :: v
+    complex(8),dimension(Nloc) :: Hv
+    if(.not.c_associated(handle))stop "gpuMatVec_main ERROR: Hsector NOT set"
+    call check(hxv_apply_host(handle,int(Nloc,c_int64_t),v,Hv),"gpuMatVec_main")
+  end subroutine gpuMatVec_main
+
+  !> Plain Lanczos tridiagonalisation driven through a cc_sparse_HxV procedure on HOST vectors:
+  !! the call shape of SciFortran's sp_lanc_tridiag(MatVec,vin,alanc,blanc) as consumed at
+  !! ED_GF_NORMAL.f90:215-220,949-951 (alanc(k)=<q_k|H|q_k>, blanc(k+1)=beta_{k+1}, blanc(1) unused).
+  !! SciFortran is not vendored with the reference; this stands where it would be linked.
+  subroutine gpu_lanc_tridiag_host(MatVec,vin,alanc,blanc,threshold)
+    interface
+       subroutine MatVec(Nloc,v,Hv)
+         integer                    :: Nloc
+         complex(8),dimension(Nloc) :: v,Hv
+       end subroutine MatVec
+    end interface
+    complex(8),intent(inout) :: vin(:)
+    real(8),intent(inout)    :: alanc(:),blanc(:)
+    real(8),intent(in),optional :: threshold
+    complex(8),allocatable   :: q(:),qm(:),w(:)
+    real(8)                  :: a,b,thr
+    integer                  :: k,n,nlanc
+    n=size(vin); nlanc=size(alanc)
+    thr=1d-12; if(present(threshold))thr=threshold
+    allocate(q(n),qm(n),w(n))
+    q=vin/sqrt(dble(dot_product(vin,vin))); qm=(0d0,0d0); b=0d0
+    alanc=0d0; blanc=0d0
+    do k=1,nlanc
+       call MatVec(n,q,w)
+       w=w-b*qm
+       a=dble(dot_product(q,w))
+       w=w-a*q
+       alanc(k)=a
+       b=sqrt(dble(dot_product(w,w)))
+       if(k<nlanc)blanc(k+1)=b
+       if(abs(b)<thr)exit
+       qm=q
+       q=w/b
+    enddo
+    deallocate(q,qm,w)
+  end subroutine gpu_lanc_tridiag_host
+
+end module ED_HAMILTONIAN_GPU_HXV

@@ -1,0 +1,119 @@
+!> Fortran host (the reference's own language) driving the HIP engine through the reference's
+!! procedure-pointer surface.  BASELINE config C1: 2x2 Hubbard plaquette, no bath, U=4, t=1,
+!! hfmode=F, sector (nup,ndw)=(2,2); the reference's dense H gives E0 = -2.10274848
+!! (SURVEY.md 8c).  Also C2-like: 4-site chain + 2 replica baths (Ns=12), sector (6,6).
+program hxv_fortran_demo
+  use ED_HAMILTONIAN_GPU_HXV
+  implicit none
+  !the reference's abstract interface and pointer (ED_VARS_GLOBAL.f90:72-78,146)
+  abstract interface
+     subroutine cc_sparse_HxV(Nloc,v,Hv)
+       integer                    :: Nloc
+       complex(8),dimension(Nloc) :: v
+       complex(8),dimension(Nloc) :: Hv
+     end subroutine cc_sparse_HxV
+  end interface
+  procedure(cc_sparse_HxV),pointer :: spHtimesV_p=>null()
+
+  call plaquette()
+  call chain_ns12()
+
+contains
+
+  subroutine plaquette()
+    integer,parameter :: Nlat=4,Norb=1,Nspin=1,Nbath=0
+    complex(8) :: impHloc(Nlat,Nlat,Nspin,Nspin,Norb,Norb),Hbath(Nlat,Nlat,Nspin,Nspin,Norb,Norb,1)
+    real(8)    :: Vbath(Nlat,Nspin,Norb,1),Uloc(5)
+    complex(8),allocatable :: v(:)
+    real(8)    :: alanc(36),blanc(36),e0
+    integer    :: dim,i
+    impHloc=(0d0,0d0); Hbath=(0d0,0d0); Vbath=0d0
+    !bonds 1-2,1-3,2-4,3-4 (drivers/cdn_hm_2dsquare.f90:231-250), t=1
+    impHloc(1,2,1,1,1,1)=-1d0; impHloc(2,1,1,1,1,1)=-1d0
+    impHloc(1,3,1,1,1,1)=-1d0; impHloc(3,1,1,1,1,1)=-1d0
+    impHloc(2,4,1,1,1,1)=-1d0; impHloc(4,2,1,1,1,1)=-1d0
+    impHloc(3,4,1,1,1,1)=-1d0; impHloc(4,3,1,1,1,1)=-1d0
+    Uloc=0d0; Uloc(1)=4d0
+    call gpu_build_Hv_sector(Nlat,Norb,Nspin,Nbath,2,2,impHloc,Hbath(:,:,:,:,:,:,1:0),Vbath(:,:,:,1:0),Uloc,0d0,0d0,0d0,0d0,0d0,.false.,0,1)
+    spHtimesV_p => gpuMatVec_main
+    dim=gpu_vecDim_Hv_sector()
+    allocate(v(dim))
+    do i=1,dim
+       v(i)=cmplx(sin(0.37d0*(i-1)+0.11d0),cos(0.23d0*(i-1)+0.05d0),8)
+    enddo
+    call gpu_lanc_tridiag_host(spHtimesV_p,v,alanc,blanc)
+    e0=lowest_tridiag(alanc,blanc)
+    write(*,"(A,I6,A,F16.10)")"C1 plaquette sector(2,2) Dim=",dim," E0=",e0
+    spHtimesV_p => null()
+    call gpu_delete_Hv_sector()
+    deallocate(v)
+  end subroutine plaquette
+
+  subroutine chain_ns12()
+    integer,parameter :: Nlat=4,Norb=1,Nspin=1,Nbath=2
+    complex(8) :: impHloc(Nlat,Nlat,Nspin,Nspin,Norb,Norb),Hbath(Nlat,Nlat,Nspin,Nspin,Norb,Norb,Nbath)
+    real(8)    :: Vbath(Nlat,Nspin,Norb,Nbath),Uloc(5),eps(Nbath)
+    complex(8),allocatable :: v(:),hv(:)
+    real(8)    :: alanc(200),blanc(200),e0
+    integer    :: dim,i,ib
+    impHloc=(0d0,0d0); Hbath=(0d0,0d0)
+    do i=1,Nlat
+       if(i>1)impHloc(i,i-1,1,1,1,1)=-0.25d0
+       if(i<Nlat)impHloc(i,i+1,1,1,1,1)=-0.25d0
+    enddo
+    eps=[0.3d0,0.6d0]
+    do ib=1,Nbath
+       Hbath(:,:,:,:,:,:,ib)=-abs(impHloc)     !Hsym1=|Hloc|, lambda=-1 (drivers/cdn_hm_1dchain.f90:80-81)
+       do i=1,Nlat
+          Hbath(i,i,1,1,1,1,ib)=eps(ib)
+       enddo
+    enddo
+    Vbath=1d0/sqrt(2d0)
+    Uloc=0d0; Uloc(1)=2d0
+    call gpu_build_Hv_sector(Nlat,Norb,Nspin,Nbath,6,6,impHloc,Hbath,Vbath,Uloc,0d0,0d0,0d0,0d0,0d0,.true.,0,1)
+    spHtimesV_p => gpuMatVec_main
+    dim=gpu_vecDim_Hv_sector()
+    allocate(v(dim),hv(dim))
+    do i=1,dim
+       v(i)=cmplx(sin(0.37d0*(i-1)+0.11d0),cos(0.23d0*(i-1)+0.05d0),8)
+    enddo
+    call spHtimesV_p(dim,v,hv)
+    write(*,"(A,I8,A,4ES24.16)")"C2 chain sector(6,6) Dim=",dim," Hv(1),Hv(Dim)=",hv(1),hv(dim)
+    call gpu_lanc_tridiag_host(spHtimesV_p,v,alanc,blanc)
+    e0=lowest_tridiag(alanc,blanc)
+    write(*,"(A,I8,A,F16.10)")"C2 chain sector(6,6) Dim=",dim," E0=",e0
+    spHtimesV_p => null()
+    call gpu_delete_Hv_sector()
+  end subroutine chain_ns12
+
+  !> lowest eigenvalue of the Lanczos tridiagonal by bisection (Sturm count); blanc(1) unused
+  function lowest_tridiag(a,b) result(e)
+    real(8) :: a(:),b(:),e,lo,hi,mid,d
+    integer :: n,k,it,cnt
+    n=size(a)
+    do while(n>1)          !trim trailing zeros left by an early exit
+       if(b(n)/=0d0.or.a(n)/=0d0)exit
+       n=n-1
+    enddo
+    lo=minval(a(1:n))-2d0*maxval(abs(b(1:n)))-1d0
+    hi=maxval(a(1:n))+2d0*maxval(abs(b(1:n)))+1d0
+    do it=1,200
+       mid=0.5d0*(lo+hi)
+       cnt=0
+       d=a(1)-mid
+       if(d<0d0)cnt=cnt+1
+       do k=2,n
+          if(d==0d0)d=1d-300
+          d=a(k)-mid-b(k)*b(k)/d
+          if(d<0d0)cnt=cnt+1
+       enddo
+       if(cnt>=1)then
+          hi=mid
+       else
+          lo=mid
+       endif
+    enddo
+    e=0.5d0*(lo+hi)
+  end function lowest_tridiag
+
+end program hxv_fortran_demo

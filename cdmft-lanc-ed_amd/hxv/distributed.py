@@ -21,8 +21,13 @@ def dw_split(DimDw: int, rank: int, size: int):
 class ShardedHxv:
     """spHtimesV_p for MpiStatus=T on device tensors: Hv_local = (H v)_slab.
 
-    apply_local(v_full, hv_local) is the per-rank slab product (HxvSector.apply_device on the GPU
-    box; tests inject a CPU stand-in to exercise the exchange with gloo)."""
+    Every product all-gathers the slabs with ONE equal-count collective (all_gather_into_tensor ->
+    ncclAllGather on RCCL): each rank contributes cmax = ceil(DimDw/P) columns, ranks that own one
+    column less pad with one unused column.  The gathered buffer is used as is -- the kernels address
+    it through the engine's column->slot table (include/hxv.h, hxv_apply_device), so there is no
+    compaction copy.  apply_local(v_gathered, hv_local) is the per-rank slab product
+    (HxvSector.apply_device on the GPU box; CPU tests inject a stand-in to exercise the exchange
+    with gloo)."""
 
     def __init__(self, DimUp: int, DimDw: int, rank: int, size: int, apply_local, group=None):
         import torch.distributed as dist
@@ -30,27 +35,42 @@ class ShardedHxv:
         self.dist = dist
         self.DimUp, self.DimDw, self.rank, self.size, self.group = DimUp, DimDw, rank, size, group
         self.qdw, self.dw0 = dw_split(DimDw, rank, size)
-        self.counts = [dw_split(DimDw, r, size)[0] * DimUp for r in range(size)]
-        self.offsets = [dw_split(DimDw, r, size)[1] * DimUp for r in range(size)]
+        self.cmax = -(-DimDw // size)
         self.Nloc = self.qdw * DimUp
+        self.slab = self.cmax * DimUp            # elements every rank contributes
         self.apply_local = apply_local
         self._vfull = None
+        self._send = None
 
     def gather(self, v_local):
-        """allgather_vector_MPI (ED_SETUP.f90:672-708) into the contiguous full vector."""
+        """allgather_vector_MPI (ED_SETUP.f90:672-708), equal counts, into the padded layout."""
         import torch
 
         assert v_local.numel() == self.Nloc
         if self.size == 1:
             return v_local  # the slab is the whole vector: no exchange, no copy
         if self._vfull is None or self._vfull.device != v_local.device or self._vfull.dtype != v_local.dtype:
-            self._vfull = torch.empty(self.DimUp * self.DimDw, dtype=v_local.dtype, device=v_local.device)
-        views = [self._vfull[o:o + c] for o, c in zip(self.offsets, self.counts)]
-        if len(set(self.counts)) == 1:
-            self.dist.all_gather_into_tensor(self._vfull, v_local.contiguous(), group=self.group)
-        else:
-            self.dist.all_gather(views, v_local.contiguous(), group=self.group)
+            self._vfull = torch.zeros(self.size * self.slab, dtype=v_local.dtype, device=v_local.device)
+        send = v_local
+        if self.Nloc != self.slab:                # this rank owns one column less: pad the send buffer
+            if self._send is None or self._send.device != v_local.device:
+                self._send = torch.zeros(self.slab, dtype=v_local.dtype, device=v_local.device)
+            self._send[: self.Nloc].copy_(v_local)
+            send = self._send
+        self.dist.all_gather_into_tensor(self._vfull, send.contiguous(), group=self.group)
         return self._vfull
+
+    def unpad(self, v_gathered):
+        """padded all-gather layout -> contiguous full vector (tests / debugging only)."""
+        import torch
+
+        if self.size == 1:
+            return v_gathered
+        parts = []
+        for r in range(self.size):
+            q, _ = dw_split(self.DimDw, r, self.size)
+            parts.append(v_gathered[r * self.slab: r * self.slab + q * self.DimUp])
+        return torch.cat(parts)
 
     def __call__(self, Nloc: int, v_local, hv_local):
         if Nloc != self.Nloc:

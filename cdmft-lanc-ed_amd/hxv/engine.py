@@ -41,7 +41,7 @@ class _Stats(C.Structure):
 # every symbol include/hxv.h declares (tests check that the library exports all of them)
 EXPORTS = [
     "hxv_create_from_model", "hxv_create_from_csr", "hxv_destroy", "hxv_vecdim", "hxv_dims", "hxv_apply_host",
-    "hxv_apply_device", "hxv_time_apply", "hxv_lanczos_tridiag", "hxv_lanczos_eigh", "hxv_time_lanczos", "hxv_get_maps",
+    "hxv_apply_device", "hxv_fullvec_elems", "hxv_time_apply", "hxv_lanczos_tridiag", "hxv_lanczos_eigh", "hxv_time_lanczos", "hxv_get_maps",
     "hxv_nnz", "hxv_get_csr", "hxv_get_diag", "hxv_set_option", "hxv_get_option", "hxv_get_stats", "hxv_last_error",
     "hxv_version",
 ]
@@ -70,6 +70,8 @@ def load_library():
     L.hxv_vecdim.argtypes = [vp]
     L.hxv_vecdim.restype = i64
     L.hxv_dims.argtypes = [vp, pi32, pi32, pi64, pi32, pi64]
+    L.hxv_fullvec_elems.argtypes = [vp]
+    L.hxv_fullvec_elems.restype = i64
     L.hxv_apply_host.argtypes = [vp, i64, vp, vp]
     L.hxv_apply_device.argtypes = [vp, vp, vp, vp]
     L.hxv_time_apply.argtypes = [vp, vp, vp, i32, C.POINTER(C.c_float)]
@@ -114,6 +116,7 @@ class HxvSector:
         _chk(L.hxv_dims(self._h, C.byref(du), C.byref(dd), C.byref(dim), C.byref(q), C.byref(ish)), "hxv_dims")
         self.DimUp, self.DimDw, self.Dim, self.mpiQdw, self.mpiIshift = du.value, dd.value, dim.value, q.value, ish.value
         self.vecDim = L.hxv_vecdim(self._h)
+        self.fullElems = L.hxv_fullvec_elems(self._h)   # length of the all-gather layout (== Dim if nranks == 1)
 
     # -- constructors ---------------------------------------------------------------------
     @classmethod
@@ -177,13 +180,24 @@ class HxvSector:
         (all-gathered for nranks>1), hv_local: vecDim elements.  Runs on torch's current stream."""
         import torch
 
-        assert v_full.is_cuda and v_full.dtype == torch.complex128 and v_full.is_contiguous() and v_full.numel() == self.Dim
+        assert v_full.is_cuda and v_full.dtype == torch.complex128 and v_full.is_contiguous() and v_full.numel() == self.fullElems
         if hv_local is None:
             hv_local = torch.empty(self.vecDim, dtype=torch.complex128, device=v_full.device)
         assert hv_local.is_cuda and hv_local.dtype == torch.complex128 and hv_local.is_contiguous() and hv_local.numel() == self.vecDim
         st = torch.cuda.current_stream(v_full.device).cuda_stream if stream is None else stream
         _chk(load_library().hxv_apply_device(self._h, v_full.data_ptr(), hv_local.data_ptr(), st), "hxv_apply_device")
         return hv_local
+
+    def to_gather_layout(self, v: np.ndarray, nranks: int) -> np.ndarray:
+        """Contiguous full vector (Dim) -> the padded all-gather layout hxv_apply_device expects."""
+        from .distributed import dw_split
+
+        cmax = -(-self.DimDw // nranks)
+        out = np.zeros(nranks * cmax * self.DimUp, dtype=np.complex128)
+        for r in range(nranks):
+            q, c0 = dw_split(self.DimDw, r, nranks)
+            out[r * cmax * self.DimUp:(r * cmax + q) * self.DimUp] = v[c0 * self.DimUp:(c0 + q) * self.DimUp]
+        return out
 
     def time_apply(self, v_full, hv_local, nrep: int) -> float:
         """Mean ms per product over nrep launches, HIP events on the launch stream."""

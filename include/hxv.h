@@ -79,12 +79,17 @@ int hxv_dims(const hxv_handle *h, int32_t *dimup, int32_t *dimdw, int64_t *dim, 
  * hxv_apply_device and INTEGRATION.md).  Pays two PCIe copies per call.                 */
 int hxv_apply_host(hxv_handle *h, int64_t nloc, const void *v, void *hv);
 
-/* Device-resident product.  d_v_full: the FULL vector (Dim elements: for nranks>1 the
- * all-gathered slabs in rank order = global column order), d_hv_local: this rank's slab
- * (vecdim elements), overwritten.  Asynchronous on `stream` (a hipStream_t; NULL = the legacy
+/* Device-resident product.  d_v_full: the FULL vector in the ALL-GATHER LAYOUT: nranks slabs of
+ * cmax*DimUp elements each, cmax = ceil(DimDw/nranks), slab r holding rank r's columns (ranks
+ * that own one column less leave their last DimUp elements unused) -- exactly what an
+ * equal-count ncclAllGather / MPI_Allgather of the padded slabs produces; hxv_fullvec_elems()
+ * elements in all.  For nranks==1 this is the plain vector (Dim elements).  d_hv_local: this
+ * rank's slab (vecdim elements), overwritten.  Asynchronous on `stream` (a hipStream_t; NULL = the legacy
  * default stream, as in every HIP API), so it orders with the caller's other work on that
  * stream.  d_v_full and d_hv_local must not overlap.                                     */
 int hxv_apply_device(hxv_handle *h, const void *d_v_full, void *d_hv_local, void *stream);
+/* number of complex elements of the all-gather layout above (= Dim when nranks==1) */
+int64_t hxv_fullvec_elems(const hxv_handle *h);
 
 /* Time `nrep` back-to-back device products with HIP events recorded on the stream the
  * kernels are launched on; returns the mean milliseconds per product.                    */
@@ -96,7 +101,8 @@ int hxv_time_apply(hxv_handle *h, const void *d_v_full, void *d_hv_local, int32_
  *   filled as alanc(k)=<q_k|H|q_k>, blanc(k+1)=beta_{k+1}, blanc(1)=0 (ED_GF_NORMAL.f90:949-951);
  *   *nsteps = iterations done (early exit when beta < threshold).
  * eigh: lowest eigenvalue *egs and eigenvector d_vect (device, Dim, written) from a
- *   deterministic start vector; stops when |dE| < threshold or at nitermax (ED_DIAG.f90:176). */
+ *   deterministic start vector; stops when |dE| < threshold (and, if d_vect is wanted, the Ritz
+ *   residual estimate |beta*y_last| < 1e-11*max(1,|E|)) or at nitermax (ED_DIAG.f90:176).     */
 int hxv_lanczos_tridiag(hxv_handle *h, const void *d_vin, int32_t nlanc, double *alanc, double *blanc, double threshold,
                         int32_t *nsteps);
 int hxv_lanczos_eigh(hxv_handle *h, int32_t nitermax, double threshold, double *egs, void *d_vect, int32_t *niter);

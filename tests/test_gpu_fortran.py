@@ -1,0 +1,37 @@
+"""The Fortran host (flang, ISO_C_BINDING glue) drives the engine through the reference's procedure-pointer
+surface: spHtimesV_p => gpuMatVec_main, Lanczos on host arrays."""
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fortran_host_through_procedure_pointer(built):
+    from hxv import models
+    from oracle.oracle import OracleSector
+
+    exe = built.build_fortran()
+    if exe is None:
+        pytest.skip("flang not available")
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    txt = out.stdout
+    e0_c1 = float(re.search(r"C1 plaquette.*E0=\s*([-\d.Ee+]+)", txt).group(1))
+    assert abs(e0_c1 - (-2.10274848)) < 5e-9                      # reference dense H
+    ref = np.linalg.eigvalsh(OracleSector(models.plaquette_2x2_nobath(U=4.0, t=1.0, hfmode=False), 2, 2).dense())[0]
+    assert abs(e0_c1 - ref) < 1e-9
+    m = models.hm_1dchain(eps_bath=[0.3, 0.6])
+    orc = OracleSector(m, 6, 6)
+    v = models.deterministic_vector(orc.Dim)
+    hv = orc.spMatVec_main(v)
+    nums = re.search(r"C2 chain.*Hv\(1\),Hv\(Dim\)=\s*(.*)", txt).group(1).split()
+    got = [float(x) for x in nums]
+    want = [hv[0].real, hv[0].imag, hv[-1].real, hv[-1].imag]
+    assert np.allclose(got, want, rtol=1e-12, atol=1e-13)
+    e0_c2 = float(re.search(r"C2 chain sector\(6,6\) Dim=\s*\d+ E0=\s*([-\d.Ee+]+)", txt).group(1))
+    a, b = orc.lanc_tridiag(v / np.linalg.norm(v), 200)
+    T = np.diag(a) + np.diag(b[1:], 1) + np.diag(b[1:], -1)
+    assert abs(e0_c2 - np.linalg.eigvalsh(T)[0]) < 1e-9

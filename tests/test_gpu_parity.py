@@ -77,7 +77,8 @@ def test_tiled_vs_naive_c3_slice(built):
     m = models.hm_2dsquare(Nbath=3)
     sec = hxv.HxvSector.from_model(m, 8, 8, rank=3, nranks=64)  # a 201/202-column slab of the full sector
     g = torch.Generator(device="cuda").manual_seed(1)
-    v = torch.randn(sec.Dim, dtype=torch.float64, device="cuda", generator=g) + 1j * torch.randn(sec.Dim, dtype=torch.float64, device="cuda", generator=g)
+    n = sec.fullElems
+    v = torch.randn(n, dtype=torch.float64, device="cuda", generator=g) + 1j * torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
     sec.set_option("kernel", 0)
     a = sec.apply_device(v).clone()
     sec.set_option("kernel", 1)
@@ -120,7 +121,7 @@ def test_tiled_outer_path_and_shards_match_oracle(built, bits, shard):
         assert (sec.vecDim, sec.mpiQdw, sec.mpiIshift) == (orc.vecDim, orc.mpiQdw, orc.mpiIshift)
         v = models.deterministic_vector(sec.Dim)
         ref = _slab_reference(orc, v)
-        dv = torch.from_numpy(v).cuda()
+        dv = torch.from_numpy(sec.to_gather_layout(v, size)).cuda()
         for cols, rows, threads in ((2, 4, 256), (4, 8, 512), (8, 16, 256)):
             sec.set_option("tile_bits_up", bits[0])
             sec.set_option("tile_bits_dw", bits[1])
@@ -150,7 +151,7 @@ def test_c3_slab_matches_oracle_matrices(built):
     rng = np.random.default_rng(7)
     v = rng.standard_normal(sec.Dim) + 1j * rng.standard_normal(sec.Dim)
     ref = _slab_reference(orc, v)
-    dv = torch.from_numpy(v).cuda()
+    dv = torch.from_numpy(sec.to_gather_layout(v, 64)).cuda()
     for kernel in (0, 1):
         sec.set_option("kernel", kernel)
         hv = sec.apply_device(dv)
