@@ -133,8 +133,11 @@ int finish_create(hxv_handle* h, int device, hxv_handle** out) {
   d.real_h = (s.up.real_vals && s.dw.real_vals) ? 1 : 0;
   HC(h->alloc(&h->d_partials, 2 * RED_BLOCKS));
   HC(h->alloc(&h->d_scalars, 8));
-  std::string perr = make_tile_plan(s, h->plan, [&](const std::vector<uint32_t>& v, uint32_t** p) { return h->upload(p, v); });
+  PlanUploader pu{[h](const std::vector<uint32_t>& v, uint32_t** p) { return h->upload(p, v); },
+                  [h](const std::vector<double2>& v, double2** p) { return h->upload(p, v); }};
+  std::string perr = make_tile_plan(s, h->plan, pu);
   if (!perr.empty()) return cleanup(HXV_ERR_HIP, perr);
+  if (!h->plan.usable) h->kernel = 0;  // too many distinct amplitudes for the LDS coefficient table
 #undef HC
   *out = h;
   return HXV_OK;
@@ -209,7 +212,7 @@ int hxv_apply_device(hxv_handle* h, const void* d_v_full, void* d_hv_local, void
   if (!h || !d_v_full || !d_hv_local) return fail(HXV_ERR_ARG, "hxv_apply_device: NULL argument");
   hipStream_t st = (hipStream_t)stream;  // NULL = the legacy default stream, as everywhere in HIP
   hipError_t e;
-  if (h->kernel == 0)
+  if (h->kernel == 0 || !h->plan.usable)
     e = launch_hxv_naive(h->dev, (const double2*)d_v_full, (double2*)d_hv_local, st);
   else
     e = launch_hxv_tiled(h->dev, h->plan, (const double2*)d_v_full, (double2*)d_hv_local, st);
@@ -295,6 +298,15 @@ int hxv_set_option(hxv_handle* h, const char* name, int64_t value) {
     h->kernel = (int)value;
     return HXV_OK;
   }
+  if (!strcmp(name, "lds_min_kb_up") || !strcmp(name, "lds_min_kb_dw")) {
+    if (value < 0 || value > 160) return fail(HXV_ERR_ARG, "lds_min_kb must be in [0,160]");
+    (name[11] == 'u' ? h->plan.opt.lds_min_kb_up : h->plan.opt.lds_min_kb_dw) = (int)value;
+    return HXV_OK;
+  }
+  if (!strcmp(name, "debug")) {
+    h->plan.opt.debug = (int)value;
+    return HXV_OK;
+  }
   if (!strcmp(name, "passes")) {
     if (value < 1 || value > 3) return fail(HXV_ERR_ARG, "passes must be 1, 2 or 3");
     h->plan.opt.passes = (int)value;
@@ -311,12 +323,16 @@ int hxv_set_option(hxv_handle* h, const char* name, int64_t value) {
   else if (!strcmp(name, "tile_bits_dw")) o.force_bits_dw = (int)value;
   else if (!strcmp(name, "threads_up")) o.threads_up = (int)value;
   else if (!strcmp(name, "threads_dw")) o.threads_dw = (int)value;
+  else if (!strcmp(name, "sort_mode")) o.sort_mode = (int)value;
+  else if (!strcmp(name, "sort_mode_dw")) o.sort_mode_dw = (int)value;
   else return fail(HXV_ERR_ARG, std::string("unknown option ") + name);
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipStreamSynchronize(h->stream));
   TilePlan np;
   np.opt = o;
-  std::string perr = make_tile_plan(h->host, np, [&](const std::vector<uint32_t>& v, uint32_t** p) { return h->upload(p, v); });
+  PlanUploader pu{[h](const std::vector<uint32_t>& v, uint32_t** p) { return h->upload(p, v); },
+                  [h](const std::vector<double2>& v, double2** p) { return h->upload(p, v); }};
+  std::string perr = make_tile_plan(h->host, np, pu);
   if (!perr.empty()) return fail(HXV_ERR_ARG, perr);
   h->plan = np;
   return HXV_OK;
@@ -339,6 +355,11 @@ int64_t hxv_get_option(const hxv_handle* h, const char* name) {
   if (!strcmp(name, "n_out_up")) return h->plan.up.n_out;
   if (!strcmp(name, "n_in_dw")) return h->plan.dw.n_in;
   if (!strcmp(name, "n_out_dw")) return h->plan.dw.n_out;
+  if (!strcmp(name, "slots_in_up_x100")) return (int64_t)(100 * h->plan.up.slots_in);
+  if (!strcmp(name, "slots_out_up_x100")) return (int64_t)(100 * h->plan.up.slots_out);
+  if (!strcmp(name, "slots_in_dw_x100")) return (int64_t)(100 * h->plan.dw.slots_in);
+  if (!strcmp(name, "max_block_up")) return h->plan.up.max_block;
+  if (!strcmp(name, "max_block_dw")) return h->plan.dw.max_block;
   if (!strcmp(name, "nblocks_up")) return h->plan.up.nblocks;
   if (!strcmp(name, "nblocks_dw")) return h->plan.dw.nblocks;
   return -1;

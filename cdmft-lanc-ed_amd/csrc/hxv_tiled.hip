@@ -1,0 +1,488 @@
+// Tiled two-pass kernels (gfx950) and their plan builder.
+//
+//   pass A (hxv_pass_up):  hv  = D.v + H_up v      tile = [up prefix block] x [C columns]
+//   pass B (hxv_pass_dw):  hv += v H_dw^T          tile = [R rows] x [dw prefix block]
+//
+// A "block" is a prefix block of the sorted spin basis (hxv_tiles.hpp): hops among its low
+// orbitals stay inside the tile and are gathered from LDS; hops that touch a high orbital read
+// another block of the same columns (pass A) / rows (pass B) from global memory, and the
+// workgroups that share those columns/rows carry the same blockIdx%8 (one XCD) so these reads
+// hit its L2.  Reference semantics: ED_HAMILTONIAN_SPARSE_HxV.f90:167-227 / :230-315.
+#include <algorithm>
+#include <numeric>
+
+#include "hxv_device.hpp"
+#include "hxv_tiles.hpp"
+
+namespace hxv {
+
+struct DevTiles {
+  const uint32_t* start;   // [nblocks+1]
+  const uint32_t* perm;    // [dim]   sorted position -> index
+  const uint32_t* gstart;  // [nblocks+1] first 64-position group of each block
+  const uint32_t* gmax;    // [groups] k_in max | k_out max << 16
+  const uint32_t* ell_in;  // [k_in][dim]
+  const uint32_t* ell_out; // [k_out][dim]
+  const double2* scoef;    // [nscoef] signed coefficients, last = 0
+  int nblocks, nscoef;
+  int debug;  // timing experiments only: 1 skip out-of-block hops, 2 skip in-block hops, 4 skip the hv read-modify-write (pass B)
+};
+
+constexpr int HOP_CHUNK = 4;
+constexpr int MAX_PAIRS = 8;  // pass B: (row,column) pairs of a tile per thread, kept in registers
+
+// Streaming accesses to hv: it is read/written exactly once per pass, keep it from evicting the v lines that
+// sibling workgroups of the same XCD are about to gather from L2.
+typedef double dbl2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 load_stream(const double2* p) {
+  dbl2_t x = __builtin_nontemporal_load(reinterpret_cast<const dbl2_t*>(p));
+  return make_double2(x.x, x.y);
+}
+__device__ __forceinline__ void store_stream(double2* p, double2 a) {
+  dbl2_t x;
+  x.x = a.x;
+  x.y = a.y;
+  __builtin_nontemporal_store(x, reinterpret_cast<dbl2_t*>(p));
+}
+
+constexpr uint32_t TILE_OFF_MASK = (1u << TILE_COEF_SHIFT) - 1u;
+
+template <bool REAL>
+struct Coef;
+template <>
+struct Coef<true> {
+  using type = double;
+  static __device__ __forceinline__ void fma(double2& acc, double c, double2 x) {
+    acc.x = ::fma(c, x.x, acc.x);
+    acc.y = ::fma(c, x.y, acc.y);
+  }
+  static __device__ __forceinline__ double from(double2 c) { return c.x; }
+};
+template <>
+struct Coef<false> {
+  using type = double2;
+  static __device__ __forceinline__ void fma(double2& acc, double2 c, double2 x) { cfma(acc, c, x); }
+  static __device__ __forceinline__ double2 from(double2 c) { return c; }
+};
+
+template <bool NORB1>
+__device__ __forceinline__ double diag_value(const DevDiag& dg, double au, uint32_t mu, int c) {
+  const uint32_t md = dg.map_dw[c];
+  if (NORB1) return au + dg.a_dw[c] + dg.cross.uloc[0] * (double)__popc(mu & md & dg.cross.orbmask[0]);
+  return au + dg.a_dw[c] + diag_cross(dg.cross, mu, md);
+}
+
+// ---------------------------------------------------------------------------------------
+// pass A
+// ---------------------------------------------------------------------------------------
+template <int C, bool REAL, bool NORB1>
+__global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, const double2* __restrict__ v, double2* __restrict__ hv,
+                                                   int ngroups) {
+  using CT = typename Coef<REAL>::type;
+  extern __shared__ double2 lds[];
+  const int b = blockIdx.x;
+  const int xcd = b & 7, j = b >> 3;
+  const int g = (j / t.nblocks) * 8 + xcd;  // column group; all blocks of a group share blockIdx%8 (= one XCD)
+  const int kb = j - (j / t.nblocks) * t.nblocks;
+  if (g >= ngroups) return;
+  const int T = blockDim.x;
+  const int r0 = (int)t.start[kb];
+  const int n = (int)t.start[kb + 1] - r0;
+  const int c0 = g * C;  // local column
+  const int nc = min(C, s.qdw - c0);
+  CT* lcoef = reinterpret_cast<CT*>(lds + C * n);
+  const double2* __restrict__ vcol0 = v + (int64_t)(s.slab0 + c0) * s.dimup;
+#pragma unroll
+  for (int cc = 0; cc < C; ++cc) {
+    const double2* __restrict__ src = vcol0 + (int64_t)min(cc, nc - 1) * s.dimup + r0;
+    for (int r = threadIdx.x; r < n; r += T) lds[cc * n + r] = src[r];
+  }
+  for (int q = threadIdx.x; q < t.nscoef; q += T) lcoef[q] = Coef<REAL>::from(t.scoef[q]);
+  __syncthreads();
+  const uint32_t g0 = t.gstart[kb];
+  for (int p = threadIdx.x; p < n; p += T) {
+    const uint32_t packed = __builtin_amdgcn_readfirstlane(t.gmax[g0 + (p >> 6)]);
+    const int kin = (int)(packed & 0xFFFFu), kout = (int)(packed >> 16);
+    const int i = (int)t.perm[r0 + p];
+    const int r = i - r0;
+    double2 acc[C];
+    if (s.diag.mode == 0) {
+      const double au = s.diag.a_up[i];
+      const uint32_t mu = s.diag.map_up[i];
+#pragma unroll
+      for (int cc = 0; cc < C; ++cc) {
+        const double d = diag_value<NORB1>(s.diag, au, mu, s.dw0 + min(c0 + cc, s.qdw - 1));
+        const double2 x = lds[cc * n + r];
+        acc[cc] = make_double2(d * x.x, d * x.y);
+      }
+    } else {
+#pragma unroll
+      for (int cc = 0; cc < C; ++cc) {
+        const double d = s.diag.stored[(int64_t)min(c0 + cc, s.qdw - 1) * s.dimup + i];
+        const double2 x = lds[cc * n + r];
+        acc[cc] = make_double2(d * x.x, d * x.y);
+      }
+    }
+    // hops that leave the block: gathers from global memory (L2 of this XCD)
+    for (int k0 = 0; k0 < ((t.debug & 1) ? 0 : kout); k0 += HOP_CHUNK) {
+      uint32_t e[HOP_CHUNK];
+#pragma unroll
+      for (int u = 0; u < HOP_CHUNK; ++u) e[u] = t.ell_out[(int64_t)(k0 + u) * s.dimup + r0 + p];
+#pragma unroll
+      for (int u = 0; u < HOP_CHUNK; ++u) {
+        const CT cf = lcoef[e[u] >> TILE_COEF_SHIFT];
+        const double2* __restrict__ src = vcol0 + (e[u] & TILE_OFF_MASK);
+#pragma unroll
+        for (int cc = 0; cc < C; ++cc) Coef<REAL>::fma(acc[cc], cf, src[(int64_t)min(cc, nc - 1) * s.dimup]);
+      }
+    }
+    // hops inside the block: gathers from the LDS tile
+    for (int k0 = 0; k0 < ((t.debug & 2) ? 0 : kin); k0 += HOP_CHUNK) {
+      uint32_t e[HOP_CHUNK];
+#pragma unroll
+      for (int u = 0; u < HOP_CHUNK; ++u) e[u] = t.ell_in[(int64_t)(k0 + u) * s.dimup + r0 + p];
+#pragma unroll
+      for (int u = 0; u < HOP_CHUNK; ++u) {
+        const CT cf = lcoef[e[u] >> TILE_COEF_SHIFT];
+        const int off = (int)(e[u] & TILE_OFF_MASK);
+#pragma unroll
+        for (int cc = 0; cc < C; ++cc) Coef<REAL>::fma(acc[cc], cf, lds[cc * n + off]);
+      }
+    }
+#pragma unroll
+    for (int cc = 0; cc < C; ++cc)
+      if (cc < nc) store_stream(&hv[(int64_t)(c0 + cc) * s.dimup + i], acc[cc]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// pass B.  The tile is kept TRANSPOSED in LDS (lds[r*n + col]) so that in the inner phase a
+// thread owns one column and R rows: one ELL decode serves R gathers.  The out-of-block hops
+// are done afterwards with lanes along the contiguous row direction (coalesced 16*R-byte
+// segments of other columns), after the inner sums have been parked in the tile.
+// ---------------------------------------------------------------------------------------
+template <int R, bool REAL>
+__global__ void __launch_bounds__(1024, 8) hxv_pass_dw(DevSector s, DevTiles t, const double2* __restrict__ v, double2* __restrict__ hv,
+                                                   int ngroups, int groups_per_xcd) {
+  using CT = typename Coef<REAL>::type;
+  extern __shared__ double2 lds[];
+  const int b = blockIdx.x;
+  const int xcd = b & 7, j = b >> 3;
+  const int gl = j / t.nblocks;
+  const int kb = j - gl * t.nblocks;
+  const int rg = xcd * groups_per_xcd + gl;  // contiguous row ranges per XCD: neighbouring row groups share cache lines
+  if (gl >= groups_per_xcd || rg >= ngroups) return;
+  const int cb0 = (int)t.start[kb];
+  const int n = (int)t.start[kb + 1] - cb0;
+  if (cb0 + n <= s.dw0 || cb0 >= s.dw0 + s.qdw) return;  // block holds no local output column
+  const int T = blockDim.x;
+  const int i0 = rg * R;
+  CT* lcoef = reinterpret_cast<CT*>(lds + R * n);
+  // phase 0: tile load, lanes along rows (R*16 B contiguous per column), transposed store; in the same
+  // mapping the out-of-block hops are gathered right away -- the sibling workgroups of this row group are
+  // loading exactly those lines now, so they are as fresh in this XCD's L2 as they will ever be.
+  const uint32_t emptyz = (uint32_t)(t.nscoef - 1) << TILE_COEF_SHIFT;
+  for (int q = threadIdx.x; q < t.nscoef; q += T) lcoef[q] = Coef<REAL>::from(t.scoef[q]);
+  for (int q = threadIdx.x; q < n * R; q += T) {
+    const int r = q % R, col = q / R;
+    const int irow = min(i0 + r, s.dimup - 1);
+    lds[r * n + col] = v[(int64_t)s.vcol[cb0 + col] * s.dimup + irow];
+  }
+  __syncthreads();
+  double2 osum[MAX_PAIRS];
+#pragma unroll
+  for (int it = 0; it < MAX_PAIRS; ++it) {
+    const int q = threadIdx.x + it * T;
+    osum[it] = make_double2(0.0, 0.0);
+    if (q < n * R) {
+      const int r = q % R, col = q / R;
+      const int c = cb0 + col;
+      const int irow = min(i0 + r, s.dimup - 1);
+      double2 a = make_double2(0.0, 0.0);
+      for (int k0 = 0;; k0 += HOP_CHUNK) {
+        uint32_t e[HOP_CHUNK];
+#pragma unroll
+        for (int u = 0; u < HOP_CHUNK; ++u) e[u] = t.ell_out[(int64_t)(k0 + u) * s.dimdw + c];
+        if (__all(e[0] == emptyz) || (t.debug & 1)) break;
+#pragma unroll
+        for (int u = 0; u < HOP_CHUNK; ++u) {
+          const CT cf = lcoef[e[u] >> TILE_COEF_SHIFT];
+          Coef<REAL>::fma(a, cf, v[(int64_t)(e[u] & TILE_OFF_MASK) * s.dimup + irow]);
+        }
+      }
+      osum[it] = a;
+    }
+  }
+  // phase 1: in-block hops, one column per thread (plan guarantees n <= blockDim.x)
+  const int p = threadIdx.x;
+  double2 acc[R];
+  int col1 = 0;
+  if (p < n) {
+    const uint32_t packed = __builtin_amdgcn_readfirstlane(t.gmax[t.gstart[kb] + (p >> 6)]);
+    const int kin = (int)(packed & 0xFFFFu);
+    col1 = (int)t.perm[cb0 + p] - cb0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = make_double2(0.0, 0.0);
+    for (int k0 = 0; k0 < ((t.debug & 2) ? 0 : kin); k0 += HOP_CHUNK) {
+      uint32_t e[HOP_CHUNK];
+#pragma unroll
+      for (int u = 0; u < HOP_CHUNK; ++u) e[u] = t.ell_in[(int64_t)(k0 + u) * s.dimdw + cb0 + p];
+#pragma unroll
+      for (int u = 0; u < HOP_CHUNK; ++u) {
+        const CT cf = lcoef[e[u] >> TILE_COEF_SHIFT];
+        const int off = (int)(e[u] & TILE_OFF_MASK);
+#pragma unroll
+        for (int r = 0; r < R; ++r) Coef<REAL>::fma(acc[r], cf, lds[r * n + off]);
+      }
+    }
+  }
+  __syncthreads();
+  if (p < n) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) lds[r * n + col1] = acc[r];
+  }
+  __syncthreads();
+  // phase 2: hv += inner + outer, lanes along rows, streaming read-modify-write
+#pragma unroll
+  for (int it = 0; it < MAX_PAIRS; ++it) {
+    const int q = threadIdx.x + it * T;
+    if (q < n * R) {
+      const int r = q % R, col = q / R;
+      const int c = cb0 + col;
+      if ((c >= s.dw0) && (c < s.dw0 + s.qdw) && (i0 + r < s.dimup)) {
+        const int64_t o = (int64_t)(c - s.dw0) * s.dimup + i0 + r;
+        double2 a = (t.debug & 4) ? make_double2(0.0, 0.0) : load_stream(&hv[o]);
+        const double2 inner = lds[r * n + col];
+        a.x += inner.x + osum[it].x;
+        a.y += inner.y + osum[it].y;
+        store_stream(&hv[o], a);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// plan builder (host)
+// ---------------------------------------------------------------------------------------
+namespace {
+
+int64_t binom64(int n, int k) {
+  if (k < 0 || k > n) return 0;
+  k = std::min(k, n - k);
+  int64_t r = 1;
+  for (int i = 1; i <= k; ++i) r = r * (n - k + i) / i;
+  return r;
+}
+
+int choose_lowbits(int ns, int npart, int width, int budget_bytes, int max_block) {
+  // largest number of low orbitals whose biggest block fits width x 16 B in the budget
+  for (int L = ns; L >= 0; --L) {
+    int64_t mx = 0;
+    for (int p = 0; p <= ns - L; ++p) mx = std::max(mx, binom64(L, npart - p));
+    if (mx * width * 16 <= budget_bytes && mx <= max_block) return L;
+  }
+  return 0;
+}
+
+struct HostTiles {
+  std::vector<uint32_t> start, perm, gstart, gmax, ell_in, ell_out;
+};
+
+// sorted_out: outer table indexed by sorted position (pass A) or by natural index (pass B)
+void build_spin_tiles(const SpinOp& op, const std::vector<uint32_t>& map, int lowbits, int chunk, const std::vector<uint32_t>* vcol,
+                      int sort_mode, bool sorted_out, SpinTiles& t, HostTiles& h) {
+  const int dim = op.dim;
+  h.start.clear();
+  if (!map.empty()) {
+    uint32_t prev = 0xFFFFFFFFu;
+    for (int i = 0; i < dim; ++i) {
+      uint32_t hi = lowbits >= 32 ? 0u : (map[i] >> lowbits);
+      if (hi != prev) {
+        h.start.push_back((uint32_t)i);
+        prev = hi;
+      }
+    }
+  } else {
+    for (int i = 0; i < dim; i += chunk) h.start.push_back((uint32_t)i);
+  }
+  h.start.push_back((uint32_t)dim);
+  t.start = h.start;
+  t.lowbits = lowbits;
+  t.nblocks = (int)h.start.size() - 1;
+  t.max_block = 0;
+  std::vector<uint32_t> block_of(dim);
+  for (int k = 0; k < t.nblocks; ++k) {
+    t.max_block = std::max<int>(t.max_block, (int)(h.start[k + 1] - h.start[k]));
+    for (uint32_t i = h.start[k]; i < h.start[k + 1]; ++i) block_of[i] = (uint32_t)k;
+  }
+  std::vector<int> cin(dim, 0), cout(dim, 0);
+  t.n_in = t.n_out = 0;
+  for (int i = 0; i < dim; ++i) {
+    for (int64_t p = op.rowptr[i]; p < op.rowptr[i + 1]; ++p) (block_of[op.cols[p]] == block_of[i] ? cin[i] : cout[i])++;
+    t.n_in += cin[i];
+    t.n_out += cout[i];
+  }
+  const int kin = *std::max_element(cin.begin(), cin.end()), kout = *std::max_element(cout.begin(), cout.end());
+  auto pad4 = [](int k) { return std::max(HOP_CHUNK, (k + HOP_CHUNK - 1) / HOP_CHUNK * HOP_CHUNK); };
+  // one extra all-empty chunk on the natural-order outer table terminates its "all lanes empty" loop
+  t.k_in = pad4(kin);
+  t.k_out = pad4(kout) + (sorted_out ? 0 : HOP_CHUNK);
+  // visiting order inside each block
+  h.perm.resize(dim);
+  std::iota(h.perm.begin(), h.perm.end(), 0u);
+  for (int k = 0; k < t.nblocks; ++k) {
+    auto first = h.perm.begin() + h.start[k], last = h.perm.begin() + h.start[k + 1];
+    if (sort_mode == 1)
+      std::stable_sort(first, last, [&](uint32_t a, uint32_t b) { return cin[a] > cin[b]; });
+    else if (sort_mode == 2)
+      std::stable_sort(first, last, [&](uint32_t a, uint32_t b) { return cout[a] != cout[b] ? cout[a] > cout[b] : cin[a] > cin[b]; });
+  }
+  // 64-position groups and their loop bounds
+  h.gstart.assign(t.nblocks + 1, 0);
+  h.gmax.clear();
+  double sl_in = 0, sl_out = 0;
+  for (int k = 0; k < t.nblocks; ++k) {
+    h.gstart[k] = (uint32_t)h.gmax.size();
+    for (uint32_t a = h.start[k]; a < h.start[k + 1]; a += 64) {
+      int mi = 0, mo = 0;
+      const uint32_t bnd = std::min<uint32_t>(a + 64, h.start[k + 1]);
+      for (uint32_t q = a; q < bnd; ++q) {
+        mi = std::max(mi, cin[h.perm[q]]);
+        mo = std::max(mo, cout[h.perm[q]]);
+      }
+      h.gmax.push_back((uint32_t)mi | ((uint32_t)mo << 16));
+      sl_in += (double)(bnd - a) * ((mi + HOP_CHUNK - 1) / HOP_CHUNK * HOP_CHUNK);
+      sl_out += (double)(bnd - a) * ((mo + HOP_CHUNK - 1) / HOP_CHUNK * HOP_CHUNK);
+    }
+  }
+  h.gstart[t.nblocks] = (uint32_t)h.gmax.size();
+  t.slots_in = sl_in / dim;
+  t.slots_out = sl_out / dim;
+  // tables
+  const uint32_t emptyz = (uint32_t)(2 * op.coef.size()) << TILE_COEF_SHIFT;
+  h.ell_in.assign((size_t)t.k_in * dim, emptyz);
+  h.ell_out.assign((size_t)t.k_out * dim, emptyz);
+  std::vector<uint32_t> pos_of(dim);
+  for (int q = 0; q < dim; ++q) pos_of[h.perm[q]] = (uint32_t)q;
+  for (int i = 0; i < dim; ++i) {
+    int a = 0, b = 0, k = 0;
+    const size_t qi = pos_of[i], qo = sorted_out ? pos_of[i] : (size_t)i;
+    for (int64_t p = op.rowptr[i]; p < op.rowptr[i + 1]; ++p, ++k) {
+      const uint32_t e = op.ell[(size_t)k * dim + i];  // same order as the CSR row
+      const uint32_t src = e & ELL_SRC_MASK;
+      const uint32_t ci = (2u * ((e >> ELL_SRC_BITS) & ELL_COEF_MASK) + (e >> 31)) << TILE_COEF_SHIFT;
+      if (block_of[src] == block_of[i])
+        h.ell_in[(size_t)(a++) * dim + qi] = ci | (src - h.start[block_of[i]]);
+      else
+        h.ell_out[(size_t)(b++) * dim + qo] = ci | (vcol ? (*vcol)[src] : src);
+    }
+  }
+}
+
+template <int C>
+hipError_t launch_up(const DevSector& s, const DevTiles& t, int lds_bytes, int threads, bool norb1, const double2* v, double2* hv,
+                     hipStream_t st) {
+  const int ngroups = (s.qdw + C - 1) / C;
+  const int64_t nwg = (int64_t)((ngroups + 7) / 8) * 8 * t.nblocks;
+  void (*kern)(DevSector, DevTiles, const double2*, double2*, int);
+  if (s.real_h)
+    kern = norb1 ? hxv_pass_up<C, true, true> : hxv_pass_up<C, true, false>;
+  else
+    kern = norb1 ? hxv_pass_up<C, false, true> : hxv_pass_up<C, false, false>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(threads), (size_t)lds_bytes, st, s, t, v, hv, ngroups);
+  return hipGetLastError();
+}
+
+template <int R>
+hipError_t launch_dw(const DevSector& s, const DevTiles& t, int lds_bytes, int threads, const double2* v, double2* hv, hipStream_t st) {
+  const int ngroups = (s.dimup + R - 1) / R;
+  const int gpx = (ngroups + 7) / 8;
+  const int64_t nwg = (int64_t)gpx * 8 * t.nblocks;
+  auto kern = s.real_h ? hxv_pass_dw<R, true> : hxv_pass_dw<R, false>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(threads), (size_t)lds_bytes, st, s, t, v, hv, ngroups, gpx);
+  return hipGetLastError();
+}
+
+std::vector<double2> signed_coefs(const SpinOp& op) {
+  std::vector<double2> sc(2 * op.coef.size() + 1);
+  for (size_t i = 0; i < op.coef.size(); ++i) {
+    sc[2 * i] = make_double2(op.coef[i].real(), op.coef[i].imag());
+    sc[2 * i + 1] = make_double2(-op.coef[i].real(), -op.coef[i].imag());
+  }
+  sc.back() = make_double2(0.0, 0.0);
+  return sc;
+}
+
+}  // namespace
+
+std::string make_tile_plan(const SectorHost& s, TilePlan& plan, const PlanUploader& up) {
+  TileOptions& o = plan.opt;
+  if (o.cols_per_tile != 2 && o.cols_per_tile != 4 && o.cols_per_tile != 8) return "cols_per_tile must be 2, 4 or 8";
+  if (o.rows_per_tile != 2 && o.rows_per_tile != 4 && o.rows_per_tile != 8) return "rows_per_tile must be 2, 4 or 8";
+  if (o.lds_budget_kb_up < 8 || o.lds_budget_kb_up > 144 || o.lds_budget_kb_dw < 8 || o.lds_budget_kb_dw > 144)
+    return "lds_budget_kb must be in [8,144]";
+  for (int th : {o.threads_up, o.threads_dw})
+    if (th != 256 && th != 512 && th != 1024) return "threads must be 256, 512 or 1024";
+  if (o.sort_mode < 0 || o.sort_mode > 2) return "sort_mode must be 0, 1 or 2";
+  plan.ncoef_up = (int)s.up.coef.size();
+  plan.ncoef_dw = (int)s.dw.coef.size();
+  plan.usable = plan.ncoef_up <= TILE_MAX_COEF && plan.ncoef_dw <= TILE_MAX_COEF;
+  if (!plan.usable) return "";
+  HostTiles h;
+  auto one = [&](const SpinOp& op, const std::vector<uint32_t>& map, int npart, int width, int force, int budget_kb, int max_block,
+                 const std::vector<uint32_t>* vcol, bool sorted_out, int sort_mode, SpinTiles& t) -> std::string {
+    const int budget = budget_kb * 1024 - 16 * (2 * (int)op.coef.size() + 1);
+    int L = 32, chunk = std::max(1, std::min(budget / (16 * width), max_block));
+    if (!map.empty()) L = force >= 0 ? std::min(force, s.ns) : choose_lowbits(s.ns, npart, width, budget, max_block);
+    build_spin_tiles(op, map, L, chunk, vcol, sort_mode, sorted_out, t, h);
+    if ((int64_t)t.max_block * width * 16 + 16 * (2 * (int64_t)op.coef.size() + 1) > 160 * 1024) return "tile does not fit the 160 KB LDS";
+    if (t.max_block > max_block) return "block larger than the workgroup (pass B needs one thread per block column)";
+    if (up.u32(h.start, &t.d_start) != hipSuccess || up.u32(h.perm, &t.d_perm) != hipSuccess ||
+        up.u32(h.gstart, &t.d_gstart) != hipSuccess || up.u32(h.gmax, &t.d_gmax) != hipSuccess ||
+        up.u32(h.ell_in, &t.d_ell_in) != hipSuccess || up.u32(h.ell_out, &t.d_ell_out) != hipSuccess)
+      return "upload of tile tables failed";
+    return "";
+  };
+  std::string e = one(s.up, s.map_up, s.nup, o.cols_per_tile, o.force_bits_up, o.lds_budget_kb_up, 1 << 20, nullptr, true, o.sort_mode,
+                      plan.up);
+  if (!e.empty()) return e;
+  // pass B sorts by the inner count only: its outer table is read in natural column order
+  e = one(s.dw, s.map_dw, s.ndw, o.rows_per_tile, o.force_bits_dw, o.lds_budget_kb_dw, o.threads_dw, &s.vcol, false,
+          o.sort_mode_dw ? 1 : 0, plan.dw);
+  if (!e.empty()) return e;
+  if (up.d2(signed_coefs(s.up), &plan.d_scoef_up) != hipSuccess || up.d2(signed_coefs(s.dw), &plan.d_scoef_dw) != hipSuccess)
+    return "upload of coefficient tables failed";
+  return "";
+}
+
+hipError_t launch_hxv_tiled(const DevSector& s, const TilePlan& plan, const double2* v, double2* hv, hipStream_t st) {
+  if (s.qdw == 0) return hipSuccess;
+  DevTiles tu{plan.up.d_start, plan.up.d_perm, plan.up.d_gstart, plan.up.d_gmax, plan.up.d_ell_in, plan.up.d_ell_out,
+              plan.d_scoef_up, plan.up.nblocks, 2 * plan.ncoef_up + 1, plan.opt.debug};
+  DevTiles td{plan.dw.d_start, plan.dw.d_perm, plan.dw.d_gstart, plan.dw.d_gmax, plan.dw.d_ell_in, plan.dw.d_ell_out,
+              plan.d_scoef_dw, plan.dw.nblocks, 2 * plan.ncoef_dw + 1, plan.opt.debug};
+  const int C = plan.opt.cols_per_tile, R = plan.opt.rows_per_tile;
+  const int lds_a = std::max((plan.up.max_block * C + tu.nscoef) * 16, plan.opt.lds_min_kb_up * 1024);
+  const int lds_b = std::max((plan.dw.max_block * R + td.nscoef) * 16, plan.opt.lds_min_kb_dw * 1024);
+  const int ta = plan.opt.threads_up, tb = plan.opt.threads_dw;
+  const bool norb1 = s.diag.mode == 0 && s.diag.cross.norb == 1;
+  hipError_t e = hipSuccess;
+  if (plan.opt.passes & 1) switch (C) {
+      case 2: e = launch_up<2>(s, tu, lds_a, ta, norb1, v, hv, st); break;
+      case 4: e = launch_up<4>(s, tu, lds_a, ta, norb1, v, hv, st); break;
+      default: e = launch_up<8>(s, tu, lds_a, ta, norb1, v, hv, st); break;
+    }
+  if (e != hipSuccess) return e;
+  if (plan.opt.passes & 2) switch (R) {
+      case 2: e = launch_dw<2>(s, td, lds_b, tb, v, hv, st); break;
+      case 4: e = launch_dw<4>(s, td, lds_b, tb, v, hv, st); break;
+      default: e = launch_dw<8>(s, td, lds_b, tb, v, hv, st); break;
+    }
+  return e;
+}
+
+}  // namespace hxv

@@ -6,41 +6,63 @@
 
 namespace hxv {
 
+// Tiled ELL word (differs from the plain table of hxv_internal.hpp):
+//   bits  0..19  inner: source offset inside the block (LDS element offset)
+//                outer: absolute source index (pass A: row; pass B: column slot of the gather layout)
+//   bits 20..30  signed-coefficient index 2*id+sign into an LDS table of 2*ncoef+1 entries;
+//                the last entry is 0, and an empty slot is (offset 0, that entry): it gathers in
+//                bounds and adds nothing, so the hop loops carry no per-lane branch.
+constexpr int TILE_COEF_SHIFT = 20;
+constexpr int TILE_MAX_COEF = 255;  // 2*255+1 signed entries fit the LDS table comfortably
+
 // Prefix-block decomposition of one spin sector.  States that share their high (ns-lowbits)
 // bits are contiguous in the sorted basis (ED_SETUP.f90:748-773 orders by integer value) and
-// closed under every hop among the low orbitals.  The ELL table is split accordingly:
-//   inner: source inside the row's own block, stored RELATIVE to the block start (LDS offset)
-//   outer: source in another block, stored as the absolute index (global-memory gather)
+// closed under every hop among the low orbitals.  Inside a block the rows are visited in an
+// order sorted by their entry counts so the 64 lanes of a wave carry equally long hop lists.
 struct SpinTiles {
   int lowbits = 0;
   int nblocks = 0;
   int max_block = 0;
   int k_in = 0, k_out = 0;
   int64_t n_in = 0, n_out = 0;       // entry counts (statistics)
+  double slots_in = 0, slots_out = 0;  // processed slots per row after sorting (statistics)
   std::vector<uint32_t> start;       // [nblocks+1]
   uint32_t* d_start = nullptr;
-  uint32_t* d_ell_in = nullptr;      // [k_in][dim]
-  uint32_t* d_ell_out = nullptr;     // [k_out][dim]
+  uint32_t* d_perm = nullptr;        // [dim] sorted position -> index
+  uint32_t* d_gstart = nullptr;      // [nblocks+1] first 64-lane group of each block
+  uint32_t* d_gmax = nullptr;        // [ngroups] k_in max | k_out max << 16 of each 64-position group
+  uint32_t* d_ell_in = nullptr;      // [k_in][dim], indexed by sorted position
+  uint32_t* d_ell_out = nullptr;     // [k_out][dim], pass A: by sorted position; pass B: by natural column
 };
 
 struct TileOptions {
-  int cols_per_tile = 4;    // pass A (up hops): columns per workgroup tile
-  int rows_per_tile = 8;    // pass B (dw hops): rows per workgroup tile
+  int cols_per_tile = 4;      // pass A (up hops): columns per workgroup tile
+  int rows_per_tile = 4;      // pass B (dw hops): rows per workgroup tile
   int lds_budget_kb_up = 64;  // LDS per workgroup tile, pass A
-  int lds_budget_kb_dw = 16;  // LDS per workgroup tile, pass B (small tiles keep one row group per XCD in flight)
+  int lds_budget_kb_dw = 64;  // LDS per workgroup tile, pass B
   int force_bits_up = -1, force_bits_dw = -1;
-  int threads_up = 512, threads_dw = 256;
-  int passes = 3;  // bit 0: pass A (diag + up hops), bit 1: pass B (dw hops); timing experiments only
+  int threads_up = 1024, threads_dw = 1024;
+  int sort_mode = 0;  // pass A visiting order: 0 natural (keeps global accesses coalesced), 1 by inner count, 2 by (outer, inner)
+  int sort_mode_dw = 1;  // pass B inner phase (LDS only): 0 natural, 1 by inner count
+  int lds_min_kb_up = 0, lds_min_kb_dw = 0;  // request at least this much LDS per workgroup (limits workgroups per CU)
+  int debug = 0;   // timing experiments only (see DevTiles::debug); results are wrong when non-zero
+  int passes = 3;     // bit 0: pass A (diag + up hops), bit 1: pass B (dw hops); timing experiments only
 };
 
 struct TilePlan {
   TileOptions opt;
   SpinTiles up, dw;
   int ncoef_up = 1, ncoef_dw = 1;
+  double2* d_scoef_up = nullptr;  // [2*ncoef+1] signed coefficient tables
+  double2* d_scoef_dw = nullptr;
+  bool usable = true;             // false: too many distinct amplitudes -> the engine uses kernel 0
 };
 
-using UploadU32 = std::function<hipError_t(const std::vector<uint32_t>&, uint32_t**)>;
-std::string make_tile_plan(const SectorHost& s, TilePlan& plan, const UploadU32& upload);
+struct PlanUploader {
+  std::function<hipError_t(const std::vector<uint32_t>&, uint32_t**)> u32;
+  std::function<hipError_t(const std::vector<double2>&, double2**)> d2;
+};
+std::string make_tile_plan(const SectorHost& s, TilePlan& plan, const PlanUploader& up);
 hipError_t launch_hxv_tiled(const DevSector& s, const TilePlan& plan, const double2* v_full, double2* hv_local, hipStream_t st);
 
 }  // namespace hxv

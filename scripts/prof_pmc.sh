@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: prof_pmc.sh <tag> <cfg> ; collects kernel-trace stats + PMC passes into gpurun_out/prof_<tag>
 set -e
-TAG=$1; CFG=${2:-64,4,8,512}; KERN=${3:-1}
+TAG=$1; CFG=${2:-64,4,1024,64,4,1024,0}; KERN=${3:-1}
 OUT=/root/repo/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

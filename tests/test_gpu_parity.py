@@ -122,13 +122,14 @@ def test_tiled_outer_path_and_shards_match_oracle(built, bits, shard):
         v = models.deterministic_vector(sec.Dim)
         ref = _slab_reference(orc, v)
         dv = torch.from_numpy(sec.to_gather_layout(v, size)).cuda()
-        for cols, rows, threads in ((2, 4, 256), (4, 8, 512), (8, 16, 256)):
+        for cols, rows, threads, srt in ((2, 2, 256, 0), (4, 4, 512, 1), (8, 8, 1024, 2)):
             sec.set_option("tile_bits_up", bits[0])
             sec.set_option("tile_bits_dw", bits[1])
             sec.set_option("cols_per_tile", cols)
             sec.set_option("rows_per_tile", rows)
             sec.set_option("threads_up", threads)
             sec.set_option("threads_dw", threads)
+            sec.set_option("sort_mode", srt)
             for kernel in (0, 1):
                 sec.set_option("kernel", kernel)
                 hv = sec.apply_device(dv)
