@@ -35,6 +35,7 @@ struct hxv_handle {
   // staging for hxv_apply_host
   double2* d_stage_v = nullptr;
   double2* d_stage_hv = nullptr;
+  double2* d_wt = nullptr;  // transposed dw-hop scratch of the tiled kernels (vecdim elements)
   // lanczos scratch
   double* d_partials = nullptr;  // [2][RED_BLOCKS]
   double* d_scalars = nullptr;   // [8]
@@ -130,6 +131,7 @@ int finish_create(hxv_handle* h, int device, hxv_handle** out) {
   d.dw0 = s.dw0;
   d.slab0 = s.rank * s.cmax;
   d.vcol = vcol;
+  d.vcol_identity = (s.nranks == 1) ? 1 : 0;
   d.real_h = (s.up.real_vals && s.dw.real_vals) ? 1 : 0;
   HC(h->alloc(&h->d_partials, 2 * RED_BLOCKS));
   HC(h->alloc(&h->d_scalars, 8));
@@ -186,6 +188,7 @@ int hxv_destroy(hxv_handle* h) {
   for (void* p : h->allocs) (void)hipFree(p);
   if (h->d_stage_v) (void)hipFree(h->d_stage_v);
   if (h->d_stage_hv) (void)hipFree(h->d_stage_hv);
+  if (h->d_wt) (void)hipFree(h->d_wt);
   for (auto& p : h->d_lz)
     if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -214,8 +217,15 @@ int hxv_apply_device(hxv_handle* h, const void* d_v_full, void* d_hv_local, void
   hipError_t e;
   if (h->kernel == 0 || !h->plan.usable)
     e = launch_hxv_naive(h->dev, (const double2*)d_v_full, (double2*)d_hv_local, st);
-  else
-    e = launch_hxv_tiled(h->dev, h->plan, (const double2*)d_v_full, (double2*)d_hv_local, st);
+  else {
+    if (!h->d_wt) {
+      HIPCHK(hipSetDevice(h->device));
+      const size_t bytes = std::max<size_t>((size_t)h->host.qdw * h->host.dimup, 1) * sizeof(double2);
+      HIPCHK(hipMalloc((void**)&h->d_wt, bytes));
+      h->device_bytes += (int64_t)bytes;
+    }
+    e = launch_hxv_tiled(h->dev, h->plan, (const double2*)d_v_full, h->d_wt, (double2*)d_hv_local, st);
+  }
   if (e != hipSuccess) return fail(HXV_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
   h->n_apply++;
   return HXV_OK;
@@ -380,6 +390,24 @@ int hxv_get_stats(const hxv_handle* h, hxv_stats* out) {
 }
 
 }  // extern "C"
+
+namespace hxv {
+hipError_t launch_strided_read(const double2* v, double2* out, int dimup, int ncols, int R, int n, int mode, hipStream_t st);
+}
+extern "C" int hxv_debug_strided_read(hxv_handle* h, const void* d_v, void* d_out, int32_t R, int32_t n, int32_t mode, int32_t nrep, float* ms) {
+  // micro-benchmark helper (scripts/ only; not declared in include/hxv.h)
+  if (!h || !d_v || !d_out || !ms) return 1;
+  (void)hipSetDevice(h->device);
+  (void)hipEventRecord(h->ev0, h->stream);
+  for (int i = 0; i < nrep; ++i)
+    if (launch_strided_read((const double2*)d_v, (double2*)d_out, h->host.dimup, h->host.dimdw, R, n, mode, h->stream) != hipSuccess) return 2;
+  (void)hipEventRecord(h->ev1, h->stream);
+  (void)hipEventSynchronize(h->ev1);
+  float t = 0;
+  (void)hipEventElapsedTime(&t, h->ev0, h->ev1);
+  *ms = t / nrep;
+  return 0;
+}
 
 // ===========================================================================================
 // Device Lanczos

@@ -100,6 +100,7 @@ struct DevSector {
   int qdw, dw0;           // local columns [dw0, dw0+qdw)
   int slab0;              // column slot of local column 0 in the padded all-gather layout (= rank*cmax)
   const uint32_t* vcol;   // [dimdw] column -> column slot (identity when nranks==1)
+  int vcol_identity;
   int real_h;
 };
 

@@ -29,10 +29,9 @@ struct DevTiles {
 };
 
 constexpr int HOP_CHUNK = 4;
-constexpr int MAX_PAIRS = 8;  // pass B: (row,column) pairs of a tile per thread, kept in registers
 
-// Streaming accesses to hv: it is read/written exactly once per pass, keep it from evicting the v lines that
-// sibling workgroups of the same XCD are about to gather from L2.
+// Non-temporal accesses (debug bit 8 only): measured SLOWER than plain loads/stores for the R*16-byte
+// column segments of pass B (they defeat L2 write combining), see scripts/strided_bench.py.
 typedef double dbl2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ double2 load_stream(const double2* p) {
   dbl2_t x = __builtin_nontemporal_load(reinterpret_cast<const dbl2_t*>(p));
@@ -76,8 +75,8 @@ __device__ __forceinline__ double diag_value(const DevDiag& dg, double au, uint3
 // pass A
 // ---------------------------------------------------------------------------------------
 template <int C, bool REAL, bool NORB1>
-__global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, const double2* __restrict__ v, double2* __restrict__ hv,
-                                                   int ngroups) {
+__global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, const double2* __restrict__ v,
+                                                      const double2* __restrict__ wt, double2* __restrict__ hv, int ngroups) {
   using CT = typename Coef<REAL>::type;
   extern __shared__ double2 lds[];
   const int b = blockIdx.x;
@@ -99,13 +98,15 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
   }
   for (int q = threadIdx.x; q < t.nscoef; q += T) lcoef[q] = Coef<REAL>::from(t.scoef[q]);
   __syncthreads();
-  const uint32_t g0 = t.gstart[kb];
-  for (int p = threadIdx.x; p < n; p += T) {
-    const uint32_t packed = __builtin_amdgcn_readfirstlane(t.gmax[g0 + (p >> 6)]);
+  // one row per thread (plan guarantees n <= blockDim.x)
+  const int p = threadIdx.x;
+  double2 acc[C];
+  int r = 0;
+  if (p < n) {
+    const uint32_t packed = __builtin_amdgcn_readfirstlane(t.gmax[t.gstart[kb] + (p >> 6)]);
     const int kin = (int)(packed & 0xFFFFu), kout = (int)(packed >> 16);
     const int i = (int)t.perm[r0 + p];
-    const int r = i - r0;
-    double2 acc[C];
+    r = i - r0;
     if (s.diag.mode == 0) {
       const double au = s.diag.a_up[i];
       const uint32_t mu = s.diag.map_up[i];
@@ -149,9 +150,42 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
         for (int cc = 0; cc < C; ++cc) Coef<REAL>::fma(acc[cc], cf, lds[cc * n + off]);
       }
     }
+  }
+  if (!wt) {  // timing experiments only (passes == 1): no dw part to add
+    if (p < n) {
 #pragma unroll
-    for (int cc = 0; cc < C; ++cc)
-      if (cc < nc) store_stream(&hv[(int64_t)(c0 + cc) * s.dimup + i], acc[cc]);
+      for (int cc = 0; cc < C; ++cc)
+        if (cc < nc) store_stream(&hv[(int64_t)(c0 + cc) * s.dimup + r0 + r], acc[cc]);
+    }
+    return;
+  }
+  // Park the sums in the tile, add the dw-hop part that pass B left TRANSPOSED in wt[row][local column]
+  // (C*16 contiguous bytes per row: lanes run along the C columns so a wave reads 64/C whole segments per
+  // instruction -- strided READS of short segments are cheap on this memory system, strided writes are not),
+  // then store hv with lanes along the rows.
+  __syncthreads();
+  if (p < n) {
+#pragma unroll
+    for (int cc = 0; cc < C; ++cc) lds[cc * n + r] = acc[cc];
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < n * C; q += T) {
+    const int row = q / C, cc = q % C;
+    if (cc < nc) {
+      const double2 w = wt[(int64_t)(r0 + row) * s.qdw + c0 + cc];
+      double2 a = lds[cc * n + row];
+      a.x += w.x;
+      a.y += w.y;
+      lds[cc * n + row] = a;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int cc = 0; cc < C; ++cc) {
+    if (cc < nc) {
+      double2* __restrict__ dst = hv + (int64_t)(c0 + cc) * s.dimup + r0;
+      for (int rr = threadIdx.x; rr < n; rr += T) store_stream(&dst[rr], lds[cc * n + rr]);
+    }
   }
 }
 
@@ -161,10 +195,13 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
 // are done afterwards with lanes along the contiguous row direction (coalesced 16*R-byte
 // segments of other columns), after the inner sums have been parked in the tile.
 // ---------------------------------------------------------------------------------------
-template <int R, bool REAL>
-__global__ void __launch_bounds__(1024, 8) hxv_pass_dw(DevSector s, DevTiles t, const double2* __restrict__ v, double2* __restrict__ hv,
-                                                   int ngroups, int groups_per_xcd) {
+template <int R, int NP, bool REAL>
+__global__ void __launch_bounds__(1024) hxv_pass_dw(DevSector s, DevTiles t, const double2* __restrict__ v, double2* __restrict__ wt,
+                                                      int ngroups, int groups_per_xcd) {
+  // NP = (row,column) pairs of the tile per thread (plan: max_block*R <= NP*blockDim.x); all their global
+  // loads are issued before the first use so a workgroup keeps NP (+NP*OUT_CHUNK) requests per lane in flight.
   using CT = typename Coef<REAL>::type;
+  constexpr int OUT_CHUNK = 2;
   extern __shared__ double2 lds[];
   const int b = blockIdx.x;
   const int xcd = b & 7, j = b >> 3;
@@ -177,53 +214,74 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_dw(DevSector s, DevTiles t, 
   if (cb0 + n <= s.dw0 || cb0 >= s.dw0 + s.qdw) return;  // block holds no local output column
   const int T = blockDim.x;
   const int i0 = rg * R;
+  const int npairs = n * R;
   CT* lcoef = reinterpret_cast<CT*>(lds + R * n);
-  // phase 0: tile load, lanes along rows (R*16 B contiguous per column), transposed store; in the same
-  // mapping the out-of-block hops are gathered right away -- the sibling workgroups of this row group are
-  // loading exactly those lines now, so they are as fresh in this XCD's L2 as they will ever be.
   const uint32_t emptyz = (uint32_t)(t.nscoef - 1) << TILE_COEF_SHIFT;
   for (int q = threadIdx.x; q < t.nscoef; q += T) lcoef[q] = Coef<REAL>::from(t.scoef[q]);
-  for (int q = threadIdx.x; q < n * R; q += T) {
-    const int r = q % R, col = q / R;
-    const int irow = min(i0 + r, s.dimup - 1);
-    lds[r * n + col] = v[(int64_t)s.vcol[cb0 + col] * s.dimup + irow];
-  }
-  __syncthreads();
-  double2 osum[MAX_PAIRS];
+  // phase 0: tile load, lanes along rows (R*16 B contiguous per column), transposed store
+  {
+    uint32_t slot[NP];
 #pragma unroll
-  for (int it = 0; it < MAX_PAIRS; ++it) {
-    const int q = threadIdx.x + it * T;
-    osum[it] = make_double2(0.0, 0.0);
-    if (q < n * R) {
-      const int r = q % R, col = q / R;
-      const int c = cb0 + col;
-      const int irow = min(i0 + r, s.dimup - 1);
-      double2 a = make_double2(0.0, 0.0);
-      for (int k0 = 0;; k0 += HOP_CHUNK) {
-        uint32_t e[HOP_CHUNK];
+    for (int it = 0; it < NP; ++it) {
+      const int q = min(threadIdx.x + it * T, npairs - 1);
+      const int c = cb0 + q / R;
+      slot[it] = s.vcol_identity ? (uint32_t)c : s.vcol[c];
+    }
+    double2 x[NP];
 #pragma unroll
-        for (int u = 0; u < HOP_CHUNK; ++u) e[u] = t.ell_out[(int64_t)(k0 + u) * s.dimdw + c];
-        if (__all(e[0] == emptyz) || (t.debug & 1)) break;
+    for (int it = 0; it < NP; ++it) {
+      const int q = min(threadIdx.x + it * T, npairs - 1);
+      x[it] = v[(int64_t)slot[it] * s.dimup + min(i0 + q % R, s.dimup - 1)];
+    }
 #pragma unroll
-        for (int u = 0; u < HOP_CHUNK; ++u) {
-          const CT cf = lcoef[e[u] >> TILE_COEF_SHIFT];
-          Coef<REAL>::fma(a, cf, v[(int64_t)(e[u] & TILE_OFF_MASK) * s.dimup + irow]);
-        }
-      }
-      osum[it] = a;
+    for (int it = 0; it < NP; ++it) {
+      const int q = threadIdx.x + it * T;
+      if (q < npairs) lds[(q % R) * n + q / R] = x[it];
     }
   }
-  // phase 1: in-block hops, one column per thread (plan guarantees n <= blockDim.x)
+  __syncthreads();
+  // out-of-block hops, same mapping, right away: the sibling workgroups of this row group are loading exactly
+  // those lines now, so they are as fresh in this XCD's L2 as they will ever be.
+  double2 osum[NP];
+#pragma unroll
+  for (int it = 0; it < NP; ++it) osum[it] = make_double2(0.0, 0.0);
+  if (!(t.debug & 1)) {
+    for (int k0 = 0;; k0 += OUT_CHUNK) {
+      uint32_t e[NP][OUT_CHUNK];
+      bool done = true;
+#pragma unroll
+      for (int it = 0; it < NP; ++it) {
+        const int q = min(threadIdx.x + it * T, npairs - 1);
+#pragma unroll
+        for (int u = 0; u < OUT_CHUNK; ++u) e[it][u] = t.ell_out[(int64_t)(k0 + u) * s.dimdw + cb0 + q / R];
+        done = done && (e[it][0] == emptyz);
+      }
+      if (__all(done)) break;
+      double2 x[NP][OUT_CHUNK];
+#pragma unroll
+      for (int it = 0; it < NP; ++it) {
+        const int q = min(threadIdx.x + it * T, npairs - 1);
+        const int irow = min(i0 + q % R, s.dimup - 1);
+#pragma unroll
+        for (int u = 0; u < OUT_CHUNK; ++u) x[it][u] = v[(int64_t)(e[it][u] & TILE_OFF_MASK) * s.dimup + irow];
+      }
+#pragma unroll
+      for (int it = 0; it < NP; ++it)
+#pragma unroll
+        for (int u = 0; u < OUT_CHUNK; ++u) Coef<REAL>::fma(osum[it], lcoef[e[it][u] >> TILE_COEF_SHIFT], x[it][u]);
+    }
+  }
+  // in-block hops, one column per thread (plan guarantees n <= blockDim.x)
   const int p = threadIdx.x;
   double2 acc[R];
   int col1 = 0;
   if (p < n) {
     const uint32_t packed = __builtin_amdgcn_readfirstlane(t.gmax[t.gstart[kb] + (p >> 6)]);
-    const int kin = (int)(packed & 0xFFFFu);
+    const int kin = (t.debug & 2) ? 0 : (int)(packed & 0xFFFFu);
     col1 = (int)t.perm[cb0 + p] - cb0;
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = make_double2(0.0, 0.0);
-    for (int k0 = 0; k0 < ((t.debug & 2) ? 0 : kin); k0 += HOP_CHUNK) {
+    for (int k0 = 0; k0 < kin; k0 += HOP_CHUNK) {
       uint32_t e[HOP_CHUNK];
 #pragma unroll
       for (int u = 0; u < HOP_CHUNK; ++u) e[u] = t.ell_in[(int64_t)(k0 + u) * s.dimdw + cb0 + p];
@@ -242,22 +300,24 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_dw(DevSector s, DevTiles t, 
     for (int r = 0; r < R; ++r) lds[r * n + col1] = acc[r];
   }
   __syncthreads();
-  // phase 2: hv += inner + outer, lanes along rows, streaming read-modify-write
+  // add the out-of-block sums (each tile element belongs to exactly one (row,column) pair of one thread)
 #pragma unroll
-  for (int it = 0; it < MAX_PAIRS; ++it) {
+  for (int it = 0; it < NP; ++it) {
     const int q = threadIdx.x + it * T;
-    if (q < n * R) {
-      const int r = q % R, col = q / R;
-      const int c = cb0 + col;
-      if ((c >= s.dw0) && (c < s.dw0 + s.qdw) && (i0 + r < s.dimup)) {
-        const int64_t o = (int64_t)(c - s.dw0) * s.dimup + i0 + r;
-        double2 a = (t.debug & 4) ? make_double2(0.0, 0.0) : load_stream(&hv[o]);
-        const double2 inner = lds[r * n + col];
-        a.x += inner.x + osum[it].x;
-        a.y += inner.y + osum[it].y;
-        store_stream(&hv[o], a);
-      }
+    if (q < npairs) {
+      double2 a = lds[(q % R) * n + q / R];
+      a.x += osum[it].x;
+      a.y += osum[it].y;
+      lds[(q % R) * n + q / R] = a;
     }
+  }
+  __syncthreads();
+  // store TRANSPOSED: wt[row][local column], lanes along the block's columns -> n*16 contiguous bytes per row
+  const int cl0 = max(cb0, s.dw0), cl1 = min(cb0 + n, s.dw0 + s.qdw);  // local output columns of this block
+  const int nloc = cl1 - cl0;
+  for (int q = threadIdx.x; q < nloc * R; q += T) {
+    const int r = q / nloc, col = (cl0 - cb0) + (q - r * nloc);
+    if (i0 + r < s.dimup) wt[(int64_t)(i0 + r) * s.qdw + (cb0 + col - s.dw0)] = lds[r * n + col];
   }
 }
 
@@ -380,31 +440,41 @@ void build_spin_tiles(const SpinOp& op, const std::vector<uint32_t>& map, int lo
 }
 
 template <int C>
-hipError_t launch_up(const DevSector& s, const DevTiles& t, int lds_bytes, int threads, bool norb1, const double2* v, double2* hv,
-                     hipStream_t st) {
+hipError_t launch_up(const DevSector& s, const DevTiles& t, int lds_bytes, int threads, bool norb1, const double2* v, const double2* wt,
+                     double2* hv, hipStream_t st) {
   const int ngroups = (s.qdw + C - 1) / C;
   const int64_t nwg = (int64_t)((ngroups + 7) / 8) * 8 * t.nblocks;
-  void (*kern)(DevSector, DevTiles, const double2*, double2*, int);
+  void (*kern)(DevSector, DevTiles, const double2*, const double2*, double2*, int);
   if (s.real_h)
     kern = norb1 ? hxv_pass_up<C, true, true> : hxv_pass_up<C, true, false>;
   else
     kern = norb1 ? hxv_pass_up<C, false, true> : hxv_pass_up<C, false, false>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(threads), (size_t)lds_bytes, st, s, t, v, hv, ngroups);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(threads), (size_t)lds_bytes, st, s, t, v, wt, hv, ngroups);
   return hipGetLastError();
 }
 
-template <int R>
-hipError_t launch_dw(const DevSector& s, const DevTiles& t, int lds_bytes, int threads, const double2* v, double2* hv, hipStream_t st) {
+template <int R, int NP>
+hipError_t launch_dw_np(const DevSector& s, const DevTiles& t, int lds_bytes, int threads, const double2* v, double2* hv, hipStream_t st) {
   const int ngroups = (s.dimup + R - 1) / R;
   const int gpx = (ngroups + 7) / 8;
   const int64_t nwg = (int64_t)gpx * 8 * t.nblocks;
-  auto kern = s.real_h ? hxv_pass_dw<R, true> : hxv_pass_dw<R, false>;
+  auto kern = s.real_h ? hxv_pass_dw<R, NP, true> : hxv_pass_dw<R, NP, false>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(threads), (size_t)lds_bytes, st, s, t, v, hv, ngroups, gpx);
   return hipGetLastError();
+}
+
+template <int R>
+hipError_t launch_dw(const DevSector& s, const DevTiles& t, int max_block, int lds_bytes, int threads, const double2* v, double2* hv,
+                     hipStream_t st) {
+  const int np = (max_block * R + threads - 1) / threads;  // <= R because max_block <= threads
+  if (np <= 1) return launch_dw_np<R, 1>(s, t, lds_bytes, threads, v, hv, st);
+  if (np <= 2) return launch_dw_np<R, 2>(s, t, lds_bytes, threads, v, hv, st);
+  if (np <= 4) return launch_dw_np<R, 4>(s, t, lds_bytes, threads, v, hv, st);
+  return launch_dw_np<R, 8>(s, t, lds_bytes, threads, v, hv, st);
 }
 
 std::vector<double2> signed_coefs(const SpinOp& op) {
@@ -440,14 +510,14 @@ std::string make_tile_plan(const SectorHost& s, TilePlan& plan, const PlanUpload
     if (!map.empty()) L = force >= 0 ? std::min(force, s.ns) : choose_lowbits(s.ns, npart, width, budget, max_block);
     build_spin_tiles(op, map, L, chunk, vcol, sort_mode, sorted_out, t, h);
     if ((int64_t)t.max_block * width * 16 + 16 * (2 * (int64_t)op.coef.size() + 1) > 160 * 1024) return "tile does not fit the 160 KB LDS";
-    if (t.max_block > max_block) return "block larger than the workgroup (pass B needs one thread per block column)";
+    if (t.max_block > max_block) return "block larger than the workgroup (one thread per block row/column)";
     if (up.u32(h.start, &t.d_start) != hipSuccess || up.u32(h.perm, &t.d_perm) != hipSuccess ||
         up.u32(h.gstart, &t.d_gstart) != hipSuccess || up.u32(h.gmax, &t.d_gmax) != hipSuccess ||
         up.u32(h.ell_in, &t.d_ell_in) != hipSuccess || up.u32(h.ell_out, &t.d_ell_out) != hipSuccess)
       return "upload of tile tables failed";
     return "";
   };
-  std::string e = one(s.up, s.map_up, s.nup, o.cols_per_tile, o.force_bits_up, o.lds_budget_kb_up, 1 << 20, nullptr, true, o.sort_mode,
+  std::string e = one(s.up, s.map_up, s.nup, o.cols_per_tile, o.force_bits_up, o.lds_budget_kb_up, o.threads_up, nullptr, true, o.sort_mode,
                       plan.up);
   if (!e.empty()) return e;
   // pass B sorts by the inner count only: its outer table is read in natural column order
@@ -459,7 +529,8 @@ std::string make_tile_plan(const SectorHost& s, TilePlan& plan, const PlanUpload
   return "";
 }
 
-hipError_t launch_hxv_tiled(const DevSector& s, const TilePlan& plan, const double2* v, double2* hv, hipStream_t st) {
+hipError_t launch_hxv_tiled(const DevSector& s, const TilePlan& plan, const double2* v, double2* wt, double2* hv, hipStream_t st) {
+  // wt: scratch of qdw*DimUp elements (transposed dw-hop part), owned by the handle
   if (s.qdw == 0) return hipSuccess;
   DevTiles tu{plan.up.d_start, plan.up.d_perm, plan.up.d_gstart, plan.up.d_gmax, plan.up.d_ell_in, plan.up.d_ell_out,
               plan.d_scoef_up, plan.up.nblocks, 2 * plan.ncoef_up + 1, plan.opt.debug};
@@ -471,18 +542,91 @@ hipError_t launch_hxv_tiled(const DevSector& s, const TilePlan& plan, const doub
   const int ta = plan.opt.threads_up, tb = plan.opt.threads_dw;
   const bool norb1 = s.diag.mode == 0 && s.diag.cross.norb == 1;
   hipError_t e = hipSuccess;
-  if (plan.opt.passes & 1) switch (C) {
-      case 2: e = launch_up<2>(s, tu, lds_a, ta, norb1, v, hv, st); break;
-      case 4: e = launch_up<4>(s, tu, lds_a, ta, norb1, v, hv, st); break;
-      default: e = launch_up<8>(s, tu, lds_a, ta, norb1, v, hv, st); break;
+  if (plan.opt.passes & 2) switch (R) {
+      case 2: e = launch_dw<2>(s, td, plan.dw.max_block, lds_b, tb, v, wt, st); break;
+      case 4: e = launch_dw<4>(s, td, plan.dw.max_block, lds_b, tb, v, wt, st); break;
+      default: e = launch_dw<8>(s, td, plan.dw.max_block, lds_b, tb, v, wt, st); break;
     }
   if (e != hipSuccess) return e;
-  if (plan.opt.passes & 2) switch (R) {
-      case 2: e = launch_dw<2>(s, td, lds_b, tb, v, hv, st); break;
-      case 4: e = launch_dw<4>(s, td, lds_b, tb, v, hv, st); break;
-      default: e = launch_dw<8>(s, td, lds_b, tb, v, hv, st); break;
+  const double2* wta = (plan.opt.passes & 2) ? wt : nullptr;
+  if (plan.opt.passes & 1) switch (C) {
+      case 2: e = launch_up<2>(s, tu, lds_a, ta, norb1, v, wta, hv, st); break;
+      case 4: e = launch_up<4>(s, tu, lds_a, ta, norb1, v, wta, hv, st); break;
+      default: e = launch_up<8>(s, tu, lds_a, ta, norb1, v, wta, hv, st); break;
     }
   return e;
 }
 
+}  // namespace hxv
+// ---------------------------------------------------------------------------------------
+// Micro-benchmark (not part of the product path): read every element of a DimUp x ncols matrix once,
+// in pass-B tile order: workgroup = [R consecutive rows] x [n consecutive columns].  Tells what HBM gives
+// for R*16-byte segments at a column stride of DimUp*16 bytes.
+// ---------------------------------------------------------------------------------------
+namespace hxv {
+template <int R>
+__global__ void __launch_bounds__(1024) strided_read_kernel(const double2* __restrict__ v, double2* __restrict__ out, int dimup, int ncols,
+                                                           int n, int ngroups, int groups_per_xcd, int nblocks, int mode) {
+  extern __shared__ double2 lds[];
+  const int b = blockIdx.x;
+  const int xcd = b & 7, j = b >> 3;
+  const int gl = j / nblocks, kb = j - gl * nblocks;
+  const int rg = xcd * groups_per_xcd + gl;
+  if (gl >= groups_per_xcd || rg >= ngroups) return;
+  const int cb0 = kb * n, nn = min(n, ncols - cb0), i0 = rg * R;
+  double2 acc = make_double2(0.0, 0.0);
+  if (mode == 0) {  // read only
+    for (int q = threadIdx.x; q < nn * R; q += blockDim.x) {
+      const double2 x = v[(int64_t)(cb0 + q / R) * dimup + min(i0 + q % R, dimup - 1)];
+      acc.x += x.x;
+      acc.y += x.y;
+    }
+    if (acc.x == 1.2345e300) out[b] = acc;  // keep the loads alive
+    return;
+  }
+  // mode >= 1: stage through LDS transposed (lds[r*nn + col]) like pass B
+  for (int q = threadIdx.x; q < nn * R; q += blockDim.x)
+    lds[(q % R) * nn + q / R] = v[(int64_t)(cb0 + q / R) * dimup + min(i0 + q % R, dimup - 1)];
+  __syncthreads();
+  if (mode == 1) {
+    for (int q = threadIdx.x; q < nn * R; q += blockDim.x) {
+      const double2 x = lds[(q % R) * nn + q / R];
+      acc.x += x.x;
+      acc.y += x.y;
+    }
+    if (acc.x == 1.2345e300) out[b] = acc;
+    return;
+  }
+  for (int q = threadIdx.x; q < nn * R; q += blockDim.x) {
+    if (i0 + q % R >= dimup) continue;
+    const int64_t o = (int64_t)(cb0 + q / R) * dimup + i0 + q % R;
+    double2 x = lds[(q % R) * nn + q / R];
+    if (mode == 4 || mode == 5) {  // read-modify-write
+      const double2 h = (mode == 5) ? load_stream(&out[o]) : out[o];
+      x.x += h.x;
+      x.y += h.y;
+    }
+    if (mode == 3 || mode == 5)
+      store_stream(&out[o], x);
+    else
+      out[o] = x;
+  }
+}
+
+hipError_t launch_strided_read(const double2* v, double2* out, int dimup, int ncols, int R, int n, int mode, hipStream_t st) {
+  const int ngroups = (dimup + R - 1) / R, gpx = (ngroups + 7) / 8, nblocks = (ncols + n - 1) / n;
+  const int64_t nwg = (int64_t)gpx * 8 * nblocks;
+  const size_t lds = mode ? (size_t)n * R * 16 : 0;
+#define SR(RR)                                                                                                         \
+  case RR: {                                                                                                           \
+    (void)hipFuncSetAttribute((const void*)strided_read_kernel<RR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL(strided_read_kernel<RR>, dim3((unsigned)nwg), dim3(1024), lds, st, v, out, dimup, ncols, n, ngroups, gpx, nblocks, mode); \
+  } break;
+  switch (R) {
+    SR(4) SR(8) SR(16) SR(32) SR(64)
+    default: return hipErrorInvalidValue;
+  }
+#undef SR
+  return hipGetLastError();
+}
 }  // namespace hxv

@@ -63,6 +63,7 @@ struct PlanUploader {
   std::function<hipError_t(const std::vector<double2>&, double2**)> d2;
 };
 std::string make_tile_plan(const SectorHost& s, TilePlan& plan, const PlanUploader& up);
-hipError_t launch_hxv_tiled(const DevSector& s, const TilePlan& plan, const double2* v_full, double2* hv_local, hipStream_t st);
+hipError_t launch_hxv_tiled(const DevSector& s, const TilePlan& plan, const double2* v_full, double2* wt_scratch, double2* hv_local,
+                            hipStream_t st);
 
 }  // namespace hxv

@@ -16,7 +16,7 @@ for cfg in cfgs:
     for k, val in (("lds_budget_kb_up", kbA), ("cols_per_tile", C), ("threads_up", TA), ("lds_budget_kb_dw", kbB), ("rows_per_tile", R), ("threads_dw", TB), ("sort_mode", srt)):
         sec.set_option(k, val)
     print("sector", NUP, NDW, "cfg", cfg, "bits", sec.get_option("tile_bits_up"), sec.get_option("tile_bits_dw"))
-    for name, dbg in (("full", 0), ("no-outer", 1), ("no-inner", 2), ("no-hops", 3), ("B no-hvread", 4), ("B no-outer no-hvread", 5), ("nothing", 7)):
+    for name, dbg in (("full", 0), ("no-outer", 1), ("no-inner", 2), ("no-hops", 3), ("B no-hvread", 4), ("B no-outer no-hvread", 5), ("nothing", 7), ("full, nt hv", 8)):
         sec.set_option("debug", dbg)
         sec.set_option("passes", 1); ta = t()
         sec.set_option("passes", 2); tb = t()
