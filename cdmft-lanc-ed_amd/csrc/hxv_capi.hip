@@ -368,6 +368,10 @@ int64_t hxv_get_option(const hxv_handle* h, const char* name) {
   if (!strcmp(name, "slots_in_up_x100")) return (int64_t)(100 * h->plan.up.slots_in);
   if (!strcmp(name, "slots_out_up_x100")) return (int64_t)(100 * h->plan.up.slots_out);
   if (!strcmp(name, "slots_in_dw_x100")) return (int64_t)(100 * h->plan.dw.slots_in);
+  if (!strcmp(name, "bh_up_x100")) return (int64_t)(100 * h->plan.up.bh_per_row);
+  if (!strcmp(name, "rs_up_x100")) return (int64_t)(100 * h->plan.up.rs_per_row);
+  if (!strcmp(name, "bh_dw_x100")) return (int64_t)(100 * h->plan.dw.bh_per_row);
+  if (!strcmp(name, "rs_dw_x100")) return (int64_t)(100 * h->plan.dw.rs_per_row);
   if (!strcmp(name, "max_block_up")) return h->plan.up.max_block;
   if (!strcmp(name, "max_block_dw")) return h->plan.dw.max_block;
   if (!strcmp(name, "nblocks_up")) return h->plan.up.nblocks;

@@ -24,6 +24,11 @@ struct DevTiles {
   const uint32_t* ell_in;  // [k_in][dim]
   const uint32_t* ell_out; // [k_out][dim]
   const double2* scoef;    // [nscoef] signed coefficients, last = 0
+  const uint32_t* bh_ptr;  // block hops / row slots of the out-of-block part (hxv_tiles.hpp)
+  const uint32_t* bh;
+  const uint32_t* rs_ptr;
+  const uint32_t* rs_off;
+  const uint32_t* rs_tab;
   int nblocks, nscoef;
   int debug;  // timing experiments only: 1 skip out-of-block hops, 2 skip in-block hops, 4 skip the hv read-modify-write (pass B)
 };
@@ -104,9 +109,9 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
   int r = 0;
   if (p < n) {
     const uint32_t packed = __builtin_amdgcn_readfirstlane(t.gmax[t.gstart[kb] + (p >> 6)]);
-    const int kin = (int)(packed & 0xFFFFu), kout = (int)(packed >> 16);
-    const int i = (int)t.perm[r0 + p];
-    r = i - r0;
+    const int kin = (int)(packed & 0xFFFFu);
+    const int i = r0 + p;  // pass A visits the rows in natural order: every global access stays coalesced
+    r = p;
     if (s.diag.mode == 0) {
       const double au = s.diag.a_up[i];
       const uint32_t mu = s.diag.map_up[i];
@@ -124,15 +129,22 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
         acc[cc] = make_double2(d * x.x, d * x.y);
       }
     }
-    // hops that leave the block: gathers from global memory (L2 of this XCD)
-    for (int k0 = 0; k0 < ((t.debug & 1) ? 0 : kout); k0 += HOP_CHUNK) {
-      uint32_t e[HOP_CHUNK];
+    // hops that leave the block, same columns, other rows: from global memory (L2 of this XCD)
+    if (!(t.debug & 1)) {
+      // block hops: the partner block is one contiguous run, lanes read consecutive rows
+      for (uint32_t h = t.bh_ptr[kb]; h < t.bh_ptr[kb + 1]; ++h) {
+        const CT cf = lcoef[t.bh[2 * h + 1]];
+        const double2* __restrict__ src = vcol0 + t.bh[2 * h] + r;
 #pragma unroll
-      for (int u = 0; u < HOP_CHUNK; ++u) e[u] = t.ell_out[(int64_t)(k0 + u) * s.dimup + r0 + p];
-#pragma unroll
-      for (int u = 0; u < HOP_CHUNK; ++u) {
-        const CT cf = lcoef[e[u] >> TILE_COEF_SHIFT];
-        const double2* __restrict__ src = vcol0 + (e[u] & TILE_OFF_MASK);
+        for (int cc = 0; cc < C; ++cc) Coef<REAL>::fma(acc[cc], cf, src[(int64_t)min(cc, nc - 1) * s.dimup]);
+      }
+      // row slots: one table word per row and (block, source block) pair
+      const uint32_t emptyz = (uint32_t)(t.nscoef - 1) << TILE_COEF_SHIFT;
+      for (uint32_t sl = t.rs_ptr[kb]; sl < t.rs_ptr[kb + 1]; ++sl) {
+        const uint32_t e = t.rs_tab[t.rs_off[sl] + r];
+        if (__all(e == emptyz)) continue;
+        const CT cf = lcoef[e >> TILE_COEF_SHIFT];
+        const double2* __restrict__ src = vcol0 + (e & TILE_OFF_MASK);
 #pragma unroll
         for (int cc = 0; cc < C; ++cc) Coef<REAL>::fma(acc[cc], cf, src[(int64_t)min(cc, nc - 1) * s.dimup]);
       }
@@ -199,9 +211,8 @@ template <int R, int NP, bool REAL>
 __global__ void __launch_bounds__(1024) hxv_pass_dw(DevSector s, DevTiles t, const double2* __restrict__ v, double2* __restrict__ wt,
                                                       int ngroups, int groups_per_xcd) {
   // NP = (row,column) pairs of the tile per thread (plan: max_block*R <= NP*blockDim.x); all their global
-  // loads are issued before the first use so a workgroup keeps NP (+NP*OUT_CHUNK) requests per lane in flight.
+  // loads are issued before the first use so a workgroup keeps NP requests per lane in flight.
   using CT = typename Coef<REAL>::type;
-  constexpr int OUT_CHUNK = 2;
   extern __shared__ double2 lds[];
   const int b = blockIdx.x;
   const int xcd = b & 7, j = b >> 3;
@@ -246,29 +257,38 @@ __global__ void __launch_bounds__(1024) hxv_pass_dw(DevSector s, DevTiles t, con
 #pragma unroll
   for (int it = 0; it < NP; ++it) osum[it] = make_double2(0.0, 0.0);
   if (!(t.debug & 1)) {
-    for (int k0 = 0;; k0 += OUT_CHUNK) {
-      uint32_t e[NP][OUT_CHUNK];
-      bool done = true;
+    // block hops: source column slot = start + column offset, one signed coefficient for the whole block
+    for (uint32_t h = t.bh_ptr[kb]; h < t.bh_ptr[kb + 1]; ++h) {
+      const CT cf = lcoef[t.bh[2 * h + 1]];
+      const uint32_t s0 = t.bh[2 * h];
+      double2 x[NP];
 #pragma unroll
       for (int it = 0; it < NP; ++it) {
         const int q = min(threadIdx.x + it * T, npairs - 1);
-#pragma unroll
-        for (int u = 0; u < OUT_CHUNK; ++u) e[it][u] = t.ell_out[(int64_t)(k0 + u) * s.dimdw + cb0 + q / R];
-        done = done && (e[it][0] == emptyz);
+        x[it] = v[(int64_t)(s0 + q / R) * s.dimup + min(i0 + q % R, s.dimup - 1)];
       }
-      if (__all(done)) break;
-      double2 x[NP][OUT_CHUNK];
+#pragma unroll
+      for (int it = 0; it < NP; ++it) Coef<REAL>::fma(osum[it], cf, x[it]);
+    }
+    // row slots: one table word per column of the block and (block, source block) pair
+    for (uint32_t sl = t.rs_ptr[kb]; sl < t.rs_ptr[kb + 1]; ++sl) {
+      const uint32_t* __restrict__ tab = t.rs_tab + t.rs_off[sl];
+      uint32_t e[NP];
+      bool none = true;
+#pragma unroll
+      for (int it = 0; it < NP; ++it) {
+        e[it] = tab[min((int)threadIdx.x + it * T, npairs - 1) / R];
+        none = none && (e[it] == emptyz);
+      }
+      if (__all(none)) continue;
+      double2 x[NP];
 #pragma unroll
       for (int it = 0; it < NP; ++it) {
         const int q = min(threadIdx.x + it * T, npairs - 1);
-        const int irow = min(i0 + q % R, s.dimup - 1);
-#pragma unroll
-        for (int u = 0; u < OUT_CHUNK; ++u) x[it][u] = v[(int64_t)(e[it][u] & TILE_OFF_MASK) * s.dimup + irow];
+        x[it] = v[(int64_t)(e[it] & TILE_OFF_MASK) * s.dimup + min(i0 + q % R, s.dimup - 1)];
       }
 #pragma unroll
-      for (int it = 0; it < NP; ++it)
-#pragma unroll
-        for (int u = 0; u < OUT_CHUNK; ++u) Coef<REAL>::fma(osum[it], lcoef[e[it][u] >> TILE_COEF_SHIFT], x[it][u]);
+      for (int it = 0; it < NP; ++it) Coef<REAL>::fma(osum[it], lcoef[e[it] >> TILE_COEF_SHIFT], x[it]);
     }
   }
   // in-block hops, one column per thread (plan guarantees n <= blockDim.x)
@@ -346,6 +366,7 @@ int choose_lowbits(int ns, int npart, int width, int budget_bytes, int max_block
 
 struct HostTiles {
   std::vector<uint32_t> start, perm, gstart, gmax, ell_in, ell_out;
+  std::vector<uint32_t> bh_ptr, bh, rs_ptr, rs_off, rs_tab;
 };
 
 // sorted_out: outer table indexed by sorted position (pass A) or by natural index (pass B)
@@ -437,6 +458,81 @@ void build_spin_tiles(const SpinOp& op, const std::vector<uint32_t>& map, int lo
         h.ell_out[(size_t)(b++) * dim + qo] = ci | (vcol ? (*vcol)[src] : src);
     }
   }
+  // ---- structured out-of-block part: group by (block, source block)
+  h.bh_ptr.assign(t.nblocks + 1, 0);
+  h.rs_ptr.assign(t.nblocks + 1, 0);
+  h.bh.clear();
+  h.rs_off.clear();
+  h.rs_tab.clear();
+  double bh_rows = 0, rs_rows = 0;
+  struct Ent {
+    uint32_t off, src, ci;
+  };
+  std::vector<std::vector<Ent>> by_src(t.nblocks);
+  std::vector<int> touched;
+  for (int k = 0; k < t.nblocks; ++k) {
+    const uint32_t b0 = h.start[k], nb = h.start[k + 1] - b0;
+    touched.clear();
+    for (uint32_t i = b0; i < b0 + nb; ++i) {
+      int kk = 0;
+      for (int64_t p = op.rowptr[i]; p < op.rowptr[i + 1]; ++p, ++kk) {
+        const uint32_t e = op.ell[(size_t)kk * dim + i];
+        const uint32_t src = e & ELL_SRC_MASK;
+        const uint32_t sb = block_of[src];
+        if ((int)sb == k) continue;
+        if (by_src[sb].empty()) touched.push_back((int)sb);
+        by_src[sb].push_back({i - b0, src, 2u * ((e >> ELL_SRC_BITS) & ELL_COEF_MASK) + (e >> 31)});
+      }
+    }
+    std::sort(touched.begin(), touched.end());
+    h.bh_ptr[k] = (uint32_t)(h.bh.size() / 2);
+    h.rs_ptr[k] = (uint32_t)h.rs_off.size();
+    for (int sb : touched) {
+      auto& ents = by_src[sb];
+      const uint32_t s0 = h.start[sb], ns = h.start[sb + 1] - s0;
+      bool uniform = ents.size() == nb && ns == nb;
+      if (uniform)
+        for (const Ent& en : ents)
+          if (en.src - s0 != en.off || en.ci != ents[0].ci) {
+            uniform = false;
+            break;
+          }
+      // the source run must also be contiguous in the (possibly padded) gather layout
+      if (uniform && vcol)
+        for (uint32_t q = 0; q < ns; ++q)
+          if ((*vcol)[s0 + q] != (*vcol)[s0] + q) {
+            uniform = false;
+            break;
+          }
+      if (uniform) {
+        h.bh.push_back(vcol ? (*vcol)[s0] : s0);
+        h.bh.push_back(ents[0].ci);
+        bh_rows += nb;
+      } else {
+        // as many slots as the busiest row has entries from this source block
+        std::vector<int> mult(nb, 0);
+        int nsl = 0;
+        for (const Ent& en : ents) nsl = std::max(nsl, ++mult[en.off]);
+        const size_t base = h.rs_tab.size();
+        h.rs_tab.resize(base + (size_t)nsl * nb, emptyz);
+        std::fill(mult.begin(), mult.end(), 0);
+        for (const Ent& en : ents) {
+          const int sl = mult[en.off]++;
+          h.rs_tab[base + (size_t)sl * nb + en.off] = (en.ci << TILE_COEF_SHIFT) | (vcol ? (*vcol)[en.src] : en.src);
+        }
+        for (int sl = 0; sl < nsl; ++sl) h.rs_off.push_back((uint32_t)(base + (size_t)sl * nb));
+        rs_rows += (double)nsl * nb;
+      }
+      ents.clear();
+    }
+  }
+  h.bh_ptr[t.nblocks] = (uint32_t)(h.bh.size() / 2);
+  h.rs_ptr[t.nblocks] = (uint32_t)h.rs_off.size();
+  if (h.bh.empty()) h.bh.assign(2, 0);
+  if (h.rs_off.empty()) h.rs_off.assign(1, 0);
+  if (h.rs_tab.empty()) h.rs_tab.assign(1, emptyz);
+  t.bh_per_row = bh_rows / dim;
+  t.rs_per_row = rs_rows / dim;
 }
 
 template <int C>
@@ -513,11 +609,14 @@ std::string make_tile_plan(const SectorHost& s, TilePlan& plan, const PlanUpload
     if (t.max_block > max_block) return "block larger than the workgroup (one thread per block row/column)";
     if (up.u32(h.start, &t.d_start) != hipSuccess || up.u32(h.perm, &t.d_perm) != hipSuccess ||
         up.u32(h.gstart, &t.d_gstart) != hipSuccess || up.u32(h.gmax, &t.d_gmax) != hipSuccess ||
-        up.u32(h.ell_in, &t.d_ell_in) != hipSuccess || up.u32(h.ell_out, &t.d_ell_out) != hipSuccess)
+        up.u32(h.ell_in, &t.d_ell_in) != hipSuccess || up.u32(h.ell_out, &t.d_ell_out) != hipSuccess ||
+        up.u32(h.bh_ptr, &t.d_bh_ptr) != hipSuccess || up.u32(h.bh, &t.d_bh) != hipSuccess ||
+        up.u32(h.rs_ptr, &t.d_rs_ptr) != hipSuccess || up.u32(h.rs_off, &t.d_rs_off) != hipSuccess ||
+        up.u32(h.rs_tab, &t.d_rs_tab) != hipSuccess)
       return "upload of tile tables failed";
     return "";
   };
-  std::string e = one(s.up, s.map_up, s.nup, o.cols_per_tile, o.force_bits_up, o.lds_budget_kb_up, o.threads_up, nullptr, true, o.sort_mode,
+  std::string e = one(s.up, s.map_up, s.nup, o.cols_per_tile, o.force_bits_up, o.lds_budget_kb_up, o.threads_up, nullptr, true, 0,
                       plan.up);
   if (!e.empty()) return e;
   // pass B sorts by the inner count only: its outer table is read in natural column order
@@ -533,9 +632,11 @@ hipError_t launch_hxv_tiled(const DevSector& s, const TilePlan& plan, const doub
   // wt: scratch of qdw*DimUp elements (transposed dw-hop part), owned by the handle
   if (s.qdw == 0) return hipSuccess;
   DevTiles tu{plan.up.d_start, plan.up.d_perm, plan.up.d_gstart, plan.up.d_gmax, plan.up.d_ell_in, plan.up.d_ell_out,
-              plan.d_scoef_up, plan.up.nblocks, 2 * plan.ncoef_up + 1, plan.opt.debug};
+              plan.d_scoef_up, plan.up.d_bh_ptr, plan.up.d_bh, plan.up.d_rs_ptr, plan.up.d_rs_off, plan.up.d_rs_tab,
+              plan.up.nblocks, 2 * plan.ncoef_up + 1, plan.opt.debug};
   DevTiles td{plan.dw.d_start, plan.dw.d_perm, plan.dw.d_gstart, plan.dw.d_gmax, plan.dw.d_ell_in, plan.dw.d_ell_out,
-              plan.d_scoef_dw, plan.dw.nblocks, 2 * plan.ncoef_dw + 1, plan.opt.debug};
+              plan.d_scoef_dw, plan.dw.d_bh_ptr, plan.dw.d_bh, plan.dw.d_rs_ptr, plan.dw.d_rs_off, plan.dw.d_rs_tab,
+              plan.dw.nblocks, 2 * plan.ncoef_dw + 1, plan.opt.debug};
   const int C = plan.opt.cols_per_tile, R = plan.opt.rows_per_tile;
   const int lds_a = std::max((plan.up.max_block * C + tu.nscoef) * 16, plan.opt.lds_min_kb_up * 1024);
   const int lds_b = std::max((plan.dw.max_block * R + td.nscoef) * 16, plan.opt.lds_min_kb_dw * 1024);

@@ -32,7 +32,17 @@ struct SpinTiles {
   uint32_t* d_gstart = nullptr;      // [nblocks+1] first 64-lane group of each block
   uint32_t* d_gmax = nullptr;        // [ngroups] k_in max | k_out max << 16 of each 64-position group
   uint32_t* d_ell_in = nullptr;      // [k_in][dim], indexed by sorted position
-  uint32_t* d_ell_out = nullptr;     // [k_out][dim], pass A: by sorted position; pass B: by natural column
+  uint32_t* d_ell_out = nullptr;     // (unused by the structured outer path; kept for statistics)
+  // Out-of-block hops, grouped by (block, source block).  A pair whose hop maps the whole source block onto
+  // the block with the identity on the low orbitals and one signed coefficient is a BLOCK hop: no per-row
+  // data at all, the partner block is read as one contiguous, coalesced run.  Everything else is a ROW slot:
+  // one table entry per row of the block (absolute source index | signed-coefficient index).
+  uint32_t* d_bh_ptr = nullptr;      // [nblocks+1] -> d_bh
+  uint32_t* d_bh = nullptr;          // [2*nbh] (source start, signed-coefficient index)
+  uint32_t* d_rs_ptr = nullptr;      // [nblocks+1] -> d_rs_off
+  uint32_t* d_rs_off = nullptr;      // [nslots] offset of each slot's table in d_rs_tab
+  uint32_t* d_rs_tab = nullptr;      // flat tables, |block| words per slot
+  double bh_per_row = 0, rs_per_row = 0;  // statistics: block hops / row slots visited per row
 };
 
 struct TileOptions {

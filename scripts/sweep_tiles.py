@@ -38,7 +38,7 @@ for cfg in cfgs:
         print(cfg, "skip", e); continue
     g = sec.get_option
     info = (f"bits {g('tile_bits_up')}/{g('tile_bits_dw')} slots up in/out {g('slots_in_up_x100')/100:.1f}/{g('slots_out_up_x100')/100:.1f} "
-            f"dw in {g('slots_in_dw_x100')/100:.1f} out-frac up {g('n_out_up')/(g('n_in_up')+g('n_out_up')):.2f} dw {g('n_out_dw')/(g('n_in_dw')+g('n_out_dw')):.2f}")
+            f"dw in {g('slots_in_dw_x100')/100:.1f} bh/rs up {g('bh_up_x100')/100:.1f}/{g('rs_up_x100')/100:.1f} dw {g('bh_dw_x100')/100:.1f}/{g('rs_dw_x100')/100:.1f} out-frac up {g('n_out_up')/(g('n_in_up')+g('n_out_up')):.2f} dw {g('n_out_dw')/(g('n_in_dw')+g('n_out_dw')):.2f}")
     sec.set_option("passes", 1); ta = t()
     sec.set_option("passes", 2); tb = t()
     sec.set_option("passes", 3); tt = t()
