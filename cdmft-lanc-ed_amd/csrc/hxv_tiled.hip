@@ -81,14 +81,18 @@ __device__ __forceinline__ double diag_value(const DevDiag& dg, double au, uint3
 // ---------------------------------------------------------------------------------------
 template <int C, bool REAL, bool NORB1>
 __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, const double2* __restrict__ v,
-                                                      const double2* __restrict__ wt, double2* __restrict__ hv, int ngroups) {
+                                                      const double2* __restrict__ wt, double2* __restrict__ hv, int ngroups,
+                                                      int groups_per_xcd) {
   using CT = typename Coef<REAL>::type;
   extern __shared__ double2 lds[];
   const int b = blockIdx.x;
   const int xcd = b & 7, j = b >> 3;
-  const int g = (j / t.nblocks) * 8 + xcd;  // column group; all blocks of a group share blockIdx%8 (= one XCD)
-  const int kb = j - (j / t.nblocks) * t.nblocks;
-  if (g >= ngroups) return;
+  // column group: all blocks of a group share blockIdx%8 (= one XCD), and each XCD owns a contiguous range of
+  // groups because neighbouring groups share the cache lines of the transposed scratch wt
+  const int gl = j / t.nblocks;
+  const int g = xcd * groups_per_xcd + gl;
+  const int kb = j - gl * t.nblocks;
+  if (gl >= groups_per_xcd || g >= ngroups) return;
   const int T = blockDim.x;
   const int r0 = (int)t.start[kb];
   const int n = (int)t.start[kb + 1] - r0;
@@ -196,7 +200,12 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
   for (int cc = 0; cc < C; ++cc) {
     if (cc < nc) {
       double2* __restrict__ dst = hv + (int64_t)(c0 + cc) * s.dimup + r0;
-      for (int rr = threadIdx.x; rr < n; rr += T) store_stream(&dst[rr], lds[cc * n + rr]);
+      for (int rr = threadIdx.x; rr < n; rr += T) {
+        if (t.debug & 8)
+          dst[rr] = lds[cc * n + rr];
+        else
+          store_stream(&dst[rr], lds[cc * n + rr]);
+      }
     }
   }
 }
@@ -226,7 +235,10 @@ __global__ void __launch_bounds__(1024) hxv_pass_dw(DevSector s, DevTiles t, con
   const int T = blockDim.x;
   const int i0 = rg * R;
   const int npairs = n * R;
-  CT* lcoef = reinterpret_cast<CT*>(lds + R * n);
+  // padded row stride of the transposed tile: (stride mod 16) = 16/R spreads the R rows x (16/R) columns touched
+  // by 16 neighbouring lanes over all 16 sixteen-byte bank slots
+  const int ns = ((n + 15) & ~15) + 16 / R;
+  CT* lcoef = reinterpret_cast<CT*>(lds + R * ns);
   const uint32_t emptyz = (uint32_t)(t.nscoef - 1) << TILE_COEF_SHIFT;
   for (int q = threadIdx.x; q < t.nscoef; q += T) lcoef[q] = Coef<REAL>::from(t.scoef[q]);
   // phase 0: tile load, lanes along rows (R*16 B contiguous per column), transposed store
@@ -247,7 +259,7 @@ __global__ void __launch_bounds__(1024) hxv_pass_dw(DevSector s, DevTiles t, con
 #pragma unroll
     for (int it = 0; it < NP; ++it) {
       const int q = threadIdx.x + it * T;
-      if (q < npairs) lds[(q % R) * n + q / R] = x[it];
+      if (q < npairs) lds[(q % R) * ns + q / R] = x[it];
     }
   }
   __syncthreads();
@@ -310,14 +322,14 @@ __global__ void __launch_bounds__(1024) hxv_pass_dw(DevSector s, DevTiles t, con
         const CT cf = lcoef[e[u] >> TILE_COEF_SHIFT];
         const int off = (int)(e[u] & TILE_OFF_MASK);
 #pragma unroll
-        for (int r = 0; r < R; ++r) Coef<REAL>::fma(acc[r], cf, lds[r * n + off]);
+        for (int r = 0; r < R; ++r) Coef<REAL>::fma(acc[r], cf, lds[r * ns + off]);
       }
     }
   }
   __syncthreads();
   if (p < n) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) lds[r * n + col1] = acc[r];
+    for (int r = 0; r < R; ++r) lds[r * ns + col1] = acc[r];
   }
   __syncthreads();
   // add the out-of-block sums (each tile element belongs to exactly one (row,column) pair of one thread)
@@ -325,10 +337,10 @@ __global__ void __launch_bounds__(1024) hxv_pass_dw(DevSector s, DevTiles t, con
   for (int it = 0; it < NP; ++it) {
     const int q = threadIdx.x + it * T;
     if (q < npairs) {
-      double2 a = lds[(q % R) * n + q / R];
+      double2 a = lds[(q % R) * ns + q / R];
       a.x += osum[it].x;
       a.y += osum[it].y;
-      lds[(q % R) * n + q / R] = a;
+      lds[(q % R) * ns + q / R] = a;
     }
   }
   __syncthreads();
@@ -337,7 +349,7 @@ __global__ void __launch_bounds__(1024) hxv_pass_dw(DevSector s, DevTiles t, con
   const int nloc = cl1 - cl0;
   for (int q = threadIdx.x; q < nloc * R; q += T) {
     const int r = q / nloc, col = (cl0 - cb0) + (q - r * nloc);
-    if (i0 + r < s.dimup) wt[(int64_t)(i0 + r) * s.qdw + (cb0 + col - s.dw0)] = lds[r * n + col];
+    if (i0 + r < s.dimup) wt[(int64_t)(i0 + r) * s.qdw + (cb0 + col - s.dw0)] = lds[r * ns + col];
   }
 }
 
@@ -539,15 +551,16 @@ template <int C>
 hipError_t launch_up(const DevSector& s, const DevTiles& t, int lds_bytes, int threads, bool norb1, const double2* v, const double2* wt,
                      double2* hv, hipStream_t st) {
   const int ngroups = (s.qdw + C - 1) / C;
-  const int64_t nwg = (int64_t)((ngroups + 7) / 8) * 8 * t.nblocks;
-  void (*kern)(DevSector, DevTiles, const double2*, const double2*, double2*, int);
+  const int gpx = (ngroups + 7) / 8;
+  const int64_t nwg = (int64_t)gpx * 8 * t.nblocks;
+  void (*kern)(DevSector, DevTiles, const double2*, const double2*, double2*, int, int);
   if (s.real_h)
     kern = norb1 ? hxv_pass_up<C, true, true> : hxv_pass_up<C, true, false>;
   else
     kern = norb1 ? hxv_pass_up<C, false, true> : hxv_pass_up<C, false, false>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(threads), (size_t)lds_bytes, st, s, t, v, wt, hv, ngroups);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(threads), (size_t)lds_bytes, st, s, t, v, wt, hv, ngroups, gpx);
   return hipGetLastError();
 }
 
@@ -639,7 +652,7 @@ hipError_t launch_hxv_tiled(const DevSector& s, const TilePlan& plan, const doub
               plan.dw.nblocks, 2 * plan.ncoef_dw + 1, plan.opt.debug};
   const int C = plan.opt.cols_per_tile, R = plan.opt.rows_per_tile;
   const int lds_a = std::max((plan.up.max_block * C + tu.nscoef) * 16, plan.opt.lds_min_kb_up * 1024);
-  const int lds_b = std::max((plan.dw.max_block * R + td.nscoef) * 16, plan.opt.lds_min_kb_dw * 1024);
+  const int lds_b = std::max(((((plan.dw.max_block + 15) & ~15) + 16 / R) * R + td.nscoef) * 16, plan.opt.lds_min_kb_dw * 1024);
   const int ta = plan.opt.threads_up, tb = plan.opt.threads_dw;
   const bool norb1 = s.diag.mode == 0 && s.diag.cross.norb == 1;
   hipError_t e = hipSuccess;
