@@ -132,6 +132,7 @@ int finish_create(hxv_handle* h, int device, hxv_handle** out) {
   d.slab0 = s.rank * s.cmax;
   d.vcol = vcol;
   d.vcol_identity = (s.nranks == 1) ? 1 : 0;
+  d.nd = s.nd;
   d.real_h = (s.up.real_vals && s.dw.real_vals) ? 1 : 0;
   HC(h->alloc(&h->d_partials, 2 * RED_BLOCKS));
   HC(h->alloc(&h->d_scalars, 8));
@@ -226,6 +227,7 @@ int hxv_apply_device(hxv_handle* h, const void* d_v_full, void* d_hv_local, void
     }
     e = launch_hxv_tiled(h->dev, h->plan, (const double2*)d_v_full, h->d_wt, (double2*)d_hv_local, st);
   }
+  if (e == hipSuccess && h->dev.nd.active) e = launch_hxv_nonlocal(h->dev, (const double2*)d_v_full, (double2*)d_hv_local, st);
   if (e != hipSuccess) return fail(HXV_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
   h->n_apply++;
   return HXV_OK;

@@ -46,6 +46,13 @@ struct CrossParams {            // non-separable part of the diagonal (H_local.f
   uint32_t sitemask[16] = {0};
 };
 
+// Spin-exchange / pair-hopping block spH0nd (sparse/H_non_local.f90:4-100), applied on the fly.
+struct NonLocalParams {
+  int32_t active = 0;  // Jhflag: Norb>1 and (Jx or Jp) != 0, ED_SETUP.f90:200-201
+  int32_t nlat = 0, norb = 0;
+  double jx = 0, jp = 0;
+};
+
 struct SectorHost {
   int ns = 0, nup = 0, ndw = 0;
   int dimup = 0, dimdw = 0;
@@ -59,6 +66,7 @@ struct SectorHost {
   bool separable_diag = true;
   std::vector<double> a_up, a_dw;  // separable diagonal tables
   CrossParams cross;
+  NonLocalParams nd;
   std::vector<double> diag_stored; // from_csr path: explicit local diagonal
 };
 
@@ -101,11 +109,13 @@ struct DevSector {
   int slab0;              // column slot of local column 0 in the padded all-gather layout (= rank*cmax)
   const uint32_t* vcol;   // [dimdw] column -> column slot (identity when nranks==1)
   int vcol_identity;
+  NonLocalParams nd;
   int real_h;
 };
 
 // kernel launchers (hxv_kernels.hip)
 struct TilePlan;  // opaque tiling data for the two-pass kernels
 hipError_t launch_hxv_naive(const DevSector& s, const double2* v_full, double2* hv_local, hipStream_t st);
+hipError_t launch_hxv_nonlocal(const DevSector& s, const double2* v_full, double2* hv_local, hipStream_t st);
 
 }  // namespace hxv

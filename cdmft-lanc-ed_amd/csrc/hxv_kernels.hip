@@ -48,4 +48,84 @@ hipError_t launch_hxv_naive(const DevSector& s, const double2* v_full, double2* 
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------
+// Non-local block spH0nd (spin exchange Jx, pair hopping Jp; Norb>1 only), on the fly:
+//   hv(i) += sum_j H_nd(i,j) v(j),   j = state reached from i by the two-spin operator
+// exactly the (symmetric, "transposed") rows the reference stores at sparse/H_non_local.f90:4-100 and
+// multiplies at ED_HAMILTONIAN_SPARSE_HxV.f90:217-225 / :300-313 (there on the all-gathered vector).
+// Signs are the product of the four single-spin signs (c/cdg, ED_SETUP.f90:807-833), no cross-spin sign.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int rank_in_map(const uint32_t* __restrict__ map, int dim, uint32_t value) {
+  int lo = 0, hi = dim - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (map[mid] < value)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+
+__device__ __forceinline__ int par_below(uint32_t m, int pos) { return __popc(m & ((1u << pos) - 1u)) & 1; }
+
+__global__ void __launch_bounds__(256) hxv_nonlocal_kernel(DevSector s, const double2* __restrict__ v, double2* __restrict__ hv) {
+  const int64_t nloc = (int64_t)s.qdw * s.dimup;
+  const uint32_t* __restrict__ map_up = s.diag.map_up;
+  const uint32_t* __restrict__ map_dw = s.diag.map_dw;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nloc; t += (int64_t)gridDim.x * blockDim.x) {
+    const int cl = (int)(t / s.dimup);
+    const int i = (int)(t - (int64_t)cl * s.dimup);
+    const uint32_t mu = map_up[i], md = map_dw[cl + s.dw0];
+    double2 acc = make_double2(0.0, 0.0);
+    bool any = false;
+    for (int il = 0; il < s.nd.nlat; ++il)
+      for (int io = 0; io < s.nd.norb; ++io)
+        for (int jo = 0; jo < s.nd.norb; ++jo) {
+          if (io == jo) continue;
+          const int is = io + il * s.nd.norb, js = jo + il * s.nd.norb;  // imp_state_index, 0-based bit
+          const bool nu_i = (mu >> is) & 1u, nu_j = (mu >> js) & 1u, nd_i = (md >> is) & 1u, nd_j = (md >> js) & 1u;
+          // spin exchange, H_non_local.f90:26-60:  [c^+_js c_is]_dw [c^+_is c_js]_up
+          if (s.nd.jx != 0.0 && nu_j && nd_i && !nd_j && !nu_i) {
+            const uint32_t k1 = md & ~(1u << is), k2 = k1 | (1u << js);
+            const uint32_t k3 = mu & ~(1u << js), k4 = k3 | (1u << is);
+            const int sg = par_below(md, is) ^ par_below(k1, js) ^ par_below(mu, js) ^ par_below(k3, is);
+            const int jdw = rank_in_map(map_dw, s.dimdw, k2), jup = rank_in_map(map_up, s.dimup, k4);
+            const double2 x = v[(int64_t)s.vcol[jdw] * s.dimup + jup];
+            const double c = sg ? -s.nd.jx : s.nd.jx;
+            acc.x += c * x.x;
+            acc.y += c * x.y;
+            any = true;
+          }
+          // pair hopping, H_non_local.f90:65-98:  [c^+_is c_js]_dw [c^+_is c_js]_up
+          if (s.nd.jp != 0.0 && nu_j && nd_j && !nd_i && !nu_i) {
+            const uint32_t k1 = md & ~(1u << js), k2 = k1 | (1u << is);
+            const uint32_t k3 = mu & ~(1u << js), k4 = k3 | (1u << is);
+            const int sg = par_below(md, js) ^ par_below(k1, is) ^ par_below(mu, js) ^ par_below(k3, is);
+            const int jdw = rank_in_map(map_dw, s.dimdw, k2), jup = rank_in_map(map_up, s.dimup, k4);
+            const double2 x = v[(int64_t)s.vcol[jdw] * s.dimup + jup];
+            const double c = sg ? -s.nd.jp : s.nd.jp;
+            acc.x += c * x.x;
+            acc.y += c * x.y;
+            any = true;
+          }
+        }
+    if (any) {
+      double2 h = hv[t];
+      h.x += acc.x;
+      h.y += acc.y;
+      hv[t] = h;
+    }
+  }
+}
+
+hipError_t launch_hxv_nonlocal(const DevSector& s, const double2* v_full, double2* hv_local, hipStream_t st) {
+  const int64_t nloc = (int64_t)s.qdw * s.dimup;
+  if (nloc == 0 || !s.nd.active) return hipSuccess;
+  int64_t blocks = (nloc + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(hxv_nonlocal_kernel, dim3((unsigned)blocks), dim3(256), 0, st, s, v_full, hv_local);
+  return hipGetLastError();
+}
+
 }  // namespace hxv

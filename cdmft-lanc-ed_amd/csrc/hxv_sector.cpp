@@ -232,8 +232,6 @@ std::string build_sector_from_model(const hxv_model& m, int nup, int ndw, int ra
   if (ns > 24) return "Ns > 24";
   if (nup < 0 || nup > ns || ndw < 0 || ndw > ns) return "nup/ndw outside [0,Ns]";
   if (nranks < 1 || rank < 0 || rank >= nranks) return "bad rank/nranks";
-  if (m.norb > 1 && (m.jx != 0.0 || m.jp != 0.0))
-    return "spin-exchange / pair-hopping block spH0nd (Jx,Jp != 0 with Norb>1) is not implemented yet";
   ModelView mv(m);
   s.ns = ns; s.nup = nup; s.ndw = ndw;
   s.map_up = make_map(ns, nup);
@@ -294,6 +292,12 @@ std::string build_sector_from_model(const hxv_model& m, int nup, int ndw, int ra
   s.a_dw.resize(s.dimdw);
   for (int i = 0; i < s.dimup; ++i) s.a_up[i] = one_spin_diag(s.map_up[i], eps_up) + cst;
   for (int i = 0; i < s.dimdw; ++i) s.a_dw[i] = one_spin_diag(s.map_dw[i], eps_dw);
+  s.nd = NonLocalParams();
+  s.nd.active = (O > 1 && (m.jx != 0.0 || m.jp != 0.0)) ? 1 : 0;  // Jhflag, ED_SETUP.f90:200-201
+  s.nd.nlat = L;
+  s.nd.norb = O;
+  s.nd.jx = m.jx;
+  s.nd.jp = m.jp;
   s.cross = CrossParams();
   s.cross.norb = O;
   s.cross.nlat = L;

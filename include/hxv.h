@@ -52,7 +52,9 @@ typedef struct {
  * (ED_HAMILTONIAN_SPARSE_HxV.f90:40-110): builds the sector maps, the one-spin hopping
  * tables and the separable diagonal on the host, uploads them to HIP device `device`.
  * (nup,ndw) = get_Nup/get_Ndw(isector) (ED_SETUP.f90:477-500). rank/nranks = the DimDw
- * split of ED_HAMILTONIAN.f90:93-105 (nranks=1: serial, MpiStatus=F).                   */
+ * split of ED_HAMILTONIAN.f90:93-105 (nranks=1: serial, MpiStatus=F).  With Norb>1 and Jx or
+ * Jp != 0 (Jhflag, ED_SETUP.f90:200-201) the spin-exchange / pair-hopping block spH0nd
+ * (sparse/H_non_local.f90:4-100) is applied on the fly as a third kernel.               */
 int hxv_create_from_model(const hxv_model *model, int32_t nup, int32_t ndw, int32_t rank, int32_t nranks, int32_t device,
                           hxv_handle **out);
 

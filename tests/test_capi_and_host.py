@@ -44,8 +44,8 @@ def test_bad_arguments_are_rejected_before_touching_the_device(built):
         hxv.HxvSector.from_model(m, 9, 2)
     with pytest.raises(hxv.HxvError, match="rank"):
         hxv.HxvSector.from_model(m, 2, 2, rank=3, nranks=2)
-    with pytest.raises(hxv.HxvError, match="not implemented"):
-        hxv.HxvSector.from_model(models.bhz_2d(Nbath=0, Jx=0.1), 4, 4)
+    with pytest.raises(hxv.HxvError, match="Norb"):
+        hxv.HxvSector.from_model(models.Model(1, 6, 1, 0, np.zeros((1, 1, 1, 1, 6, 6)), np.zeros((1, 1, 1, 1, 6, 6, 0)), np.zeros((1, 1, 6, 0))), 1, 1)
 
 
 @pytest.mark.parametrize("DimDw,P", [(6, 1), (6, 4), (924, 8), (12870, 8), (12870, 7), (48620, 8), (5, 5)])

@@ -18,6 +18,7 @@ def _models():
         ("square_B1", models.hm_2dsquare(Nbath=1), [(4, 4), (3, 5), (5, 4)]),
         ("bhz_B0", models.bhz_2d(Nbath=0), [(4, 4), (3, 5)]),
         ("bhz_B0_ust", models.bhz_2d(Nbath=0, Ust=0.7, Jh=0.2, xmu=0.1), [(4, 4), (2, 5)]),
+        ("bhz_B0_kanamori", models.bhz_2d(Nbath=0, Ust=0.7, Jh=0.2, Jx=0.2, Jp=0.15), [(4, 4), (3, 5), (1, 6)]),
     ]
 
 
@@ -101,7 +102,12 @@ def _slab_reference(orc, v_full):
     c0 = orc.mpiIshift // du
     sl = slice(c0, c0 + orc.mpiQdw)
     out = orc.diag().reshape((du, orc.mpiQdw), order="F") * V[:, sl] + Hup @ V[:, sl] + (Hdw[sl, :] @ V.T).T
-    return np.asarray(out).reshape(-1, order="F")
+    out = np.asarray(out).reshape(-1, order="F")
+    m = orc.model
+    if m.Norb > 1 and (m.Jx != 0 or m.Jp != 0):   # spH0nd: local rows, GLOBAL columns (H_non_local.f90:46,84)
+        rp, cols, vals = orc.csr("nd")
+        out = out + sp.csr_matrix((vals, cols - 1, rp), shape=(orc.vecDim, orc.Dim)) @ v_full
+    return out
 
 
 @pytest.mark.parametrize("bits", [(2, 3), (4, 1), (0, 0), (5, 6)])
@@ -115,7 +121,8 @@ def test_tiled_outer_path_and_shards_match_oracle(built, bits, shard):
     from oracle.oracle import OracleSector
 
     rank, size = shard
-    for m, (nup, ndw) in ((models.hm_2dsquare(Nbath=1), (4, 3)), (models.bhz_2d(Nbath=0, Ust=0.4, Jh=0.1), (3, 5))):
+    for m, (nup, ndw) in ((models.hm_2dsquare(Nbath=1), (4, 3)), (models.bhz_2d(Nbath=0, Ust=0.4, Jh=0.1), (3, 5)),
+                          (models.bhz_2d(Nbath=0, Ust=0.4, Jh=0.1, Jx=0.25, Jp=-0.1), (4, 3))):
         sec = hxv.HxvSector.from_model(m, nup, ndw, rank=rank, nranks=size)
         orc = OracleSector(m, nup, ndw, rank, size)
         assert (sec.vecDim, sec.mpiQdw, sec.mpiIshift) == (orc.vecDim, orc.mpiQdw, orc.mpiIshift)
@@ -138,16 +145,20 @@ def test_tiled_outer_path_and_shards_match_oracle(built, bits, shard):
         sec.close()
 
 
-def test_c3_slab_matches_oracle_matrices(built):
-    """BASELINE C3 (Ns=16, Dim=1.66e8) is out of reach of the serial oracle in seconds; a 1/64 slab is not:
-    its Hv is rebuilt on the host from the oracle's H_up, H_dw and diagonal."""
+@pytest.mark.parametrize("config", ["C3", "C4", "C4_kanamori"])
+def test_full_size_slab_matches_oracle_matrices(built, config):
+    """BASELINE C3 / C4 (Ns=16, Dim=1.66e8; C4 = BHZ: complex H, Norb=2, Nspin=2 so H_up != H_dw) are out of reach
+    of the serial oracle in seconds; a 1/64 slab is not: its Hv is rebuilt on the host from the oracle's H_up,
+    H_dw and diagonal."""
     import torch
     import hxv
     from hxv import models
     from oracle.oracle import OracleSector
 
-    m = models.hm_2dsquare(Nbath=3)
+    m = {"C3": models.hm_2dsquare(Nbath=3), "C4": models.bhz_2d(Nbath=1, Ust=0.5, Jh=0.1),
+         "C4_kanamori": models.bhz_2d(Nbath=1, Ust=0.5, Jh=0.1, Jx=0.1, Jp=0.1)}[config]
     sec = hxv.HxvSector.from_model(m, 8, 8, rank=3, nranks=64)
+    assert sec.stats()["real_h"] == (1 if config == "C3" else 0)
     orc = OracleSector(m, 8, 8, 3, 64)
     rng = np.random.default_rng(7)
     v = rng.standard_normal(sec.Dim) + 1j * rng.standard_normal(sec.Dim)
