@@ -40,6 +40,9 @@ struct hxv_handle {
   double* d_partials = nullptr;  // [2][RED_BLOCKS]
   double* d_scalars = nullptr;   // [8]
   double2* d_lz[3] = {nullptr, nullptr, nullptr};
+  double* d_lz_partial = nullptr;  // per-workgroup partial sums of the fused Lanczos epilogue
+  int64_t lz_partial_n = 0;
+  int lz_fused = 1;                // option "lanczos_fused"
   int kernel = 1;
   int64_t n_apply = 0;
   int64_t device_bytes = 0;
@@ -192,6 +195,7 @@ int hxv_destroy(hxv_handle* h) {
   if (h->d_wt) (void)hipFree(h->d_wt);
   for (auto& p : h->d_lz)
     if (p) (void)hipFree(p);
+  if (h->d_lz_partial) (void)hipFree(h->d_lz_partial);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -313,6 +317,10 @@ int hxv_set_option(hxv_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "lds_min_kb_up") || !strcmp(name, "lds_min_kb_dw")) {
     if (value < 0 || value > 160) return fail(HXV_ERR_ARG, "lds_min_kb must be in [0,160]");
     (name[11] == 'u' ? h->plan.opt.lds_min_kb_up : h->plan.opt.lds_min_kb_dw) = (int)value;
+    return HXV_OK;
+  }
+  if (!strcmp(name, "lanczos_fused")) {
+    h->lz_fused = value ? 1 : 0;
     return HXV_OK;
   }
   if (!strcmp(name, "debug")) {
@@ -594,33 +602,108 @@ struct LzBuf {
   double2 *q, *qm, *w;
 };
 
-// One Lanczos step on device: w = H q - beta qm; alpha = <q,w>; w -= alpha q; beta' = |w|.
-// scal[0]=alpha, scal[1]=beta' (sqrt), scal[2]=previous beta.
-int lanczos_step(hxv_handle* h, LzBuf& b, bool first, double* alpha, double* beta) {
-  const int64_t n = h->host.dim;
-  const int g = grid_for(n);
-  int rc = hxv_apply_device(h, b.q, b.w, h->stream);
-  if (rc) return rc;
-  hipLaunchKernelGGL(lz_sub_dot, dim3(g), dim3(256), 0, h->stream, n, b.w, b.qm, b.q, h->d_scalars, first ? -1 : 2, h->d_partials);
-  hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_partials, g, h->d_scalars, 0, 0);
-  hipLaunchKernelGGL(lz_sub_nrm, dim3(g), dim3(256), 0, h->stream, n, b.w, b.q, h->d_scalars, 0, h->d_partials + RED_BLOCKS);
-  hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_partials + RED_BLOCKS, g, h->d_scalars, 1, 1);
-  double host[2];
-  HIPCHK(hipMemcpyAsync(host, h->d_scalars, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  *alpha = host[0];
-  *beta = host[1];
-  return HXV_OK;
-}
+// scal[i] = scal[a] * scal[b]
+__global__ void lz_mul(double* scal, int i, int a, int b) { scal[i] = scal[a] * scal[b]; }
 
-// rotate: qm <- q, q <- w/beta  (scal[2] <- beta)
-int lanczos_advance(hxv_handle* h, LzBuf& b) {
-  const int64_t n = h->host.dim;
-  HIPCHK(hipMemcpyAsync(h->d_scalars + 2, h->d_scalars + 1, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-  std::swap(b.q, b.qm);
-  hipLaunchKernelGGL(lz_scale, dim3(grid_for(n)), dim3(256), 0, h->stream, n, b.q, b.w, h->d_scalars, 2);
-  return HXV_OK;
-}
+// Lanczos recurrence on device.  Two implementations of one step:
+//  * plain : w = H q (any kernel), then lz_sub_dot / lz_sub_nrm / lz_scale on normalised vectors;
+//  * fused : vectors are kept UNNORMALISED (q_k = s*X, s = 1/beta_k); pass A's epilogue produces
+//            w = s*H X - c*Xm and the partial sums of alpha, one more pass subtracts alpha*q and reduces beta.
+//            144 B/state per iteration instead of 224.
+struct LzRunner {
+  hxv_handle* h;
+  LzBuf b;
+  bool fused;
+  bool first = true;
+  double s_cur = 1.0;   // q = s_cur * b.q (fused) ; 1 (plain)
+  double beta_prev = 1.0;
+
+  LzRunner(hxv_handle* hh, double2* x, double2* xm, double2* w) : h(hh), b{x, xm, w} {
+    fused = hh->kernel == 1 && hh->plan.usable && !hh->dev.nd.active && hh->plan.opt.passes == 3 && hh->plan.opt.debug == 0 &&
+            hh->host.nranks == 1 && hh->lz_fused;
+  }
+
+  // b.q holds a vector of norm `nrm` (pass 1.0 if already normalised)
+  int begin(double nrm) {
+    first = true;
+    s_cur = 1.0 / nrm;
+    beta_prev = nrm;
+    if (!fused && nrm != 1.0) return fail(HXV_ERR_STATE, "plain Lanczos expects a normalised start vector");
+    return HXV_OK;
+  }
+
+  int step(double* alpha, double* beta) {
+    const int64_t n = h->host.dim;
+    const int g = grid_for(n);
+    if (!fused) {
+      int rc = hxv_apply_device(h, b.q, b.w, h->stream);
+      if (rc) return rc;
+      hipLaunchKernelGGL(lz_sub_dot, dim3(g), dim3(256), 0, h->stream, n, b.w, b.qm, b.q, h->d_scalars, first ? -1 : 2, h->d_partials);
+      hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_partials, g, h->d_scalars, 0, 0);
+      hipLaunchKernelGGL(lz_sub_nrm, dim3(g), dim3(256), 0, h->stream, n, b.w, b.q, h->d_scalars, 0, h->d_partials + RED_BLOCKS);
+      hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_partials + RED_BLOCKS, g, h->d_scalars, 1, 1);
+    } else {
+      const int64_t nwg = tiled_pass_up_workgroups(h->dev, h->plan);
+      if (nwg > h->lz_partial_n) {
+        if (h->d_lz_partial) (void)hipFree(h->d_lz_partial);
+        HIPCHK(hipMalloc((void**)&h->d_lz_partial, (size_t)nwg * sizeof(double)));
+        h->lz_partial_n = nwg;
+      }
+      if (!h->d_wt) {
+        const size_t bytes = (size_t)n * sizeof(double2);
+        HIPCHK(hipMalloc((void**)&h->d_wt, bytes));
+        h->device_bytes += (int64_t)bytes;
+      }
+      // scal[2] = s, scal[3] = c = beta_k / beta_{k-1}
+      const double sc[2] = {s_cur, first ? 0.0 : 1.0 / (s_cur * beta_prev)};
+      HIPCHK(hipMemcpyAsync(h->d_scalars + 2, sc, 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+      LzEpilogue ep;
+      ep.xm = first ? nullptr : b.qm;
+      ep.scal = h->d_scalars;
+      ep.i_s = 2;
+      ep.i_c = 3;
+      ep.partial = h->d_lz_partial;
+      hipError_t e = launch_hxv_tiled(h->dev, h->plan, b.q, h->d_wt, b.w, h->stream, &ep);
+      if (e != hipSuccess) return fail(HXV_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+      h->n_apply++;
+      hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_lz_partial, (int)nwg, h->d_scalars, 0, 0);
+      hipLaunchKernelGGL(lz_mul, dim3(1), dim3(1), 0, h->stream, h->d_scalars, 4, 0, 2);
+      hipLaunchKernelGGL(lz_sub_nrm, dim3(g), dim3(256), 0, h->stream, n, b.w, b.q, h->d_scalars, 4, h->d_partials + RED_BLOCKS);
+      hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_partials + RED_BLOCKS, g, h->d_scalars, 1, 1);
+    }
+    double host[2];
+    HIPCHK(hipMemcpyAsync(host, h->d_scalars, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *alpha = host[0];
+    *beta = host[1];
+    last_beta = host[1];
+    return HXV_OK;
+  }
+
+  // rotate to the next Lanczos vector (needs the beta returned by step())
+  int advance() {
+    const int64_t n = h->host.dim;
+    if (!fused) {
+      HIPCHK(hipMemcpyAsync(h->d_scalars + 2, h->d_scalars + 1, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+      std::swap(b.q, b.qm);
+      hipLaunchKernelGGL(lz_scale, dim3(grid_for(n)), dim3(256), 0, h->stream, n, b.q, b.w, h->d_scalars, 2);
+    } else {
+      double2* old_m = b.qm;
+      b.qm = b.q;      // X_{k-1}
+      b.q = b.w;       // X_k = unnormalised residual
+      b.w = old_m;
+      beta_prev = 1.0 / s_cur;   // beta_k
+      s_cur = 1.0 / last_beta;   // 1/beta_{k+1}
+    }
+    first = false;
+    return HXV_OK;
+  }
+
+  double last_beta = 0.0;
+  // current normalised Lanczos vector = scale() * vec()
+  const double2* vec() const { return b.q; }
+  double scale() const { return fused ? s_cur : 1.0; }
+};
 
 int ensure_lz(hxv_handle* h) {
   if (h->host.nranks != 1) return fail(HXV_ERR_STATE, "device Lanczos needs nranks==1 (global dots belong to the caller's communicator)");
@@ -643,8 +726,10 @@ int hxv_lanczos_tridiag(hxv_handle* h, const void* d_vin, int32_t nlanc, double*
   int rc = ensure_lz(h);
   if (rc) return rc;
   const int64_t n = h->host.dim;
-  LzBuf b{h->d_lz[0], h->d_lz[1], h->d_lz[2]};
-  HIPCHK(hipMemcpyAsync(b.q, d_vin, (size_t)n * sizeof(double2), hipMemcpyDeviceToDevice, h->stream));
+  LzRunner lz(h, h->d_lz[0], h->d_lz[1], h->d_lz[2]);
+  HIPCHK(hipMemcpyAsync(lz.b.q, d_vin, (size_t)n * sizeof(double2), hipMemcpyDeviceToDevice, h->stream));
+  rc = lz.begin(1.0);  // vin is normalised by the caller (ED_GF_NORMAL.f90:197-199)
+  if (rc) return rc;
   for (int k = 0; k < nlanc; ++k) {
     alanc[k] = 0;
     blanc[k] = 0;
@@ -652,7 +737,7 @@ int hxv_lanczos_tridiag(hxv_handle* h, const void* d_vin, int32_t nlanc, double*
   int k = 0;
   for (; k < nlanc; ++k) {
     double a, bt;
-    rc = lanczos_step(h, b, k == 0, &a, &bt);
+    rc = lz.step(&a, &bt);
     if (rc) return rc;
     alanc[k] = a;
     if (k + 1 < nlanc) blanc[k + 1] = bt;
@@ -661,7 +746,7 @@ int hxv_lanczos_tridiag(hxv_handle* h, const void* d_vin, int32_t nlanc, double*
       break;
     }
     if (k + 1 < nlanc) {
-      rc = lanczos_advance(h, b);
+      rc = lz.advance();
       if (rc) return rc;
     }
   }
@@ -677,18 +762,18 @@ int hxv_lanczos_eigh(hxv_handle* h, int32_t nitermax, double threshold, double* 
   const int64_t n = h->host.dim;
   const int g = grid_for(n);
   const int nmax = (int)std::min<int64_t>(nitermax, n);
-  LzBuf b{h->d_lz[0], h->d_lz[1], h->d_lz[2]};
   const uint64_t seed = 0x5EED5EEDull;
-  auto start = [&]() -> int {
-    hipLaunchKernelGGL(lz_init, dim3(g), dim3(256), 0, h->stream, n, b.w, seed);
-    // normalise: scal[1] = |w|, then q = w/scal[1] via advance-like scale
+  // deterministic start vector, normalised
+  auto start = [&](LzRunner& lz) -> int {
+    hipLaunchKernelGGL(lz_init, dim3(g), dim3(256), 0, h->stream, n, lz.b.w, seed);
     HIPCHK(hipMemsetAsync(h->d_scalars, 0, 8 * sizeof(double), h->stream));
-    hipLaunchKernelGGL(lz_nrm, dim3(g), dim3(256), 0, h->stream, n, b.w, h->d_partials + RED_BLOCKS);
+    hipLaunchKernelGGL(lz_nrm, dim3(g), dim3(256), 0, h->stream, n, lz.b.w, h->d_partials + RED_BLOCKS);
     hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_partials + RED_BLOCKS, g, h->d_scalars, 1, 1);
-    hipLaunchKernelGGL(lz_scale, dim3(g), dim3(256), 0, h->stream, n, b.q, b.w, h->d_scalars, 1);
-    return HXV_OK;
+    hipLaunchKernelGGL(lz_scale, dim3(g), dim3(256), 0, h->stream, n, lz.b.q, lz.b.w, h->d_scalars, 1);
+    return lz.begin(1.0);
   };
-  rc = start();
+  LzRunner lz(h, h->d_lz[0], h->d_lz[1], h->d_lz[2]);
+  rc = start(lz);
   if (rc) return rc;
   std::vector<double> al, be(1, 0.0);
   double e_old = 1e300, e_new = 0;
@@ -696,7 +781,7 @@ int hxv_lanczos_eigh(hxv_handle* h, int32_t nitermax, double threshold, double* 
   std::vector<double> d, e;
   for (; k < nmax; ++k) {
     double a, bt;
-    rc = lanczos_step(h, b, k == 0, &a, &bt);
+    rc = lz.step(&a, &bt);
     if (rc) return rc;
     al.push_back(a);
     d = al;
@@ -722,13 +807,13 @@ int hxv_lanczos_eigh(hxv_handle* h, int32_t nitermax, double threshold, double* 
       break;
     }
     be.push_back(bt);
-    rc = lanczos_advance(h, b);
+    rc = lz.advance();
     if (rc) return rc;
   }
   *egs = e_new;
   if (niter) *niter = k;
   if (d_vect) {
-    // second pass: re-run the recurrence and accumulate the Ritz vector y_j q_j
+    // second pass: re-run the recurrence and accumulate the Ritz vector sum_j y_j q_j
     const int m = (int)al.size();
     d = al;
     e = be;
@@ -739,17 +824,17 @@ int hxv_lanczos_eigh(hxv_handle* h, int32_t nitermax, double threshold, double* 
     int jmin = (int)(std::min_element(d.begin(), d.end()) - d.begin());
     const double* y = &z[(size_t)jmin * m];
     double2* out = (double2*)d_vect;
-    b = LzBuf{h->d_lz[0], h->d_lz[1], h->d_lz[2]};
-    rc = start();
+    LzRunner lz2(h, h->d_lz[0], h->d_lz[1], h->d_lz[2]);
+    rc = start(lz2);
     if (rc) return rc;
     HIPCHK(hipMemsetAsync(out, 0, (size_t)n * sizeof(double2), h->stream));
     for (int j = 0; j < m; ++j) {
-      hipLaunchKernelGGL(lz_axpy, dim3(g), dim3(256), 0, h->stream, n, out, b.q, y[j]);
+      hipLaunchKernelGGL(lz_axpy, dim3(g), dim3(256), 0, h->stream, n, out, lz2.vec(), y[j] * lz2.scale());
       if (j + 1 == m) break;
       double a, bt;
-      rc = lanczos_step(h, b, j == 0, &a, &bt);
+      rc = lz2.step(&a, &bt);
       if (rc) return rc;
-      rc = lanczos_advance(h, b);
+      rc = lz2.advance();
       if (rc) return rc;
     }
     // normalise the Ritz vector
@@ -766,20 +851,26 @@ int hxv_time_lanczos(hxv_handle* h, void* d_work3, int32_t nrep, float* ms_per_i
   if (h->host.nranks != 1) return fail(HXV_ERR_STATE, "hxv_time_lanczos needs nranks==1");
   HIPCHK(hipSetDevice(h->device));
   const int64_t n = h->host.dim;
-  LzBuf b{(double2*)d_work3, (double2*)d_work3 + n, (double2*)d_work3 + 2 * n};
+  LzRunner lz(h, (double2*)d_work3, (double2*)d_work3 + n, (double2*)d_work3 + 2 * n);
   const int g = grid_for(n);
-  hipLaunchKernelGGL(lz_init, dim3(g), dim3(256), 0, h->stream, n, b.w, 0x1234ull);
+  hipLaunchKernelGGL(lz_init, dim3(g), dim3(256), 0, h->stream, n, lz.b.w, 0x1234ull);
   HIPCHK(hipMemsetAsync(h->d_scalars, 0, 8 * sizeof(double), h->stream));
-  hipLaunchKernelGGL(lz_nrm, dim3(g), dim3(256), 0, h->stream, n, b.w, h->d_partials + RED_BLOCKS);
+  hipLaunchKernelGGL(lz_nrm, dim3(g), dim3(256), 0, h->stream, n, lz.b.w, h->d_partials + RED_BLOCKS);
   hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_partials + RED_BLOCKS, g, h->d_scalars, 1, 1);
-  hipLaunchKernelGGL(lz_scale, dim3(g), dim3(256), 0, h->stream, n, b.q, b.w, h->d_scalars, 1);
-  HIPCHK(hipMemsetAsync(b.qm, 0, (size_t)n * sizeof(double2), h->stream));
+  hipLaunchKernelGGL(lz_scale, dim3(g), dim3(256), 0, h->stream, n, lz.b.q, lz.b.w, h->d_scalars, 1);
+  HIPCHK(hipMemsetAsync(lz.b.qm, 0, (size_t)n * sizeof(double2), h->stream));
+  int rc = lz.begin(1.0);
+  if (rc) return rc;
+  double a, bt;
+  rc = lz.step(&a, &bt);  // untimed first step (lazy allocations)
+  if (rc) return rc;
+  rc = lz.advance();
+  if (rc) return rc;
   HIPCHK(hipEventRecord(h->ev0, h->stream));
   for (int k = 0; k < nrep; ++k) {
-    double a, bt;
-    int rc = lanczos_step(h, b, k == 0, &a, &bt);
+    rc = lz.step(&a, &bt);
     if (rc) return rc;
-    rc = lanczos_advance(h, b);
+    rc = lz.advance();
     if (rc) return rc;
   }
   HIPCHK(hipEventRecord(h->ev1, h->stream));

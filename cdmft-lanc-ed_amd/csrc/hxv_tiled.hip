@@ -79,10 +79,10 @@ __device__ __forceinline__ double diag_value(const DevDiag& dg, double au, uint3
 // ---------------------------------------------------------------------------------------
 // pass A
 // ---------------------------------------------------------------------------------------
-template <int C, bool REAL, bool NORB1>
+template <int C, bool REAL, bool NORB1, bool LZ>
 __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, const double2* __restrict__ v,
                                                       const double2* __restrict__ wt, double2* __restrict__ hv, int ngroups,
-                                                      int groups_per_xcd) {
+                                                      int groups_per_xcd, LzEpilogue lz) {
   using CT = typename Coef<REAL>::type;
   extern __shared__ double2 lds[];
   const int b = blockIdx.x;
@@ -92,7 +92,10 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
   const int gl = j / t.nblocks;
   const int g = xcd * groups_per_xcd + gl;
   const int kb = j - gl * t.nblocks;
-  if (gl >= groups_per_xcd || g >= ngroups) return;
+  if (gl >= groups_per_xcd || g >= ngroups) {
+    if (LZ && threadIdx.x == 0) lz.partial[blockIdx.x] = 0.0;
+    return;
+  }
   const int T = blockDim.x;
   const int r0 = (int)t.start[kb];
   const int n = (int)t.start[kb + 1] - r0;
@@ -110,10 +113,15 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
   // one row per thread (plan guarantees n <= blockDim.x)
   const int p = threadIdx.x;
   double2 acc[C];
+  double2 xq[LZ ? C : 1];  // the thread's own input elements, kept for the Lanczos epilogue
   int r = 0;
   if (p < n) {
     const uint32_t packed = __builtin_amdgcn_readfirstlane(t.gmax[t.gstart[kb] + (p >> 6)]);
     const int kin = (int)(packed & 0xFFFFu);
+    if (LZ) {
+#pragma unroll
+      for (int cc = 0; cc < C; ++cc) xq[LZ ? cc : 0] = lds[cc * n + p];
+    }
     const int i = r0 + p;  // pass A visits the rows in natural order: every global access stays coalesced
     r = p;
     if (s.diag.mode == 0) {
@@ -196,17 +204,51 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
     }
   }
   __syncthreads();
+  if (!LZ) {
 #pragma unroll
-  for (int cc = 0; cc < C; ++cc) {
-    if (cc < nc) {
-      double2* __restrict__ dst = hv + (int64_t)(c0 + cc) * s.dimup + r0;
-      for (int rr = threadIdx.x; rr < n; rr += T) {
-        if (t.debug & 8)
-          dst[rr] = lds[cc * n + rr];
-        else
-          store_stream(&dst[rr], lds[cc * n + rr]);
+    for (int cc = 0; cc < C; ++cc) {
+      if (cc < nc) {
+        double2* __restrict__ dst = hv + (int64_t)(c0 + cc) * s.dimup + r0;
+        for (int rr = threadIdx.x; rr < n; rr += T) {
+          if (t.debug & 8)
+            dst[rr] = lds[cc * n + rr];
+          else
+            store_stream(&dst[rr], lds[cc * n + rr]);
+        }
       }
     }
+  } else {
+    // Lanczos epilogue: w = s*(H x) - c*xm, partial sum of Re(conj(s*x) w); same thread <-> row mapping as above
+    const double sc = lz.scal[lz.i_s], cm = lz.xm ? lz.scal[lz.i_c] : 0.0;
+    double asum = 0.0;
+    if (p < n) {
+#pragma unroll
+      for (int cc = 0; cc < C; ++cc) {
+        if (cc < nc) {
+          const int64_t o = (int64_t)(c0 + cc) * s.dimup + r0 + p;
+          double2 w = lds[cc * n + p];
+          w.x *= sc;
+          w.y *= sc;
+          if (lz.xm) {
+            const double2 m = lz.xm[o];
+            w.x -= cm * m.x;
+            w.y -= cm * m.y;
+          }
+          const double2 x = xq[LZ ? cc : 0];
+          asum += sc * (x.x * w.x + x.y * w.y);
+          store_stream(&hv[o], w);
+        }
+      }
+    }
+    __syncthreads();
+    double* red = reinterpret_cast<double*>(lds);
+    red[threadIdx.x] = asum;
+    __syncthreads();
+    for (int st = T >> 1; st > 0; st >>= 1) {
+      if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) lz.partial[blockIdx.x] = red[0];
   }
 }
 
@@ -547,21 +589,29 @@ void build_spin_tiles(const SpinOp& op, const std::vector<uint32_t>& map, int lo
   t.rs_per_row = rs_rows / dim;
 }
 
-template <int C>
-hipError_t launch_up(const DevSector& s, const DevTiles& t, int lds_bytes, int threads, bool norb1, const double2* v, const double2* wt,
-                     double2* hv, hipStream_t st) {
+template <int C, bool LZ>
+hipError_t launch_up_lz(const DevSector& s, const DevTiles& t, int lds_bytes, int threads, bool norb1, const double2* v, const double2* wt,
+                        double2* hv, const LzEpilogue& lz, hipStream_t st) {
   const int ngroups = (s.qdw + C - 1) / C;
   const int gpx = (ngroups + 7) / 8;
   const int64_t nwg = (int64_t)gpx * 8 * t.nblocks;
-  void (*kern)(DevSector, DevTiles, const double2*, const double2*, double2*, int, int);
+  void (*kern)(DevSector, DevTiles, const double2*, const double2*, double2*, int, int, LzEpilogue);
   if (s.real_h)
-    kern = norb1 ? hxv_pass_up<C, true, true> : hxv_pass_up<C, true, false>;
+    kern = norb1 ? hxv_pass_up<C, true, true, LZ> : hxv_pass_up<C, true, false, LZ>;
   else
-    kern = norb1 ? hxv_pass_up<C, false, true> : hxv_pass_up<C, false, false>;
+    kern = norb1 ? hxv_pass_up<C, false, true, LZ> : hxv_pass_up<C, false, false, LZ>;
+  lds_bytes = std::max(lds_bytes, threads * 8);  // the epilogue reduces through LDS
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(threads), (size_t)lds_bytes, st, s, t, v, wt, hv, ngroups, gpx);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(threads), (size_t)lds_bytes, st, s, t, v, wt, hv, ngroups, gpx, lz);
   return hipGetLastError();
+}
+
+template <int C>
+hipError_t launch_up(const DevSector& s, const DevTiles& t, int lds_bytes, int threads, bool norb1, const double2* v, const double2* wt,
+                     double2* hv, const LzEpilogue* lz, hipStream_t st) {
+  if (lz) return launch_up_lz<C, true>(s, t, lds_bytes, threads, norb1, v, wt, hv, *lz, st);
+  return launch_up_lz<C, false>(s, t, lds_bytes, threads, norb1, v, wt, hv, LzEpilogue(), st);
 }
 
 template <int R, int NP>
@@ -641,7 +691,14 @@ std::string make_tile_plan(const SectorHost& s, TilePlan& plan, const PlanUpload
   return "";
 }
 
-hipError_t launch_hxv_tiled(const DevSector& s, const TilePlan& plan, const double2* v, double2* wt, double2* hv, hipStream_t st) {
+int64_t tiled_pass_up_workgroups(const DevSector& s, const TilePlan& plan) {
+  const int C = plan.opt.cols_per_tile;
+  const int ngroups = (s.qdw + C - 1) / C;
+  return (int64_t)((ngroups + 7) / 8) * 8 * plan.up.nblocks;
+}
+
+hipError_t launch_hxv_tiled(const DevSector& s, const TilePlan& plan, const double2* v, double2* wt, double2* hv, hipStream_t st,
+                            const LzEpilogue* lz) {
   // wt: scratch of qdw*DimUp elements (transposed dw-hop part), owned by the handle
   if (s.qdw == 0) return hipSuccess;
   DevTiles tu{plan.up.d_start, plan.up.d_perm, plan.up.d_gstart, plan.up.d_gmax, plan.up.d_ell_in, plan.up.d_ell_out,
@@ -664,9 +721,9 @@ hipError_t launch_hxv_tiled(const DevSector& s, const TilePlan& plan, const doub
   if (e != hipSuccess) return e;
   const double2* wta = (plan.opt.passes & 2) ? wt : nullptr;
   if (plan.opt.passes & 1) switch (C) {
-      case 2: e = launch_up<2>(s, tu, lds_a, ta, norb1, v, wta, hv, st); break;
-      case 4: e = launch_up<4>(s, tu, lds_a, ta, norb1, v, wta, hv, st); break;
-      default: e = launch_up<8>(s, tu, lds_a, ta, norb1, v, wta, hv, st); break;
+      case 2: e = launch_up<2>(s, tu, lds_a, ta, norb1, v, wta, hv, lz, st); break;
+      case 4: e = launch_up<4>(s, tu, lds_a, ta, norb1, v, wta, hv, lz, st); break;
+      default: e = launch_up<8>(s, tu, lds_a, ta, norb1, v, wta, hv, lz, st); break;
     }
   return e;
 }

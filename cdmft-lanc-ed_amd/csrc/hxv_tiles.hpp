@@ -68,12 +68,23 @@ struct TilePlan {
   bool usable = true;             // false: too many distinct amplitudes -> the engine uses kernel 0
 };
 
+// Optional Lanczos epilogue of pass A (device Lanczos, hxv_capi.hip): with x the input vector of the product,
+//   w = s*(H x) - c*xm   is stored instead of H x, and   sum Re(conj(s*x) * w)   is reduced per workgroup,
+// s = scal[i_s], c = scal[i_c] read from device memory.  Saves two full vector passes per iteration.
+struct LzEpilogue {
+  const double2* xm = nullptr;  // previous (unnormalised) Lanczos vector, may be null when c == 0
+  const double* scal = nullptr;
+  int i_s = 0, i_c = 0;
+  double* partial = nullptr;    // one partial sum per workgroup of pass A
+};
+int64_t tiled_pass_up_workgroups(const DevSector& s, const TilePlan& plan);
+
 struct PlanUploader {
   std::function<hipError_t(const std::vector<uint32_t>&, uint32_t**)> u32;
   std::function<hipError_t(const std::vector<double2>&, double2**)> d2;
 };
 std::string make_tile_plan(const SectorHost& s, TilePlan& plan, const PlanUploader& up);
 hipError_t launch_hxv_tiled(const DevSector& s, const TilePlan& plan, const double2* v_full, double2* wt_scratch, double2* hv_local,
-                            hipStream_t st);
+                            hipStream_t st, const LzEpilogue* lz = nullptr);
 
 }  // namespace hxv

@@ -146,3 +146,25 @@ def test_impurity_green_function_vs_lehmann(built, model_name):
     assert np.abs(G - Gref).max() <= 1e-9, np.abs(G - Gref).max()
     # sum rule: total spectral weight of c^dagger and c channels = 1
     assert abs((G * 1j * wm)[-1].real - 1.0) < 0.2
+
+
+def test_fused_and_plain_recurrence_agree(built):
+    """The fused Lanczos (pass-A epilogue, unnormalised vectors) and the plain one produce the same tridiagonal."""
+    import torch
+    import hxv
+    from hxv import models
+
+    m = models.hm_1dchain()          # C2, Ns=12, Dim=853776: tiled kernels with several blocks
+    sec = hxv.HxvSector.from_model(m, 6, 6)
+    sec.set_option("lds_budget_kb_up", 16)   # force several prefix blocks (block hops + row slots in the epilogue path)
+    sec.set_option("lds_budget_kb_dw", 32)
+    v = models.deterministic_vector(sec.Dim)
+    v /= np.linalg.norm(v)
+    dv = torch.from_numpy(v).cuda()
+    sec.set_option("lanczos_fused", 1)
+    a1, b1, n1 = sec.lanczos_tridiag(dv, 60)
+    sec.set_option("lanczos_fused", 0)
+    a0, b0, n0 = sec.lanczos_tridiag(dv, 60)
+    assert n0 == n1 == 60
+    assert np.abs(a1 - a0).max() <= 1e-10 * np.abs(a0).max()
+    assert np.abs(b1 - b0).max() <= 1e-10 * np.abs(b0).max()
