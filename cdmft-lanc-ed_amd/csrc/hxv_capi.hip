@@ -35,7 +35,8 @@ struct hxv_handle {
   // staging for hxv_apply_host
   double2* d_stage_v = nullptr;
   double2* d_stage_hv = nullptr;
-  double2* d_wt = nullptr;  // transposed dw-hop scratch of the tiled kernels (vecdim elements)
+  double2* d_wt = nullptr;  // dw-hop scratch of the tiled kernels (column-group-blocked, tiled_wt_elems())
+  int64_t wt_elems = 0;
   // lanczos scratch
   double* d_partials = nullptr;  // [2][RED_BLOCKS]
   double* d_scalars = nullptr;   // [8]
@@ -70,6 +71,23 @@ struct hxv_handle {
 namespace {
 
 constexpr int RED_BLOCKS = 1024;
+
+int ensure_wt(hxv_handle* h) {
+  const int64_t need = std::max<int64_t>(tiled_wt_elems(h->dev, h->plan), 1);
+  if (h->d_wt && h->wt_elems >= need) return HXV_OK;
+  HIPCHK(hipSetDevice(h->device));
+  if (h->d_wt) {
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipDeviceSynchronize());
+    (void)hipFree(h->d_wt);
+    h->device_bytes -= h->wt_elems * (int64_t)sizeof(double2);
+    h->d_wt = nullptr;
+  }
+  HIPCHK(hipMalloc((void**)&h->d_wt, (size_t)need * sizeof(double2)));
+  h->wt_elems = need;
+  h->device_bytes += need * (int64_t)sizeof(double2);
+  return HXV_OK;
+}
 
 int finish_create(hxv_handle* h, int device, hxv_handle** out) {
   int ndev = 0;
@@ -223,12 +241,8 @@ int hxv_apply_device(hxv_handle* h, const void* d_v_full, void* d_hv_local, void
   if (h->kernel == 0 || !h->plan.usable)
     e = launch_hxv_naive(h->dev, (const double2*)d_v_full, (double2*)d_hv_local, st);
   else {
-    if (!h->d_wt) {
-      HIPCHK(hipSetDevice(h->device));
-      const size_t bytes = std::max<size_t>((size_t)h->host.qdw * h->host.dimup, 1) * sizeof(double2);
-      HIPCHK(hipMalloc((void**)&h->d_wt, bytes));
-      h->device_bytes += (int64_t)bytes;
-    }
+    int rcw = ensure_wt(h);
+    if (rcw) return rcw;
     e = launch_hxv_tiled(h->dev, h->plan, (const double2*)d_v_full, h->d_wt, (double2*)d_hv_local, st);
   }
   if (e == hipSuccess && h->dev.nd.active) e = launch_hxv_nonlocal(h->dev, (const double2*)d_v_full, (double2*)d_hv_local, st);
@@ -344,6 +358,7 @@ int hxv_set_option(hxv_handle* h, const char* name, int64_t value) {
   else if (!strcmp(name, "threads_up")) o.threads_up = (int)value;
   else if (!strcmp(name, "threads_dw")) o.threads_dw = (int)value;
   else if (!strcmp(name, "sort_mode")) o.sort_mode = (int)value;
+  else if (!strcmp(name, "wt_cols")) o.wt_cols = (int)value;
   else if (!strcmp(name, "sort_mode_dw")) o.sort_mode_dw = (int)value;
   else return fail(HXV_ERR_ARG, std::string("unknown option ") + name);
   HIPCHK(hipSetDevice(h->device));
@@ -649,11 +664,8 @@ struct LzRunner {
         HIPCHK(hipMalloc((void**)&h->d_lz_partial, (size_t)nwg * sizeof(double)));
         h->lz_partial_n = nwg;
       }
-      if (!h->d_wt) {
-        const size_t bytes = (size_t)n * sizeof(double2);
-        HIPCHK(hipMalloc((void**)&h->d_wt, bytes));
-        h->device_bytes += (int64_t)bytes;
-      }
+      int rcw = ensure_wt(h);
+      if (rcw) return rcw;
       // scal[2] = s, scal[3] = c = beta_k / beta_{k-1}
       const double sc[2] = {s_cur, first ? 0.0 : 1.0 / (s_cur * beta_prev)};
       HIPCHK(hipMemcpyAsync(h->d_scalars + 2, sc, 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));

@@ -82,7 +82,7 @@ __device__ __forceinline__ double diag_value(const DevDiag& dg, double au, uint3
 template <int C, bool REAL, bool NORB1, bool LZ>
 __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, const double2* __restrict__ v,
                                                       const double2* __restrict__ wt, double2* __restrict__ hv, int ngroups,
-                                                      int groups_per_xcd, LzEpilogue lz) {
+                                                      int groups_per_xcd, int wc, LzEpilogue lz) {
   using CT = typename Coef<REAL>::type;
   extern __shared__ double2 lds[];
   const int b = blockIdx.x;
@@ -175,58 +175,25 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
       }
     }
   }
-  if (!wt) {  // timing experiments only (passes == 1): no dw part to add
-    if (p < n) {
-#pragma unroll
-      for (int cc = 0; cc < C; ++cc)
-        if (cc < nc) store_stream(&hv[(int64_t)(c0 + cc) * s.dimup + r0 + r], acc[cc]);
-    }
-    return;
-  }
-  // Park the sums in the tile, add the dw-hop part that pass B left TRANSPOSED in wt[row][local column]
-  // (C*16 contiguous bytes per row: lanes run along the C columns so a wave reads 64/C whole segments per
-  // instruction -- strided READS of short segments are cheap on this memory system, strided writes are not),
-  // then store hv with lanes along the rows.
-  __syncthreads();
+  // Epilogue, same thread <-> row mapping: add the dw-hop part that pass B left in the column-group-blocked
+  // scratch wt[group][row][C] (C*16 contiguous bytes per row, rows consecutive: a plain streaming read), then
+  // store hv with lanes along the rows.  With LZ: w = s*(H x) - c*xm and the partial sums of Re(conj(s*x) w).
+  double asum = 0.0;
   if (p < n) {
-#pragma unroll
-    for (int cc = 0; cc < C; ++cc) lds[cc * n + r] = acc[cc];
-  }
-  __syncthreads();
-  for (int q = threadIdx.x; q < n * C; q += T) {
-    const int row = q / C, cc = q % C;
-    if (cc < nc) {
-      const double2 w = wt[(int64_t)(r0 + row) * s.qdw + c0 + cc];
-      double2 a = lds[cc * n + row];
-      a.x += w.x;
-      a.y += w.y;
-      lds[cc * n + row] = a;
-    }
-  }
-  __syncthreads();
-  if (!LZ) {
+    const double sc = LZ ? lz.scal[lz.i_s] : 1.0;
+    const double cm = (LZ && lz.xm) ? lz.scal[lz.i_c] : 0.0;
+    const double2* __restrict__ wrow = wt ? wt + ((int64_t)(c0 / wc) * s.dimup + r0 + p) * wc + (c0 % wc) : nullptr;
 #pragma unroll
     for (int cc = 0; cc < C; ++cc) {
       if (cc < nc) {
-        double2* __restrict__ dst = hv + (int64_t)(c0 + cc) * s.dimup + r0;
-        for (int rr = threadIdx.x; rr < n; rr += T) {
-          if (t.debug & 8)
-            dst[rr] = lds[cc * n + rr];
-          else
-            store_stream(&dst[rr], lds[cc * n + rr]);
+        const int64_t o = (int64_t)(c0 + cc) * s.dimup + r0 + p;
+        double2 w = acc[cc];
+        if (wt) {
+          const double2 wd = wrow[cc];
+          w.x += wd.x;
+          w.y += wd.y;
         }
-      }
-    }
-  } else {
-    // Lanczos epilogue: w = s*(H x) - c*xm, partial sum of Re(conj(s*x) w); same thread <-> row mapping as above
-    const double sc = lz.scal[lz.i_s], cm = lz.xm ? lz.scal[lz.i_c] : 0.0;
-    double asum = 0.0;
-    if (p < n) {
-#pragma unroll
-      for (int cc = 0; cc < C; ++cc) {
-        if (cc < nc) {
-          const int64_t o = (int64_t)(c0 + cc) * s.dimup + r0 + p;
-          double2 w = lds[cc * n + p];
+        if (LZ) {
           w.x *= sc;
           w.y *= sc;
           if (lz.xm) {
@@ -236,10 +203,15 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
           }
           const double2 x = xq[LZ ? cc : 0];
           asum += sc * (x.x * w.x + x.y * w.y);
-          store_stream(&hv[o], w);
         }
+        if (t.debug & 8)
+          hv[o] = w;
+        else  // contiguous runs of a whole block: streaming stores measured ~10 % faster here
+          store_stream(&hv[o], w);
       }
     }
+  }
+  if (LZ) {
     __syncthreads();
     double* red = reinterpret_cast<double*>(lds);
     red[threadIdx.x] = asum;
@@ -260,7 +232,7 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
 // ---------------------------------------------------------------------------------------
 template <int R, int NP, bool REAL>
 __global__ void __launch_bounds__(1024) hxv_pass_dw(DevSector s, DevTiles t, const double2* __restrict__ v, double2* __restrict__ wt,
-                                                      int ngroups, int groups_per_xcd) {
+                                                      int ngroups, int groups_per_xcd, int wc) {
   // NP = (row,column) pairs of the tile per thread (plan: max_block*R <= NP*blockDim.x); all their global
   // loads are issued before the first use so a workgroup keeps NP requests per lane in flight.
   using CT = typename Coef<REAL>::type;
@@ -386,12 +358,18 @@ __global__ void __launch_bounds__(1024) hxv_pass_dw(DevSector s, DevTiles t, con
     }
   }
   __syncthreads();
-  // store TRANSPOSED: wt[row][local column], lanes along the block's columns -> n*16 contiguous bytes per row
-  const int cl0 = max(cb0, s.dw0), cl1 = min(cb0 + n, s.dw0 + s.qdw);  // local output columns of this block
-  const int nloc = cl1 - cl0;
-  for (int q = threadIdx.x; q < nloc * R; q += T) {
-    const int r = q / nloc, col = (cl0 - cb0) + (q - r * nloc);
-    if (i0 + r < s.dimup) wt[(int64_t)(i0 + r) * s.qdw + (cb0 + col - s.dw0)] = lds[r * ns + col];
+  // store into the column-group-blocked scratch wt[group][row][WC] (WC = pass A's columns per tile): the R rows x
+  // WC columns of one group are R*WC*16 contiguous, aligned bytes -- strided WRITES need long aligned runs on this
+  // memory system -- and pass A later reads its whole tile of wt as one contiguous run.
+  const int cl0 = max(cb0, s.dw0) - s.dw0, cl1 = min(cb0 + n, s.dw0 + s.qdw) - s.dw0;  // local output columns [cl0,cl1)
+  const int g0 = cl0 / wc, g1 = (cl1 + wc - 1) / wc;
+  const int per = R * wc;
+  for (int q = threadIdx.x; q < (g1 - g0) * per; q += T) {
+    const int gq = g0 + q / per, rem = q % per;
+    const int r = rem / wc, cc = rem % wc;
+    const int lc = gq * wc + cc;  // local column
+    if (lc >= cl0 && lc < cl1 && i0 + r < s.dimup)
+      wt[((int64_t)gq * s.dimup + i0 + r) * wc + cc] = lds[r * ns + (lc + s.dw0 - cb0)];
   }
 }
 
@@ -590,12 +568,12 @@ void build_spin_tiles(const SpinOp& op, const std::vector<uint32_t>& map, int lo
 }
 
 template <int C, bool LZ>
-hipError_t launch_up_lz(const DevSector& s, const DevTiles& t, int lds_bytes, int threads, bool norb1, const double2* v, const double2* wt,
-                        double2* hv, const LzEpilogue& lz, hipStream_t st) {
+hipError_t launch_up_lz(const DevSector& s, const DevTiles& t, int lds_bytes, int threads, bool norb1, int wc, const double2* v,
+                        const double2* wt, double2* hv, const LzEpilogue& lz, hipStream_t st) {
   const int ngroups = (s.qdw + C - 1) / C;
   const int gpx = (ngroups + 7) / 8;
   const int64_t nwg = (int64_t)gpx * 8 * t.nblocks;
-  void (*kern)(DevSector, DevTiles, const double2*, const double2*, double2*, int, int, LzEpilogue);
+  void (*kern)(DevSector, DevTiles, const double2*, const double2*, double2*, int, int, int, LzEpilogue);
   if (s.real_h)
     kern = norb1 ? hxv_pass_up<C, true, true, LZ> : hxv_pass_up<C, true, false, LZ>;
   else
@@ -603,37 +581,38 @@ hipError_t launch_up_lz(const DevSector& s, const DevTiles& t, int lds_bytes, in
   lds_bytes = std::max(lds_bytes, threads * 8);  // the epilogue reduces through LDS
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(threads), (size_t)lds_bytes, st, s, t, v, wt, hv, ngroups, gpx, lz);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(threads), (size_t)lds_bytes, st, s, t, v, wt, hv, ngroups, gpx, wc, lz);
   return hipGetLastError();
 }
 
 template <int C>
-hipError_t launch_up(const DevSector& s, const DevTiles& t, int lds_bytes, int threads, bool norb1, const double2* v, const double2* wt,
-                     double2* hv, const LzEpilogue* lz, hipStream_t st) {
-  if (lz) return launch_up_lz<C, true>(s, t, lds_bytes, threads, norb1, v, wt, hv, *lz, st);
-  return launch_up_lz<C, false>(s, t, lds_bytes, threads, norb1, v, wt, hv, LzEpilogue(), st);
+hipError_t launch_up(const DevSector& s, const DevTiles& t, int lds_bytes, int threads, bool norb1, int wc, const double2* v,
+                     const double2* wt, double2* hv, const LzEpilogue* lz, hipStream_t st) {
+  if (lz) return launch_up_lz<C, true>(s, t, lds_bytes, threads, norb1, wc, v, wt, hv, *lz, st);
+  return launch_up_lz<C, false>(s, t, lds_bytes, threads, norb1, wc, v, wt, hv, LzEpilogue(), st);
 }
 
 template <int R, int NP>
-hipError_t launch_dw_np(const DevSector& s, const DevTiles& t, int lds_bytes, int threads, const double2* v, double2* hv, hipStream_t st) {
+hipError_t launch_dw_np(const DevSector& s, const DevTiles& t, int lds_bytes, int threads, int wc, const double2* v, double2* hv,
+                        hipStream_t st) {
   const int ngroups = (s.dimup + R - 1) / R;
   const int gpx = (ngroups + 7) / 8;
   const int64_t nwg = (int64_t)gpx * 8 * t.nblocks;
   auto kern = s.real_h ? hxv_pass_dw<R, NP, true> : hxv_pass_dw<R, NP, false>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(threads), (size_t)lds_bytes, st, s, t, v, hv, ngroups, gpx);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(threads), (size_t)lds_bytes, st, s, t, v, hv, ngroups, gpx, wc);
   return hipGetLastError();
 }
 
 template <int R>
-hipError_t launch_dw(const DevSector& s, const DevTiles& t, int max_block, int lds_bytes, int threads, const double2* v, double2* hv,
-                     hipStream_t st) {
+hipError_t launch_dw(const DevSector& s, const DevTiles& t, int max_block, int lds_bytes, int threads, int wc, const double2* v,
+                     double2* hv, hipStream_t st) {
   const int np = (max_block * R + threads - 1) / threads;  // <= R because max_block <= threads
-  if (np <= 1) return launch_dw_np<R, 1>(s, t, lds_bytes, threads, v, hv, st);
-  if (np <= 2) return launch_dw_np<R, 2>(s, t, lds_bytes, threads, v, hv, st);
-  if (np <= 4) return launch_dw_np<R, 4>(s, t, lds_bytes, threads, v, hv, st);
-  return launch_dw_np<R, 8>(s, t, lds_bytes, threads, v, hv, st);
+  if (np <= 1) return launch_dw_np<R, 1>(s, t, lds_bytes, threads, wc, v, hv, st);
+  if (np <= 2) return launch_dw_np<R, 2>(s, t, lds_bytes, threads, wc, v, hv, st);
+  if (np <= 4) return launch_dw_np<R, 4>(s, t, lds_bytes, threads, wc, v, hv, st);
+  return launch_dw_np<R, 8>(s, t, lds_bytes, threads, wc, v, hv, st);
 }
 
 std::vector<double2> signed_coefs(const SpinOp& op) {
@@ -657,6 +636,7 @@ std::string make_tile_plan(const SectorHost& s, TilePlan& plan, const PlanUpload
   for (int th : {o.threads_up, o.threads_dw})
     if (th != 256 && th != 512 && th != 1024) return "threads must be 256, 512 or 1024";
   if (o.sort_mode < 0 || o.sort_mode > 2) return "sort_mode must be 0, 1 or 2";
+  if (o.wt_cols != 2 && o.wt_cols != 4 && o.wt_cols != 8 && o.wt_cols != 16) return "wt_cols must be 2, 4, 8 or 16";
   plan.ncoef_up = (int)s.up.coef.size();
   plan.ncoef_dw = (int)s.dw.coef.size();
   plan.usable = plan.ncoef_up <= TILE_MAX_COEF && plan.ncoef_dw <= TILE_MAX_COEF;
@@ -691,6 +671,11 @@ std::string make_tile_plan(const SectorHost& s, TilePlan& plan, const PlanUpload
   return "";
 }
 
+int64_t tiled_wt_elems(const DevSector& s, const TilePlan& plan) {
+  const int wc = std::max(plan.opt.cols_per_tile, plan.opt.wt_cols);
+  return (int64_t)((s.qdw + wc - 1) / wc) * wc * s.dimup;
+}
+
 int64_t tiled_pass_up_workgroups(const DevSector& s, const TilePlan& plan) {
   const int C = plan.opt.cols_per_tile;
   const int ngroups = (s.qdw + C - 1) / C;
@@ -699,7 +684,7 @@ int64_t tiled_pass_up_workgroups(const DevSector& s, const TilePlan& plan) {
 
 hipError_t launch_hxv_tiled(const DevSector& s, const TilePlan& plan, const double2* v, double2* wt, double2* hv, hipStream_t st,
                             const LzEpilogue* lz) {
-  // wt: scratch of qdw*DimUp elements (transposed dw-hop part), owned by the handle
+  // wt: scratch of tiled_wt_elems() elements (dw-hop part, column-group-blocked), owned by the handle
   if (s.qdw == 0) return hipSuccess;
   DevTiles tu{plan.up.d_start, plan.up.d_perm, plan.up.d_gstart, plan.up.d_gmax, plan.up.d_ell_in, plan.up.d_ell_out,
               plan.d_scoef_up, plan.up.d_bh_ptr, plan.up.d_bh, plan.up.d_rs_ptr, plan.up.d_rs_off, plan.up.d_rs_tab,
@@ -708,22 +693,23 @@ hipError_t launch_hxv_tiled(const DevSector& s, const TilePlan& plan, const doub
               plan.d_scoef_dw, plan.dw.d_bh_ptr, plan.dw.d_bh, plan.dw.d_rs_ptr, plan.dw.d_rs_off, plan.dw.d_rs_tab,
               plan.dw.nblocks, 2 * plan.ncoef_dw + 1, plan.opt.debug};
   const int C = plan.opt.cols_per_tile, R = plan.opt.rows_per_tile;
+  const int wc = std::max(C, plan.opt.wt_cols);  // columns per group of the wt scratch (a multiple of C)
   const int lds_a = std::max((plan.up.max_block * C + tu.nscoef) * 16, plan.opt.lds_min_kb_up * 1024);
   const int lds_b = std::max(((((plan.dw.max_block + 15) & ~15) + 16 / R) * R + td.nscoef) * 16, plan.opt.lds_min_kb_dw * 1024);
   const int ta = plan.opt.threads_up, tb = plan.opt.threads_dw;
   const bool norb1 = s.diag.mode == 0 && s.diag.cross.norb == 1;
   hipError_t e = hipSuccess;
   if (plan.opt.passes & 2) switch (R) {
-      case 2: e = launch_dw<2>(s, td, plan.dw.max_block, lds_b, tb, v, wt, st); break;
-      case 4: e = launch_dw<4>(s, td, plan.dw.max_block, lds_b, tb, v, wt, st); break;
-      default: e = launch_dw<8>(s, td, plan.dw.max_block, lds_b, tb, v, wt, st); break;
+      case 2: e = launch_dw<2>(s, td, plan.dw.max_block, lds_b, tb, wc, v, wt, st); break;
+      case 4: e = launch_dw<4>(s, td, plan.dw.max_block, lds_b, tb, wc, v, wt, st); break;
+      default: e = launch_dw<8>(s, td, plan.dw.max_block, lds_b, tb, wc, v, wt, st); break;
     }
   if (e != hipSuccess) return e;
   const double2* wta = (plan.opt.passes & 2) ? wt : nullptr;
   if (plan.opt.passes & 1) switch (C) {
-      case 2: e = launch_up<2>(s, tu, lds_a, ta, norb1, v, wta, hv, lz, st); break;
-      case 4: e = launch_up<4>(s, tu, lds_a, ta, norb1, v, wta, hv, lz, st); break;
-      default: e = launch_up<8>(s, tu, lds_a, ta, norb1, v, wta, hv, lz, st); break;
+      case 2: e = launch_up<2>(s, tu, lds_a, ta, norb1, wc, v, wta, hv, lz, st); break;
+      case 4: e = launch_up<4>(s, tu, lds_a, ta, norb1, wc, v, wta, hv, lz, st); break;
+      default: e = launch_up<8>(s, tu, lds_a, ta, norb1, wc, v, wta, hv, lz, st); break;
     }
   return e;
 }

@@ -55,6 +55,7 @@ struct TileOptions {
   int sort_mode = 0;  // pass A visiting order: 0 natural (keeps global accesses coalesced), 1 by inner count, 2 by (outer, inner)
   int sort_mode_dw = 1;  // pass B inner phase (LDS only): 0 natural, 1 by inner count
   int lds_min_kb_up = 0, lds_min_kb_dw = 0;  // request at least this much LDS per workgroup (limits workgroups per CU)
+  int wt_cols = 4;  // columns per group of the blocked dw-hop scratch (>= cols_per_tile): R*wt_cols*16-byte write runs in pass B
   int debug = 0;   // timing experiments only (see DevTiles::debug); results are wrong when non-zero
   int passes = 3;     // bit 0: pass A (diag + up hops), bit 1: pass B (dw hops); timing experiments only
 };
@@ -78,6 +79,7 @@ struct LzEpilogue {
   double* partial = nullptr;    // one partial sum per workgroup of pass A
 };
 int64_t tiled_pass_up_workgroups(const DevSector& s, const TilePlan& plan);
+int64_t tiled_wt_elems(const DevSector& s, const TilePlan& plan);
 
 struct PlanUploader {
   std::function<hipError_t(const std::vector<uint32_t>&, uint32_t**)> u32;

@@ -29,6 +29,7 @@ for cfg in cfgs:
     parts = list(map(int, cfg.split(",")))
     kbA, C, TA, kbB, R, TB, srt = parts[:7]
     padA, padB = (parts[7:9] + [0, 0])[:2] if len(parts) > 7 else (0, 0)
+    sec.set_option("wt_cols", int(os.environ.get("WT_COLS", "4")))
     try:
         sec.set_option("lds_min_kb_up", padA); sec.set_option("lds_min_kb_dw", padB)
         for k, val in (("lds_budget_kb_up", kbA), ("cols_per_tile", C), ("threads_up", TA), ("lds_budget_kb_dw", kbB),
