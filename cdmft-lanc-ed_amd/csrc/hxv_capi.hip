@@ -858,6 +858,34 @@ int hxv_lanczos_eigh(hxv_handle* h, int32_t nitermax, double threshold, double* 
   return HXV_OK;
 }
 
+int hxv_apply_ladder(hxv_handle* from, hxv_handle* to, int32_t orbital, int32_t spin, int32_t create, const void* d_psi, void* d_out,
+                     double* norm2) {
+  if (!from || !to || !d_psi || !d_out) return fail(HXV_ERR_ARG, "hxv_apply_ladder: NULL argument");
+  const SectorHost &a = from->host, &b = to->host;
+  if (a.nranks != 1 || b.nranks != 1) return fail(HXV_ERR_STATE, "hxv_apply_ladder needs nranks==1 (the reference does this step on the master)");
+  if (a.map_up.empty() || b.map_up.empty()) return fail(HXV_ERR_STATE, "hxv_apply_ladder needs handles built from a model (basis maps)");
+  if (from->device != to->device) return fail(HXV_ERR_ARG, "hxv_apply_ladder: handles on different devices");
+  if (a.ns != b.ns || orbital < 0 || orbital >= a.ns || spin < 0 || spin > 1) return fail(HXV_ERR_ARG, "hxv_apply_ladder: bad orbital/spin");
+  const int d = create ? 1 : -1;
+  if (spin == 0 ? (b.nup != a.nup + d || b.ndw != a.ndw) : (b.ndw != a.ndw + d || b.nup != a.nup))
+    return fail(HXV_ERR_ARG, "hxv_apply_ladder: `to` is not the sector reached by this operator");
+  HIPCHK(hipSetDevice(to->device));
+  const uint32_t* mf = spin == 0 ? from->dev.diag.map_up : from->dev.diag.map_dw;
+  const uint32_t* mt = spin == 0 ? to->dev.diag.map_up : to->dev.diag.map_dw;
+  hipError_t e = launch_ladder(mf, spin == 0 ? a.dimup : a.dimdw, mt, spin == 0 ? b.dimup : b.dimdw, a.dimup, b.dimup, b.dimdw, orbital, spin,
+                               create ? 1 : 0, (const double2*)d_psi, (double2*)d_out, to->stream);
+  if (e != hipSuccess) return fail(HXV_ERR_HIP, std::string("ladder kernel: ") + hipGetErrorString(e));
+  if (norm2) {
+    const int64_t n = b.dim;
+    const int g = grid_for(n);
+    hipLaunchKernelGGL(lz_nrm, dim3(g), dim3(256), 0, to->stream, n, (const double2*)d_out, to->d_partials);
+    hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, to->stream, to->d_partials, g, to->d_scalars, 5, 0);
+    HIPCHK(hipMemcpyAsync(norm2, to->d_scalars + 5, sizeof(double), hipMemcpyDeviceToHost, to->stream));
+  }
+  HIPCHK(hipStreamSynchronize(to->stream));
+  return HXV_OK;
+}
+
 int hxv_time_lanczos(hxv_handle* h, void* d_work3, int32_t nrep, float* ms_per_iter) {
   if (!h || !d_work3 || nrep < 1 || !ms_per_iter) return fail(HXV_ERR_ARG, "hxv_time_lanczos: bad argument");
   if (h->host.nranks != 1) return fail(HXV_ERR_STATE, "hxv_time_lanczos needs nranks==1");

@@ -128,4 +128,41 @@ hipError_t launch_hxv_nonlocal(const DevSector& s, const double2* v_full, double
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------
+// c / c^dagger on one orbital of one spin, between two sectors (ED_GF_NORMAL.f90:180-199:
+// vvinit(j) = sgn * state_cvec(i)).  One thread per TARGET element: it looks its source up.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) ladder_kernel(const uint32_t* __restrict__ map_from, int dim_from, const uint32_t* __restrict__ map_to,
+                                                    int dimup_from, int dimup_to, int dimdw_to, int orbital, int spin, int create,
+                                                    const double2* __restrict__ psi, double2* __restrict__ out) {
+  const int64_t n = (int64_t)dimup_to * dimdw_to;
+  const uint32_t bit = 1u << orbital;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(t / dimup_to), i = (int)(t - (int64_t)c * dimup_to);
+    const uint32_t m_to = map_to[spin == 0 ? i : c];
+    double2 r = make_double2(0.0, 0.0);
+    // the target must have the orbital occupied after a creation / empty after a destruction
+    if (((m_to & bit) != 0u) == (create != 0)) {
+      const uint32_t m_from = m_to ^ bit;
+      const int j = rank_in_map(map_from, dim_from, m_from);
+      const double sg = par_below(m_from, orbital) ? -1.0 : 1.0;
+      const double2 x = spin == 0 ? psi[(int64_t)c * dimup_from + j] : psi[(int64_t)j * dimup_from + i];
+      r = make_double2(sg * x.x, sg * x.y);
+    }
+    out[t] = r;
+  }
+}
+
+hipError_t launch_ladder(const uint32_t* map_from, int dim_from, const uint32_t* map_to, int dim_to, int dimup_from, int dimup_to,
+                         int dimdw_to, int orbital, int spin, int create, const double2* psi, double2* out, hipStream_t st) {
+  (void)dim_to;
+  const int64_t n = (int64_t)dimup_to * dimdw_to;
+  if (n == 0) return hipSuccess;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(ladder_kernel, dim3((unsigned)blocks), dim3(256), 0, st, map_from, dim_from, map_to, dimup_from, dimup_to, dimdw_to,
+                     orbital, spin, create, psi, out);
+  return hipGetLastError();
+}
+
 }  // namespace hxv

@@ -231,7 +231,7 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
 // segments of other columns), after the inner sums have been parked in the tile.
 // ---------------------------------------------------------------------------------------
 template <int R, int NP, bool REAL>
-__global__ void __launch_bounds__(1024) hxv_pass_dw(DevSector s, DevTiles t, const double2* __restrict__ v, double2* __restrict__ wt,
+__global__ void __launch_bounds__(1024, 8) hxv_pass_dw(DevSector s, DevTiles t, const double2* __restrict__ v, double2* __restrict__ wt,
                                                       int ngroups, int groups_per_xcd, int wc) {
   // NP = (row,column) pairs of the tile per thread (plan: max_block*R <= NP*blockDim.x); all their global
   // loads are issued before the first use so a workgroup keeps NP requests per lane in flight.
@@ -277,84 +277,90 @@ __global__ void __launch_bounds__(1024) hxv_pass_dw(DevSector s, DevTiles t, con
     }
   }
   __syncthreads();
-  // out-of-block hops, same mapping, right away: the sibling workgroups of this row group are loading exactly
-  // those lines now, so they are as fresh in this XCD's L2 as they will ever be.
-  double2 osum[NP];
-#pragma unroll
-  for (int it = 0; it < NP; ++it) osum[it] = make_double2(0.0, 0.0);
-  if (!(t.debug & 1)) {
-    // block hops: source column slot = start + column offset, one signed coefficient for the whole block
-    for (uint32_t h = t.bh_ptr[kb]; h < t.bh_ptr[kb + 1]; ++h) {
-      const CT cf = lcoef[t.bh[2 * h + 1]];
-      const uint32_t s0 = t.bh[2 * h];
-      double2 x[NP];
-#pragma unroll
-      for (int it = 0; it < NP; ++it) {
-        const int q = min(threadIdx.x + it * T, npairs - 1);
-        x[it] = v[(int64_t)(s0 + q / R) * s.dimup + min(i0 + q % R, s.dimup - 1)];
-      }
-#pragma unroll
-      for (int it = 0; it < NP; ++it) Coef<REAL>::fma(osum[it], cf, x[it]);
-    }
-    // row slots: one table word per column of the block and (block, source block) pair
-    for (uint32_t sl = t.rs_ptr[kb]; sl < t.rs_ptr[kb + 1]; ++sl) {
-      const uint32_t* __restrict__ tab = t.rs_tab + t.rs_off[sl];
-      uint32_t e[NP];
-      bool none = true;
-#pragma unroll
-      for (int it = 0; it < NP; ++it) {
-        e[it] = tab[min((int)threadIdx.x + it * T, npairs - 1) / R];
-        none = none && (e[it] == emptyz);
-      }
-      if (__all(none)) continue;
-      double2 x[NP];
-#pragma unroll
-      for (int it = 0; it < NP; ++it) {
-        const int q = min(threadIdx.x + it * T, npairs - 1);
-        x[it] = v[(int64_t)(e[it] & TILE_OFF_MASK) * s.dimup + min(i0 + q % R, s.dimup - 1)];
-      }
-#pragma unroll
-      for (int it = 0; it < NP; ++it) Coef<REAL>::fma(osum[it], lcoef[e[it] >> TILE_COEF_SHIFT], x[it]);
-    }
-  }
   // in-block hops, one column per thread (plan guarantees n <= blockDim.x)
   const int p = threadIdx.x;
-  double2 acc[R];
-  int col1 = 0;
-  if (p < n) {
-    const uint32_t packed = __builtin_amdgcn_readfirstlane(t.gmax[t.gstart[kb] + (p >> 6)]);
-    const int kin = (t.debug & 2) ? 0 : (int)(packed & 0xFFFFu);
-    col1 = (int)t.perm[cb0 + p] - cb0;
+  {
+    double2 acc[R];
+    int col1 = 0;
+    if (p < n) {
+      const uint32_t packed = __builtin_amdgcn_readfirstlane(t.gmax[t.gstart[kb] + (p >> 6)]);
+      const int kin = (t.debug & 2) ? 0 : (int)(packed & 0xFFFFu);
+      col1 = (int)t.perm[cb0 + p] - cb0;
 #pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = make_double2(0.0, 0.0);
-    for (int k0 = 0; k0 < kin; k0 += HOP_CHUNK) {
-      uint32_t e[HOP_CHUNK];
+      for (int r = 0; r < R; ++r) acc[r] = make_double2(0.0, 0.0);
+      for (int k0 = 0; k0 < kin; k0 += HOP_CHUNK) {
+        uint32_t e[HOP_CHUNK];
 #pragma unroll
-      for (int u = 0; u < HOP_CHUNK; ++u) e[u] = t.ell_in[(int64_t)(k0 + u) * s.dimdw + cb0 + p];
+        for (int u = 0; u < HOP_CHUNK; ++u) e[u] = t.ell_in[(int64_t)(k0 + u) * s.dimdw + cb0 + p];
 #pragma unroll
-      for (int u = 0; u < HOP_CHUNK; ++u) {
-        const CT cf = lcoef[e[u] >> TILE_COEF_SHIFT];
-        const int off = (int)(e[u] & TILE_OFF_MASK);
+        for (int u = 0; u < HOP_CHUNK; ++u) {
+          const CT cf = lcoef[e[u] >> TILE_COEF_SHIFT];
+          const int off = (int)(e[u] & TILE_OFF_MASK);
 #pragma unroll
-        for (int r = 0; r < R; ++r) Coef<REAL>::fma(acc[r], cf, lds[r * ns + off]);
+          for (int r = 0; r < R; ++r) Coef<REAL>::fma(acc[r], cf, lds[r * ns + off]);
+        }
       }
+    }
+    __syncthreads();  // every in-block gather is done: the tile can be overwritten by the sums
+    if (p < n) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) lds[r * ns + col1] = acc[r];
     }
   }
   __syncthreads();
-  if (p < n) {
+  // out-of-block hops: lanes along the contiguous rows again (coalesced R*16-byte segments of other columns, L2 of
+  // this XCD); the sums are added into the tile, each element by the one thread that owns the (row,column) pair.
+  // Pairs are handled HB at a time to bound the registers (two 1024-thread workgroups per CU need <= 64 VGPRs).
+  if (!(t.debug & 1)) {
+    constexpr int HB = NP > 4 ? 4 : NP;
 #pragma unroll
-    for (int r = 0; r < R; ++r) lds[r * ns + col1] = acc[r];
-  }
-  __syncthreads();
-  // add the out-of-block sums (each tile element belongs to exactly one (row,column) pair of one thread)
+    for (int base = 0; base < NP; base += HB) {
+      double2 osum[HB];
 #pragma unroll
-  for (int it = 0; it < NP; ++it) {
-    const int q = threadIdx.x + it * T;
-    if (q < npairs) {
-      double2 a = lds[(q % R) * ns + q / R];
-      a.x += osum[it].x;
-      a.y += osum[it].y;
-      lds[(q % R) * ns + q / R] = a;
+      for (int it = 0; it < HB; ++it) osum[it] = make_double2(0.0, 0.0);
+      // block hops: source column slot = start + column offset, one signed coefficient for the whole block
+      for (uint32_t h = t.bh_ptr[kb]; h < t.bh_ptr[kb + 1]; ++h) {
+        const CT cf = lcoef[t.bh[2 * h + 1]];
+        const uint32_t s0 = t.bh[2 * h];
+        double2 x[HB];
+#pragma unroll
+        for (int it = 0; it < HB; ++it) {
+          const int q = min((int)threadIdx.x + (base + it) * T, npairs - 1);
+          x[it] = v[(int64_t)(s0 + q / R) * s.dimup + min(i0 + q % R, s.dimup - 1)];
+        }
+#pragma unroll
+        for (int it = 0; it < HB; ++it) Coef<REAL>::fma(osum[it], cf, x[it]);
+      }
+      // row slots: one table word per column of the block and (block, source block) pair
+      for (uint32_t sl = t.rs_ptr[kb]; sl < t.rs_ptr[kb + 1]; ++sl) {
+        const uint32_t* __restrict__ tab = t.rs_tab + t.rs_off[sl];
+        uint32_t e[HB];
+        bool none = true;
+#pragma unroll
+        for (int it = 0; it < HB; ++it) {
+          e[it] = tab[min((int)threadIdx.x + (base + it) * T, npairs - 1) / R];
+          none = none && (e[it] == emptyz);
+        }
+        if (__all(none)) continue;
+        double2 x[HB];
+#pragma unroll
+        for (int it = 0; it < HB; ++it) {
+          const int q = min((int)threadIdx.x + (base + it) * T, npairs - 1);
+          x[it] = v[(int64_t)(e[it] & TILE_OFF_MASK) * s.dimup + min(i0 + q % R, s.dimup - 1)];
+        }
+#pragma unroll
+        for (int it = 0; it < HB; ++it) Coef<REAL>::fma(osum[it], lcoef[e[it] >> TILE_COEF_SHIFT], x[it]);
+      }
+#pragma unroll
+      for (int it = 0; it < HB; ++it) {
+        const int q = threadIdx.x + (base + it) * T;
+        if (q < npairs) {
+          double2 a = lds[(q % R) * ns + q / R];
+          a.x += osum[it].x;
+          a.y += osum[it].y;
+          lds[(q % R) * ns + q / R] = a;
+        }
+      }
     }
   }
   __syncthreads();

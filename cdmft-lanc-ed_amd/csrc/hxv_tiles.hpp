@@ -47,9 +47,9 @@ struct SpinTiles {
 
 struct TileOptions {
   int cols_per_tile = 4;      // pass A (up hops): columns per workgroup tile
-  int rows_per_tile = 8;      // pass B (dw hops): rows per workgroup tile
+  int rows_per_tile = 4;      // pass B (dw hops): rows per workgroup tile
   int lds_budget_kb_up = 64;  // LDS per workgroup tile, pass A
-  int lds_budget_kb_dw = 128; // LDS per workgroup tile, pass B
+  int lds_budget_kb_dw = 64;  // LDS per workgroup tile, pass B (two 1024-thread workgroups per CU)
   int force_bits_up = -1, force_bits_dw = -1;
   int threads_up = 1024, threads_dw = 1024;
   int sort_mode = 0;  // pass A visiting order: 0 natural (keeps global accesses coalesced), 1 by inner count, 2 by (outer, inner)

@@ -41,7 +41,7 @@ class _Stats(C.Structure):
 # every symbol include/hxv.h declares (tests check that the library exports all of them)
 EXPORTS = [
     "hxv_create_from_model", "hxv_create_from_csr", "hxv_destroy", "hxv_vecdim", "hxv_dims", "hxv_apply_host",
-    "hxv_apply_device", "hxv_fullvec_elems", "hxv_time_apply", "hxv_lanczos_tridiag", "hxv_lanczos_eigh", "hxv_time_lanczos", "hxv_get_maps",
+    "hxv_apply_device", "hxv_fullvec_elems", "hxv_time_apply", "hxv_lanczos_tridiag", "hxv_lanczos_eigh", "hxv_time_lanczos", "hxv_apply_ladder", "hxv_get_maps",
     "hxv_nnz", "hxv_get_csr", "hxv_get_diag", "hxv_set_option", "hxv_get_option", "hxv_get_stats", "hxv_last_error",
     "hxv_version",
 ]
@@ -78,6 +78,7 @@ def load_library():
     L.hxv_lanczos_tridiag.argtypes = [vp, vp, i32, pd, pd, dbl, pi32]
     L.hxv_lanczos_eigh.argtypes = [vp, i32, dbl, pd, vp, pi32]
     L.hxv_time_lanczos.argtypes = [vp, vp, i32, C.POINTER(C.c_float)]
+    L.hxv_apply_ladder.argtypes = [vp, vp, i32, i32, i32, vp, vp, pd]
     L.hxv_get_maps.argtypes = [vp, pi32, pi32]
     L.hxv_nnz.argtypes = [vp, i32]
     L.hxv_nnz.restype = i64
@@ -233,6 +234,18 @@ class HxvSector:
         _chk(load_library().hxv_lanczos_eigh(self._h, nitermax, threshold, C.byref(e), vec.data_ptr() if want_vector else None,
                                              C.byref(n)), "hxv_lanczos_eigh")
         return e.value, vec, n.value
+
+    def apply_ladder(self, to: "HxvSector", orbital: int, spin: int, create: bool, psi):
+        """c / c^dagger on (orbital, spin) from this sector into `to` (ED_GF_NORMAL.f90:180-199); returns (vector, norm2)."""
+        import torch
+
+        assert psi.is_cuda and psi.dtype == torch.complex128 and psi.numel() == self.Dim
+        out = torch.empty(to.Dim, dtype=torch.complex128, device=psi.device)
+        torch.cuda.synchronize()
+        n2 = C.c_double()
+        _chk(load_library().hxv_apply_ladder(self._h, to._h, orbital, spin, int(bool(create)), psi.data_ptr(), out.data_ptr(), C.byref(n2)),
+             "hxv_apply_ladder")
+        return out, n2.value
 
     def time_lanczos(self, nrep: int) -> float:
         import torch

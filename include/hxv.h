@@ -111,6 +111,16 @@ int hxv_lanczos_eigh(hxv_handle *h, int32_t nitermax, double threshold, double *
 /* Time nrep full Lanczos iterations (HxV + recurrence + 2 reductions) on device. */
 int hxv_time_lanczos(hxv_handle *h, void *d_work3 /* 3*Dim complex */, int32_t nrep, float *ms_per_iter);
 
+/* ---- Green's-function start vectors (ED_GF_NORMAL.f90:174-214: the reference applies c / c^dagger to the
+ * ground state serially on the master and scatters): d_out = c^(dagger)_{orbital,spin} d_psi, from the sector
+ * open in `from` (vector of its Dim) into the sector open in `to` (N_spin +- 1; vector of its Dim), sign =
+ * (-1)^(# occupied orbitals of the SAME spin below `orbital`) (c/cdg, ED_SETUP.f90:807-833; no cross-spin sign,
+ * as in the reference).  orbital is 0-based (= pos-1), spin 0 = up, 1 = dw, create 1 = c^dagger, 0 = c.
+ * *norm2 = <out|out> (the reference normalises by it, ED_GF_NORMAL.f90:197-199).  Both handles from_model,
+ * nranks==1, same device.                                                                                */
+int hxv_apply_ladder(hxv_handle *from, hxv_handle *to, int32_t orbital, int32_t spin, int32_t create, const void *d_psi,
+                     void *d_out, double *norm2);
+
 /* ---- introspection (parity tests against spH0ups/spH0dws/spH0d) ------------------------ */
 int hxv_get_maps(const hxv_handle *h, int32_t *map_up, int32_t *map_dw); /* Hs(1)%map, Hs(2)%map */
 int64_t hxv_nnz(const hxv_handle *h, int32_t which);                      /* 0: H_up, 1: H_dw */
