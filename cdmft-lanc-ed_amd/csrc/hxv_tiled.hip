@@ -33,7 +33,7 @@ struct DevTiles {
   int debug;  // timing experiments only: 1 skip out-of-block hops, 2 skip in-block hops, 4 skip the hv read-modify-write (pass B)
 };
 
-constexpr int HOP_CHUNK = 4;
+constexpr int HOP_CHUNK = 8;
 
 // Non-temporal accesses (debug bit 8 only): measured SLOWER than plain loads/stores for the R*16-byte
 // column segments of pass B (they defeat L2 write combining), see scripts/strided_bench.py.
@@ -109,12 +109,31 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
     for (int r = threadIdx.x; r < n; r += T) lds[cc * n + r] = src[r];
   }
   for (int q = threadIdx.x; q < t.nscoef; q += T) lcoef[q] = Coef<REAL>::from(t.scoef[q]);
-  __syncthreads();
   // one row per thread (plan guarantees n <= blockDim.x)
   const int p = threadIdx.x;
   double2 acc[C];
   double2 xq[LZ ? C : 1];  // the thread's own input elements, kept for the Lanczos epilogue
   int r = 0;
+  // Issued BEFORE the barrier so their latency hides behind the tile load: the dw-hop part that pass B left in the
+  // column-group-blocked scratch wt[group][row][wc] (C*16 contiguous bytes per row, rows consecutive: a plain
+  // streaming read) becomes the initial value of the accumulators; the diagonal's per-row inputs come along.
+  double au = 0.0;
+  uint32_t mu = 0;
+  if (p < n) {
+    if (wt) {
+      const double2* __restrict__ wrow = wt + ((int64_t)(c0 / wc) * s.dimup + r0 + p) * wc + (c0 % wc);
+#pragma unroll
+      for (int cc = 0; cc < C; ++cc) acc[cc] = wrow[min(cc, nc - 1)];
+    } else {
+#pragma unroll
+      for (int cc = 0; cc < C; ++cc) acc[cc] = make_double2(0.0, 0.0);
+    }
+    if (s.diag.mode == 0) {
+      au = s.diag.a_up[r0 + p];
+      mu = s.diag.map_up[r0 + p];
+    }
+  }
+  __syncthreads();
   if (p < n) {
     const uint32_t packed = __builtin_amdgcn_readfirstlane(t.gmax[t.gstart[kb] + (p >> 6)]);
     const int kin = (int)(packed & 0xFFFFu);
@@ -125,20 +144,20 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
     const int i = r0 + p;  // pass A visits the rows in natural order: every global access stays coalesced
     r = p;
     if (s.diag.mode == 0) {
-      const double au = s.diag.a_up[i];
-      const uint32_t mu = s.diag.map_up[i];
 #pragma unroll
       for (int cc = 0; cc < C; ++cc) {
         const double d = diag_value<NORB1>(s.diag, au, mu, s.dw0 + min(c0 + cc, s.qdw - 1));
         const double2 x = lds[cc * n + r];
-        acc[cc] = make_double2(d * x.x, d * x.y);
+        acc[cc].x = fma(d, x.x, acc[cc].x);
+        acc[cc].y = fma(d, x.y, acc[cc].y);
       }
     } else {
 #pragma unroll
       for (int cc = 0; cc < C; ++cc) {
         const double d = s.diag.stored[(int64_t)min(c0 + cc, s.qdw - 1) * s.dimup + i];
         const double2 x = lds[cc * n + r];
-        acc[cc] = make_double2(d * x.x, d * x.y);
+        acc[cc].x = fma(d, x.x, acc[cc].x);
+        acc[cc].y = fma(d, x.y, acc[cc].y);
       }
     }
     // hops that leave the block, same columns, other rows: from global memory (L2 of this XCD)
@@ -168,31 +187,26 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
       for (int u = 0; u < HOP_CHUNK; ++u) e[u] = t.ell_in[(int64_t)(k0 + u) * s.dimup + r0 + p];
 #pragma unroll
       for (int u = 0; u < HOP_CHUNK; ++u) {
-        const CT cf = lcoef[e[u] >> TILE_COEF_SHIFT];
-        const int off = (int)(e[u] & TILE_OFF_MASK);
+        if (k0 + u < kin) {  // wave-uniform: all 8 words are loaded at once, only the live slots are computed
+          const CT cf = lcoef[e[u] >> TILE_COEF_SHIFT];
+          const int off = (int)(e[u] & TILE_OFF_MASK);
 #pragma unroll
-        for (int cc = 0; cc < C; ++cc) Coef<REAL>::fma(acc[cc], cf, lds[cc * n + off]);
+          for (int cc = 0; cc < C; ++cc) Coef<REAL>::fma(acc[cc], cf, lds[cc * n + off]);
+        }
       }
     }
   }
-  // Epilogue, same thread <-> row mapping: add the dw-hop part that pass B left in the column-group-blocked
-  // scratch wt[group][row][C] (C*16 contiguous bytes per row, rows consecutive: a plain streaming read), then
-  // store hv with lanes along the rows.  With LZ: w = s*(H x) - c*xm and the partial sums of Re(conj(s*x) w).
+  // Epilogue, same thread <-> row mapping: store hv with lanes along the rows.
+  // With LZ: w = s*(H x) - c*xm and the partial sums of Re(conj(s*x) w).
   double asum = 0.0;
   if (p < n) {
     const double sc = LZ ? lz.scal[lz.i_s] : 1.0;
     const double cm = (LZ && lz.xm) ? lz.scal[lz.i_c] : 0.0;
-    const double2* __restrict__ wrow = wt ? wt + ((int64_t)(c0 / wc) * s.dimup + r0 + p) * wc + (c0 % wc) : nullptr;
 #pragma unroll
     for (int cc = 0; cc < C; ++cc) {
       if (cc < nc) {
         const int64_t o = (int64_t)(c0 + cc) * s.dimup + r0 + p;
         double2 w = acc[cc];
-        if (wt) {
-          const double2 wd = wrow[cc];  // plain load: the non-temporal form measured 8 % slower on the whole product
-          w.x += wd.x;
-          w.y += wd.y;
-        }
         if (LZ) {
           w.x *= sc;
           w.y *= sc;
@@ -294,10 +308,12 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_dw(DevSector s, DevTiles t, 
         for (int u = 0; u < HOP_CHUNK; ++u) e[u] = t.ell_in[(int64_t)(k0 + u) * s.dimdw + cb0 + p];
 #pragma unroll
         for (int u = 0; u < HOP_CHUNK; ++u) {
-          const CT cf = lcoef[e[u] >> TILE_COEF_SHIFT];
-          const int off = (int)(e[u] & TILE_OFF_MASK);
+          if (k0 + u < kin) {  // wave-uniform
+            const CT cf = lcoef[e[u] >> TILE_COEF_SHIFT];
+            const int off = (int)(e[u] & TILE_OFF_MASK);
 #pragma unroll
-          for (int r = 0; r < R; ++r) Coef<REAL>::fma(acc[r], cf, lds[r * ns + off]);
+            for (int r = 0; r < R; ++r) Coef<REAL>::fma(acc[r], cf, lds[r * ns + off]);
+          }
         }
       }
     }
