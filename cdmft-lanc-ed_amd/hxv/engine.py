@@ -13,7 +13,7 @@ from pathlib import Path
 import numpy as np
 
 _PKG = Path(__file__).resolve().parent.parent
-LIB_PATH = _PKG / "lib" / "libhxv.so"
+LIB_PATH = Path(os.environ.get("HXV_LIB", str(_PKG / "lib" / "libhxv.so")))  # HXV_LIB: A/B experiments only
 
 
 class HxvError(RuntimeError):
