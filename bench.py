@@ -104,11 +104,11 @@ def main():
         model, (nup, ndw) = models.hm_ring(6, 2), (9, 9)
 
     sec = hxv.HxvSector.from_model(model, nup, ndw, rank=rank, nranks=world, device=local_rank)
-    Dim, Nloc = sec.Dim, sec.vecDim
+    Dim, Nloc = sec.Dim, sec.localElems   # Nloc: local vector length in the padded device layout (include/hxv.h)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     v_local = torch.randn(Nloc, dtype=torch.float64, device=dev, generator=g) + 1j * torch.randn(Nloc, dtype=torch.float64, device=dev, generator=g)
     hv_local = torch.empty(Nloc, dtype=torch.complex128, device=dev)
-    sh = hxv.ShardedHxv(sec.DimUp, sec.DimDw, rank, world, sec.apply_device)
+    sh = hxv.ShardedHxv(sec.DimUp, sec.DimDw, rank, world, sec.apply_device, pitch=sec.pitch)
 
     def step():
         sh(Nloc, v_local, hv_local)
@@ -118,9 +118,9 @@ def main():
         step()
         full_sec = hxv.HxvSector.from_model(model, nup, ndw, device=local_rank)
         vg = sh.unpad(sh.gather(v_local)).contiguous()
-        ref = full_sec.apply_device(vg)[sec.mpiIshift: sec.mpiIshift + Nloc]
+        ref = full_sec.apply_device(vg)[sec.mpiIshift: sec.mpiIshift + sec.vecDim]
         torch.cuda.synchronize()
-        err = (ref - hv_local).abs().max().item() / ref.abs().max().item()
+        err = (ref - sec.unpad(hv_local)).abs().max().item() / ref.abs().max().item()
         print(f"[rank {rank}] sharded vs unsharded slab: rel err {err:.2e}", flush=True)
         assert err < 1e-13
         full_sec.close()
@@ -148,7 +148,7 @@ def main():
     vfull = sh.gather(v_local)
     torch.cuda.synchronize()
     k_ms = sec.time_apply(vfull, hv_local, max(5, min(args.steps, 20)))
-    achieved = 32.0 * Nloc / (k_ms * 1e-3) / 1e9
+    achieved = 32.0 * sec.vecDim / (k_ms * 1e-3) / 1e9
     traffic = None
     tf = ROOT / "profiles" / "traffic.json"
     if tf.exists():
@@ -160,7 +160,7 @@ def main():
             traffic = None
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "kernel": "hxv_pass_up + hxv_pass_dw (one product)", "kernel_ms": round(k_ms, 4),
-                "algorithmic_bytes": 32 * Nloc}
+                "algorithmic_bytes": 32 * sec.vecDim}
 
     out = {"metric": "sector-HxV achieved HBM GB/s (algorithmic 32 B x Dim per product), Ns=16 half-filled sector", "value": round(value, 1),
            "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),

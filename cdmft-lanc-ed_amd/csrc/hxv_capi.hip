@@ -148,6 +148,7 @@ int finish_create(hxv_handle* h, int device, hxv_handle** out) {
   d.diag.cross = s.cross;
   d.dimup = s.dimup;
   d.dimdw = s.dimdw;
+  d.pitch = s.pitch;
   d.qdw = s.qdw;
   d.dw0 = s.dw0;
   d.slab0 = s.rank * s.cmax;
@@ -222,7 +223,9 @@ int hxv_destroy(hxv_handle* h) {
 }
 
 int64_t hxv_vecdim(const hxv_handle* h) { return h ? (int64_t)h->host.qdw * h->host.dimup : -1; }
-int64_t hxv_fullvec_elems(const hxv_handle* h) { return h ? (int64_t)h->host.nranks * h->host.cmax * h->host.dimup : -1; }
+int64_t hxv_fullvec_elems(const hxv_handle* h) { return h ? (int64_t)h->host.nranks * h->host.cmax * h->host.pitch : -1; }
+int64_t hxv_localvec_elems(const hxv_handle* h) { return h ? (int64_t)h->host.qdw * h->host.pitch : -1; }
+int32_t hxv_pitch(const hxv_handle* h) { return h ? h->host.pitch : -1; }
 
 int hxv_dims(const hxv_handle* h, int32_t* dimup, int32_t* dimdw, int64_t* dim, int32_t* qdw, int64_t* ishift) {
   if (!h) return fail(HXV_ERR_ARG, "NULL handle");
@@ -257,16 +260,20 @@ int hxv_apply_host(hxv_handle* h, int64_t nloc, const void* v, void* hv) {
     return fail(HXV_ERR_STATE, "hxv_apply_host needs nranks==1; a split sector exchanges slabs first (hxv_apply_device)");
   if (nloc != h->host.dim) return fail(HXV_ERR_ARG, "hxv_apply_host: Nloc != Dim of the open sector");
   HIPCHK(hipSetDevice(h->device));
-  size_t bytes = (size_t)nloc * sizeof(double2);
+  // host arrays are in the reference's contiguous layout; the device layout pads every column to `pitch`
+  const size_t col = (size_t)h->host.dimup * sizeof(double2), pit = (size_t)h->host.pitch * sizeof(double2);
+  const size_t bytes = pit * (size_t)h->host.dimdw;
   if (!h->d_stage_v) {
     HIPCHK(hipMalloc((void**)&h->d_stage_v, bytes));
     HIPCHK(hipMalloc((void**)&h->d_stage_hv, bytes));
+    HIPCHK(hipMemset(h->d_stage_v, 0, bytes));
+    HIPCHK(hipMemset(h->d_stage_hv, 0, bytes));
     h->device_bytes += 2 * (int64_t)bytes;
   }
-  HIPCHK(hipMemcpyAsync(h->d_stage_v, v, bytes, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpy2DAsync(h->d_stage_v, pit, v, col, col, (size_t)h->host.dimdw, hipMemcpyHostToDevice, h->stream));
   int rc = hxv_apply_device(h, h->d_stage_v, h->d_stage_hv, h->stream);
   if (rc) return rc;
-  HIPCHK(hipMemcpyAsync(hv, h->d_stage_hv, bytes, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpy2DAsync(hv, col, h->d_stage_hv, pit, col, (size_t)h->host.dimdw, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return HXV_OK;
 }
@@ -429,7 +436,7 @@ extern "C" int hxv_debug_strided_read(hxv_handle* h, const void* d_v, void* d_ou
   (void)hipSetDevice(h->device);
   (void)hipEventRecord(h->ev0, h->stream);
   for (int i = 0; i < nrep; ++i)
-    if (launch_strided_read((const double2*)d_v, (double2*)d_out, h->host.dimup, h->host.dimdw, R, n, mode, h->stream) != hipSuccess) return 2;
+    if (launch_strided_read((const double2*)d_v, (double2*)d_out, h->host.pitch, h->host.dimdw, R, n, mode, h->stream) != hipSuccess) return 2;
   (void)hipEventRecord(h->ev1, h->stream);
   (void)hipEventSynchronize(h->ev1);
   float t = 0;
@@ -542,9 +549,15 @@ __global__ void __launch_bounds__(256) lz_axpy(int64_t n, double2* __restrict__ 
 }
 
 // deterministic start vector: splitmix64 hash of the global index -> uniform(-0.5,0.5) re and im
-__global__ void __launch_bounds__(256) lz_init(int64_t n, double2* __restrict__ q, uint64_t seed) {
+__global__ void __launch_bounds__(256) lz_init(int64_t n, double2* __restrict__ q, uint64_t seed, int dimup, int pitch) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    uint64_t z = (uint64_t)i * 2 + seed;
+    const int64_t col = i / pitch;
+    const int row = (int)(i - col * pitch);
+    if (row >= dimup) {  // pad rows stay zero: they must not enter the dot products
+      q[i] = make_double2(0.0, 0.0);
+      continue;
+    }
+    uint64_t z = (uint64_t)(col * dimup + row) * 2 + seed;
     double r[2];
     for (int k = 0; k < 2; ++k) {
       uint64_t x = z + (uint64_t)k + 0x9E3779B97F4A7C15ull;
@@ -648,7 +661,7 @@ struct LzRunner {
   }
 
   int step(double* alpha, double* beta) {
-    const int64_t n = h->host.dim;
+    const int64_t n = (int64_t)h->host.pitch * h->host.dimdw;
     const int g = grid_for(n);
     if (!fused) {
       int rc = hxv_apply_device(h, b.q, b.w, h->stream);
@@ -694,7 +707,7 @@ struct LzRunner {
 
   // rotate to the next Lanczos vector (needs the beta returned by step())
   int advance() {
-    const int64_t n = h->host.dim;
+    const int64_t n = (int64_t)h->host.pitch * h->host.dimdw;
     if (!fused) {
       HIPCHK(hipMemcpyAsync(h->d_scalars + 2, h->d_scalars + 1, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
       std::swap(b.q, b.qm);
@@ -722,8 +735,10 @@ int ensure_lz(hxv_handle* h) {
   HIPCHK(hipSetDevice(h->device));
   for (auto& p : h->d_lz)
     if (!p) {
-      HIPCHK(hipMalloc((void**)&p, (size_t)h->host.dim * sizeof(double2)));
-      h->device_bytes += h->host.dim * (int64_t)sizeof(double2);
+      const size_t bytes = (size_t)h->host.pitch * h->host.dimdw * sizeof(double2);
+      HIPCHK(hipMalloc((void**)&p, bytes));
+      HIPCHK(hipMemset(p, 0, bytes));
+      h->device_bytes += (int64_t)bytes;
     }
   return HXV_OK;
 }
@@ -737,7 +752,7 @@ int hxv_lanczos_tridiag(hxv_handle* h, const void* d_vin, int32_t nlanc, double*
   if (!h || !d_vin || nlanc < 1 || !alanc || !blanc) return fail(HXV_ERR_ARG, "hxv_lanczos_tridiag: bad argument");
   int rc = ensure_lz(h);
   if (rc) return rc;
-  const int64_t n = h->host.dim;
+  const int64_t n = (int64_t)h->host.pitch * h->host.dimdw;
   LzRunner lz(h, h->d_lz[0], h->d_lz[1], h->d_lz[2]);
   HIPCHK(hipMemcpyAsync(lz.b.q, d_vin, (size_t)n * sizeof(double2), hipMemcpyDeviceToDevice, h->stream));
   rc = lz.begin(1.0);  // vin is normalised by the caller (ED_GF_NORMAL.f90:197-199)
@@ -771,13 +786,13 @@ int hxv_lanczos_eigh(hxv_handle* h, int32_t nitermax, double threshold, double* 
   if (!h || nitermax < 1 || !egs) return fail(HXV_ERR_ARG, "hxv_lanczos_eigh: bad argument");
   int rc = ensure_lz(h);
   if (rc) return rc;
-  const int64_t n = h->host.dim;
+  const int64_t n = (int64_t)h->host.pitch * h->host.dimdw;
   const int g = grid_for(n);
-  const int nmax = (int)std::min<int64_t>(nitermax, n);
+  const int nmax = (int)std::min<int64_t>(nitermax, h->host.dim);
   const uint64_t seed = 0x5EED5EEDull;
   // deterministic start vector, normalised
   auto start = [&](LzRunner& lz) -> int {
-    hipLaunchKernelGGL(lz_init, dim3(g), dim3(256), 0, h->stream, n, lz.b.w, seed);
+    hipLaunchKernelGGL(lz_init, dim3(g), dim3(256), 0, h->stream, n, lz.b.w, seed, h->host.dimup, h->host.pitch);
     HIPCHK(hipMemsetAsync(h->d_scalars, 0, 8 * sizeof(double), h->stream));
     hipLaunchKernelGGL(lz_nrm, dim3(g), dim3(256), 0, h->stream, n, lz.b.w, h->d_partials + RED_BLOCKS);
     hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_partials + RED_BLOCKS, g, h->d_scalars, 1, 1);
@@ -870,13 +885,14 @@ int hxv_apply_ladder(hxv_handle* from, hxv_handle* to, int32_t orbital, int32_t 
   if (spin == 0 ? (b.nup != a.nup + d || b.ndw != a.ndw) : (b.ndw != a.ndw + d || b.nup != a.nup))
     return fail(HXV_ERR_ARG, "hxv_apply_ladder: `to` is not the sector reached by this operator");
   HIPCHK(hipSetDevice(to->device));
+  HIPCHK(hipMemsetAsync(d_out, 0, (size_t)b.pitch * b.dimdw * sizeof(double2), to->stream));  // pad rows = 0
   const uint32_t* mf = spin == 0 ? from->dev.diag.map_up : from->dev.diag.map_dw;
   const uint32_t* mt = spin == 0 ? to->dev.diag.map_up : to->dev.diag.map_dw;
-  hipError_t e = launch_ladder(mf, spin == 0 ? a.dimup : a.dimdw, mt, spin == 0 ? b.dimup : b.dimdw, a.dimup, b.dimup, b.dimdw, orbital, spin,
-                               create ? 1 : 0, (const double2*)d_psi, (double2*)d_out, to->stream);
+  hipError_t e = launch_ladder(mf, spin == 0 ? a.dimup : a.dimdw, mt, spin == 0 ? b.dimup : b.dimdw, a.pitch, b.dimup, b.pitch, b.dimdw,
+                               orbital, spin, create ? 1 : 0, (const double2*)d_psi, (double2*)d_out, to->stream);
   if (e != hipSuccess) return fail(HXV_ERR_HIP, std::string("ladder kernel: ") + hipGetErrorString(e));
   if (norm2) {
-    const int64_t n = b.dim;
+    const int64_t n = (int64_t)b.pitch * b.dimdw;  // pads of d_out must be zero (hxv.h)
     const int g = grid_for(n);
     hipLaunchKernelGGL(lz_nrm, dim3(g), dim3(256), 0, to->stream, n, (const double2*)d_out, to->d_partials);
     hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, to->stream, to->d_partials, g, to->d_scalars, 5, 0);
@@ -890,10 +906,11 @@ int hxv_time_lanczos(hxv_handle* h, void* d_work3, int32_t nrep, float* ms_per_i
   if (!h || !d_work3 || nrep < 1 || !ms_per_iter) return fail(HXV_ERR_ARG, "hxv_time_lanczos: bad argument");
   if (h->host.nranks != 1) return fail(HXV_ERR_STATE, "hxv_time_lanczos needs nranks==1");
   HIPCHK(hipSetDevice(h->device));
-  const int64_t n = h->host.dim;
+  const int64_t n = (int64_t)h->host.pitch * h->host.dimdw;
+  HIPCHK(hipMemsetAsync(d_work3, 0, (size_t)3 * n * sizeof(double2), h->stream));
   LzRunner lz(h, (double2*)d_work3, (double2*)d_work3 + n, (double2*)d_work3 + 2 * n);
   const int g = grid_for(n);
-  hipLaunchKernelGGL(lz_init, dim3(g), dim3(256), 0, h->stream, n, lz.b.w, 0x1234ull);
+  hipLaunchKernelGGL(lz_init, dim3(g), dim3(256), 0, h->stream, n, lz.b.w, 0x1234ull, h->host.dimup, h->host.pitch);
   HIPCHK(hipMemsetAsync(h->d_scalars, 0, 8 * sizeof(double), h->stream));
   hipLaunchKernelGGL(lz_nrm, dim3(g), dim3(256), 0, h->stream, n, lz.b.w, h->d_partials + RED_BLOCKS);
   hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_partials + RED_BLOCKS, g, h->d_scalars, 1, 1);

@@ -56,6 +56,7 @@ struct NonLocalParams {
 struct SectorHost {
   int ns = 0, nup = 0, ndw = 0;
   int dimup = 0, dimdw = 0;
+  int pitch = 0;                    // device column pitch: DimUp rounded up to 8 elements (128-byte lines)
   int64_t dim = 0;
   int rank = 0, nranks = 1, qdw = 0, dw0 = 0;
   int cmax = 0;                     // columns per rank in the padded all-gather layout
@@ -105,6 +106,7 @@ struct DevSector {
   DevSpin up, dw;
   DevDiag diag;
   int dimup, dimdw;
+  int pitch;              // elements between column starts of v / hv on the device (>= dimup, multiple of 8)
   int qdw, dw0;           // local columns [dw0, dw0+qdw)
   int slab0;              // column slot of local column 0 in the padded all-gather layout (= rank*cmax)
   const uint32_t* vcol;   // [dimdw] column -> column slot (identity when nranks==1)
@@ -116,8 +118,8 @@ struct DevSector {
 // kernel launchers (hxv_kernels.hip)
 struct TilePlan;  // opaque tiling data for the two-pass kernels
 hipError_t launch_hxv_naive(const DevSector& s, const double2* v_full, double2* hv_local, hipStream_t st);
-hipError_t launch_ladder(const uint32_t* map_from, int dim_from, const uint32_t* map_to, int dim_to, int dimup_from, int dimup_to,
-                         int dimdw_to, int orbital, int spin, int create, const double2* psi, double2* out, hipStream_t st);
+hipError_t launch_ladder(const uint32_t* map_from, int dim_from, const uint32_t* map_to, int dim_to, int pitch_from, int dimup_to,
+                         int pitch_to, int dimdw_to, int orbital, int spin, int create, const double2* psi, double2* out, hipStream_t st);
 hipError_t launch_hxv_nonlocal(const DevSector& s, const double2* v_full, double2* hv_local, hipStream_t st);
 
 }  // namespace hxv

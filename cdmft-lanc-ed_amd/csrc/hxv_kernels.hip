@@ -21,7 +21,7 @@ __global__ void __launch_bounds__(256) hxv_naive_kernel(DevSector s, const doubl
     const int cl = (int)(t / s.dimup);
     const int i = (int)(t - (int64_t)cl * s.dimup);
     const int c = cl + s.dw0;
-    const double2* __restrict__ vcol = v + (int64_t)(s.slab0 + cl) * s.dimup;
+    const double2* __restrict__ vcol = v + (int64_t)(s.slab0 + cl) * s.pitch;
     const double d = diag_at(s.diag, i, c, t);
     const double2 x = vcol[i];
     double2 acc = make_double2(d * x.x, d * x.y);
@@ -33,9 +33,9 @@ __global__ void __launch_bounds__(256) hxv_naive_kernel(DevSector s, const doubl
     for (int k = 0; k < s.dw.K; ++k) {
       const uint32_t e = s.dw.ell[(int64_t)k * s.dw.dim + c];
       if (e == ELL_EMPTY) break;
-      cfma(acc, ell_coef(s.dw.coef, e), v[(int64_t)(e & ELL_SRC_MASK) * s.dimup + i]);
+      cfma(acc, ell_coef(s.dw.coef, e), v[(int64_t)(e & ELL_SRC_MASK) * s.pitch + i]);
     }
-    hv[t] = acc;
+    hv[(int64_t)cl * s.pitch + i] = acc;
   }
 }
 
@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(256) hxv_nonlocal_kernel(DevSector s, const do
             const uint32_t k3 = mu & ~(1u << js), k4 = k3 | (1u << is);
             const int sg = par_below(md, is) ^ par_below(k1, js) ^ par_below(mu, js) ^ par_below(k3, is);
             const int jdw = rank_in_map(map_dw, s.dimdw, k2), jup = rank_in_map(map_up, s.dimup, k4);
-            const double2 x = v[(int64_t)s.vcol[jdw] * s.dimup + jup];
+            const double2 x = v[(int64_t)s.vcol[jdw] * s.pitch + jup];
             const double c = sg ? -s.nd.jx : s.nd.jx;
             acc.x += c * x.x;
             acc.y += c * x.y;
@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(256) hxv_nonlocal_kernel(DevSector s, const do
             const uint32_t k3 = mu & ~(1u << js), k4 = k3 | (1u << is);
             const int sg = par_below(md, js) ^ par_below(k1, is) ^ par_below(mu, js) ^ par_below(k3, is);
             const int jdw = rank_in_map(map_dw, s.dimdw, k2), jup = rank_in_map(map_up, s.dimup, k4);
-            const double2 x = v[(int64_t)s.vcol[jdw] * s.dimup + jup];
+            const double2 x = v[(int64_t)s.vcol[jdw] * s.pitch + jup];
             const double c = sg ? -s.nd.jp : s.nd.jp;
             acc.x += c * x.x;
             acc.y += c * x.y;
@@ -111,10 +111,11 @@ __global__ void __launch_bounds__(256) hxv_nonlocal_kernel(DevSector s, const do
           }
         }
     if (any) {
-      double2 h = hv[t];
+      const int64_t o = (int64_t)cl * s.pitch + i;
+      double2 h = hv[o];
       h.x += acc.x;
       h.y += acc.y;
-      hv[t] = h;
+      hv[o] = h;
     }
   }
 }
@@ -133,7 +134,7 @@ hipError_t launch_hxv_nonlocal(const DevSector& s, const double2* v_full, double
 // vvinit(j) = sgn * state_cvec(i)).  One thread per TARGET element: it looks its source up.
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) ladder_kernel(const uint32_t* __restrict__ map_from, int dim_from, const uint32_t* __restrict__ map_to,
-                                                    int dimup_from, int dimup_to, int dimdw_to, int orbital, int spin, int create,
+                                                    int pitch_from, int dimup_to, int pitch_to, int dimdw_to, int orbital, int spin, int create,
                                                     const double2* __restrict__ psi, double2* __restrict__ out) {
   const int64_t n = (int64_t)dimup_to * dimdw_to;
   const uint32_t bit = 1u << orbital;
@@ -146,22 +147,22 @@ __global__ void __launch_bounds__(256) ladder_kernel(const uint32_t* __restrict_
       const uint32_t m_from = m_to ^ bit;
       const int j = rank_in_map(map_from, dim_from, m_from);
       const double sg = par_below(m_from, orbital) ? -1.0 : 1.0;
-      const double2 x = spin == 0 ? psi[(int64_t)c * dimup_from + j] : psi[(int64_t)j * dimup_from + i];
+      const double2 x = spin == 0 ? psi[(int64_t)c * pitch_from + j] : psi[(int64_t)j * pitch_from + i];
       r = make_double2(sg * x.x, sg * x.y);
     }
-    out[t] = r;
+    out[(int64_t)c * pitch_to + i] = r;
   }
 }
 
-hipError_t launch_ladder(const uint32_t* map_from, int dim_from, const uint32_t* map_to, int dim_to, int dimup_from, int dimup_to,
-                         int dimdw_to, int orbital, int spin, int create, const double2* psi, double2* out, hipStream_t st) {
+hipError_t launch_ladder(const uint32_t* map_from, int dim_from, const uint32_t* map_to, int dim_to, int pitch_from, int dimup_to,
+                         int pitch_to, int dimdw_to, int orbital, int spin, int create, const double2* psi, double2* out, hipStream_t st) {
   (void)dim_to;
   const int64_t n = (int64_t)dimup_to * dimdw_to;
   if (n == 0) return hipSuccess;
   int64_t blocks = (n + 255) / 256;
   if (blocks > 256 * 32) blocks = 256 * 32;
-  hipLaunchKernelGGL(ladder_kernel, dim3((unsigned)blocks), dim3(256), 0, st, map_from, dim_from, map_to, dimup_from, dimup_to, dimdw_to,
-                     orbital, spin, create, psi, out);
+  hipLaunchKernelGGL(ladder_kernel, dim3((unsigned)blocks), dim3(256), 0, st, map_from, dim_from, map_to, pitch_from, dimup_to, pitch_to,
+                     dimdw_to, orbital, spin, create, psi, out);
   return hipGetLastError();
 }
 

@@ -169,6 +169,7 @@ void dw_split(int dimdw, int rank, int nranks, int& qdw, int& dw0) {
 // ceil(DimDw/nranks) column slots, so rank r's slab starts at slot r*cmax; ranks that own one
 // column less (ED_HAMILTONIAN.f90:93-98) leave their last slot unused.
 void make_vcol(SectorHost& s) {
+  s.pitch = (s.dimup + 7) & ~7;
   s.cmax = (s.dimdw + s.nranks - 1) / s.nranks;
   s.vcol.resize(s.dimdw);
   for (int r = 0; r < s.nranks; ++r) {

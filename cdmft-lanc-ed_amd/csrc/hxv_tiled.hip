@@ -102,10 +102,10 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
   const int c0 = g * C;  // local column
   const int nc = min(C, s.qdw - c0);
   CT* lcoef = reinterpret_cast<CT*>(lds + C * n);
-  const double2* __restrict__ vcol0 = v + (int64_t)(s.slab0 + c0) * s.dimup;
+  const double2* __restrict__ vcol0 = v + (int64_t)(s.slab0 + c0) * s.pitch;
 #pragma unroll
   for (int cc = 0; cc < C; ++cc) {
-    const double2* __restrict__ src = vcol0 + (int64_t)min(cc, nc - 1) * s.dimup + r0;
+    const double2* __restrict__ src = vcol0 + (int64_t)min(cc, nc - 1) * s.pitch + r0;
     for (int r = threadIdx.x; r < n; r += T) lds[cc * n + r] = src[r];
   }
   for (int q = threadIdx.x; q < t.nscoef; q += T) lcoef[q] = Coef<REAL>::from(t.scoef[q]);
@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
         const CT cf = lcoef[t.bh[2 * h + 1]];
         const double2* __restrict__ src = vcol0 + t.bh[2 * h] + r;
 #pragma unroll
-        for (int cc = 0; cc < C; ++cc) Coef<REAL>::fma(acc[cc], cf, src[(int64_t)min(cc, nc - 1) * s.dimup]);
+        for (int cc = 0; cc < C; ++cc) Coef<REAL>::fma(acc[cc], cf, src[(int64_t)min(cc, nc - 1) * s.pitch]);
       }
       // row slots: one table word per row and (block, source block) pair
       const uint32_t emptyz = (uint32_t)(t.nscoef - 1) << TILE_COEF_SHIFT;
@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
         const CT cf = lcoef[e >> TILE_COEF_SHIFT];
         const double2* __restrict__ src = vcol0 + (e & TILE_OFF_MASK);
 #pragma unroll
-        for (int cc = 0; cc < C; ++cc) Coef<REAL>::fma(acc[cc], cf, src[(int64_t)min(cc, nc - 1) * s.dimup]);
+        for (int cc = 0; cc < C; ++cc) Coef<REAL>::fma(acc[cc], cf, src[(int64_t)min(cc, nc - 1) * s.pitch]);
       }
     }
     // hops inside the block: gathers from the LDS tile
@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
 #pragma unroll
     for (int cc = 0; cc < C; ++cc) {
       if (cc < nc) {
-        const int64_t o = (int64_t)(c0 + cc) * s.dimup + r0 + p;
+        const int64_t o = (int64_t)(c0 + cc) * s.pitch + r0 + p;
         double2 w = acc[cc];
         if (LZ) {
           w.x *= sc;
@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_dw(DevSector s, DevTiles t, 
 #pragma unroll
     for (int it = 0; it < NP; ++it) {
       const int q = min(threadIdx.x + it * T, npairs - 1);
-      x[it] = v[(int64_t)slot[it] * s.dimup + min(i0 + q % R, s.dimup - 1)];
+      x[it] = v[(int64_t)slot[it] * s.pitch + min(i0 + q % R, s.dimup - 1)];
     }
 #pragma unroll
     for (int it = 0; it < NP; ++it) {
@@ -342,7 +342,7 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_dw(DevSector s, DevTiles t, 
 #pragma unroll
         for (int it = 0; it < HB; ++it) {
           const int q = min((int)threadIdx.x + (base + it) * T, npairs - 1);
-          x[it] = v[(int64_t)(s0 + q / R) * s.dimup + min(i0 + q % R, s.dimup - 1)];
+          x[it] = v[(int64_t)(s0 + q / R) * s.pitch + min(i0 + q % R, s.dimup - 1)];
         }
 #pragma unroll
         for (int it = 0; it < HB; ++it) Coef<REAL>::fma(osum[it], cf, x[it]);
@@ -362,7 +362,7 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_dw(DevSector s, DevTiles t, 
 #pragma unroll
         for (int it = 0; it < HB; ++it) {
           const int q = min((int)threadIdx.x + (base + it) * T, npairs - 1);
-          x[it] = v[(int64_t)(e[it] & TILE_OFF_MASK) * s.dimup + min(i0 + q % R, s.dimup - 1)];
+          x[it] = v[(int64_t)(e[it] & TILE_OFF_MASK) * s.pitch + min(i0 + q % R, s.dimup - 1)];
         }
 #pragma unroll
         for (int it = 0; it < HB; ++it) Coef<REAL>::fma(osum[it], lcoef[e[it] >> TILE_COEF_SHIFT], x[it]);

@@ -29,15 +29,17 @@ class ShardedHxv:
     (HxvSector.apply_device on the GPU box; CPU tests inject a stand-in to exercise the exchange
     with gloo)."""
 
-    def __init__(self, DimUp: int, DimDw: int, rank: int, size: int, apply_local, group=None):
+    def __init__(self, DimUp: int, DimDw: int, rank: int, size: int, apply_local, group=None, pitch: int | None = None):
+        """pitch = device column pitch (HxvSector.pitch); vectors are [columns x pitch] (default: DimUp, unpadded)."""
         import torch.distributed as dist
 
         self.dist = dist
         self.DimUp, self.DimDw, self.rank, self.size, self.group = DimUp, DimDw, rank, size, group
+        self.pitch = DimUp if pitch is None else pitch
         self.qdw, self.dw0 = dw_split(DimDw, rank, size)
         self.cmax = -(-DimDw // size)
-        self.Nloc = self.qdw * DimUp
-        self.slab = self.cmax * DimUp            # elements every rank contributes
+        self.Nloc = self.qdw * self.pitch        # local vector length in the device layout
+        self.slab = self.cmax * self.pitch       # elements every rank contributes
         self.apply_local = apply_local
         self._vfull = None
         self._send = None
@@ -69,7 +71,8 @@ class ShardedHxv:
         parts = []
         for r in range(self.size):
             q, _ = dw_split(self.DimDw, r, self.size)
-            parts.append(v_gathered[r * self.slab: r * self.slab + q * self.DimUp])
+            part = v_gathered[r * self.slab: r * self.slab + q * self.pitch]
+            parts.append(part.view(q, self.pitch)[:, : self.DimUp].reshape(-1))
         return torch.cat(parts)
 
     def __call__(self, Nloc: int, v_local, hv_local):

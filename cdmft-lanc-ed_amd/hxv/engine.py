@@ -41,7 +41,7 @@ class _Stats(C.Structure):
 # every symbol include/hxv.h declares (tests check that the library exports all of them)
 EXPORTS = [
     "hxv_create_from_model", "hxv_create_from_csr", "hxv_destroy", "hxv_vecdim", "hxv_dims", "hxv_apply_host",
-    "hxv_apply_device", "hxv_fullvec_elems", "hxv_time_apply", "hxv_lanczos_tridiag", "hxv_lanczos_eigh", "hxv_time_lanczos", "hxv_apply_ladder", "hxv_get_maps",
+    "hxv_apply_device", "hxv_fullvec_elems", "hxv_localvec_elems", "hxv_pitch", "hxv_time_apply", "hxv_lanczos_tridiag", "hxv_lanczos_eigh", "hxv_time_lanczos", "hxv_apply_ladder", "hxv_get_maps",
     "hxv_nnz", "hxv_get_csr", "hxv_get_diag", "hxv_set_option", "hxv_get_option", "hxv_get_stats", "hxv_last_error",
     "hxv_version",
 ]
@@ -72,6 +72,10 @@ def load_library():
     L.hxv_dims.argtypes = [vp, pi32, pi32, pi64, pi32, pi64]
     L.hxv_fullvec_elems.argtypes = [vp]
     L.hxv_fullvec_elems.restype = i64
+    L.hxv_localvec_elems.argtypes = [vp]
+    L.hxv_localvec_elems.restype = i64
+    L.hxv_pitch.argtypes = [vp]
+    L.hxv_pitch.restype = i32
     L.hxv_apply_host.argtypes = [vp, i64, vp, vp]
     L.hxv_apply_device.argtypes = [vp, vp, vp, vp]
     L.hxv_time_apply.argtypes = [vp, vp, vp, i32, C.POINTER(C.c_float)]
@@ -117,7 +121,11 @@ class HxvSector:
         _chk(L.hxv_dims(self._h, C.byref(du), C.byref(dd), C.byref(dim), C.byref(q), C.byref(ish)), "hxv_dims")
         self.DimUp, self.DimDw, self.Dim, self.mpiQdw, self.mpiIshift = du.value, dd.value, dim.value, q.value, ish.value
         self.vecDim = L.hxv_vecdim(self._h)
-        self.fullElems = L.hxv_fullvec_elems(self._h)   # length of the all-gather layout (== Dim if nranks == 1)
+        # device layout: every column padded to `pitch` elements (include/hxv.h, DEVICE VECTOR LAYOUT)
+        self.pitch = L.hxv_pitch(self._h)
+        self.fullElems = L.hxv_fullvec_elems(self._h)   # length of the (padded) all-gather layout handed to apply_device
+        self.localElems = L.hxv_localvec_elems(self._h)  # length of the (padded) local result / of a Lanczos vector
+        self.ncolsFull = self.fullElems // self.pitch
 
     # -- constructors ---------------------------------------------------------------------
     @classmethod
@@ -176,17 +184,48 @@ class HxvSector:
         _chk(load_library().hxv_apply_host(self._h, v.size, v.ctypes.data, hv.ctypes.data), "hxv_apply_host")
         return hv
 
-    def apply_device(self, v_full, hv_local=None, stream=None):
-        """Device-resident product on torch complex128 CUDA tensors. v_full: Dim elements
-        (all-gathered for nranks>1), hv_local: vecDim elements.  Runs on torch's current stream."""
+    # -- padded device layout helpers -------------------------------------------------------
+    def pad(self, x, ncols=None):
+        """contiguous [ncols x DimUp] torch vector -> padded device layout [ncols x pitch] (pads zero)."""
         import torch
 
-        assert v_full.is_cuda and v_full.dtype == torch.complex128 and v_full.is_contiguous() and v_full.numel() == self.fullElems
-        if hv_local is None:
-            hv_local = torch.empty(self.vecDim, dtype=torch.complex128, device=v_full.device)
-        assert hv_local.is_cuda and hv_local.dtype == torch.complex128 and hv_local.is_contiguous() and hv_local.numel() == self.vecDim
+        if self.pitch == self.DimUp:
+            return x
+        ncols = x.numel() // self.DimUp if ncols is None else ncols
+        out = torch.zeros(ncols * self.pitch, dtype=x.dtype, device=x.device)
+        out.view(ncols, self.pitch)[:, : self.DimUp] = x.view(ncols, self.DimUp)
+        return out
+
+    def unpad(self, x):
+        if self.pitch == self.DimUp:
+            return x
+        return x.view(-1, self.pitch)[:, : self.DimUp].contiguous().view(-1)
+
+    def apply_device(self, v_full, hv_local=None, stream=None):
+        """Device-resident product on torch complex128 CUDA tensors, on torch's current stream.
+        Native form: v_full in the padded all-gather layout (fullElems), hv_local padded (localElems).
+        Convenience form (tests): a contiguous vector of ncolsFull*DimUp elements is padded on the fly and the
+        result comes back contiguous (vecDim elements)."""
+        import torch
+
+        assert v_full.is_cuda and v_full.dtype == torch.complex128 and v_full.is_contiguous()
+        convenience = v_full.numel() != self.fullElems
+        if convenience:
+            assert v_full.numel() == self.ncolsFull * self.DimUp and hv_local is None or (hv_local is not None and hv_local.numel() == self.vecDim)
+            v_full = self.pad(v_full)
+            out = hv_local
+            hv_local = torch.zeros(self.localElems, dtype=torch.complex128, device=v_full.device)
+        elif hv_local is None:
+            hv_local = torch.zeros(self.localElems, dtype=torch.complex128, device=v_full.device)
+        assert hv_local.is_cuda and hv_local.dtype == torch.complex128 and hv_local.is_contiguous() and hv_local.numel() == self.localElems
         st = torch.cuda.current_stream(v_full.device).cuda_stream if stream is None else stream
         _chk(load_library().hxv_apply_device(self._h, v_full.data_ptr(), hv_local.data_ptr(), st), "hxv_apply_device")
+        if convenience:
+            res = self.unpad(hv_local)
+            if out is not None:
+                out.copy_(res)
+                return out
+            return res
         return hv_local
 
     def to_gather_layout(self, v: np.ndarray, nranks: int) -> np.ndarray:
@@ -194,11 +233,12 @@ class HxvSector:
         from .distributed import dw_split
 
         cmax = -(-self.DimDw // nranks)
-        out = np.zeros(nranks * cmax * self.DimUp, dtype=np.complex128)
+        out = np.zeros((nranks * cmax, self.pitch), dtype=np.complex128)
+        V = v.reshape(self.DimDw, self.DimUp)
         for r in range(nranks):
             q, c0 = dw_split(self.DimDw, r, nranks)
-            out[r * cmax * self.DimUp:(r * cmax + q) * self.DimUp] = v[c0 * self.DimUp:(c0 + q) * self.DimUp]
-        return out
+            out[r * cmax: r * cmax + q, : self.DimUp] = V[c0: c0 + q]
+        return out.reshape(-1)
 
     def time_apply(self, v_full, hv_local, nrep: int) -> float:
         """Mean ms per product over nrep launches, HIP events on the launch stream."""
@@ -211,10 +251,13 @@ class HxvSector:
 
     # -- Lanczos ---------------------------------------------------------------------------
     def lanczos_tridiag(self, vin, nlanc: int, threshold: float = 1e-12):
-        """sp_lanc_tridiag(MatVec, vin, alanc, blanc): vin = normalised torch CUDA vector."""
+        """sp_lanc_tridiag(MatVec, vin, alanc, blanc): vin = normalised torch CUDA vector (contiguous or padded)."""
         import torch
 
-        assert vin.is_cuda and vin.dtype == torch.complex128 and vin.numel() == self.Dim
+        assert vin.is_cuda and vin.dtype == torch.complex128
+        if vin.numel() != self.localElems:
+            assert vin.numel() == self.Dim
+            vin = self.pad(vin)
         torch.cuda.synchronize()
         a = np.zeros(nlanc)
         b = np.zeros(nlanc)
@@ -223,34 +266,41 @@ class HxvSector:
                                                 C.byref(n)), "hxv_lanczos_tridiag")
         return a, b, n.value
 
-    def lanczos_eigh(self, nitermax: int = 512, threshold: float = 1e-12, want_vector: bool = True):
-        """sp_lanc_eigh(MatVec, egs, vect, Nitermax, threshold): lowest eigenpair."""
+    def lanczos_eigh(self, nitermax: int = 512, threshold: float = 1e-12, want_vector: bool = True, native: bool = False):
+        """sp_lanc_eigh(MatVec, egs, vect, Nitermax, threshold): lowest eigenpair; the vector comes back
+        contiguous (Dim) unless native=True (padded device layout)."""
         import torch
 
         torch.cuda.synchronize()
         e = C.c_double()
         n = C.c_int32()
-        vec = torch.empty(self.Dim, dtype=torch.complex128, device="cuda") if want_vector else None
+        vec = torch.zeros(self.localElems, dtype=torch.complex128, device="cuda") if want_vector else None
         _chk(load_library().hxv_lanczos_eigh(self._h, nitermax, threshold, C.byref(e), vec.data_ptr() if want_vector else None,
                                              C.byref(n)), "hxv_lanczos_eigh")
+        if want_vector and not native:
+            vec = self.unpad(vec)
         return e.value, vec, n.value
 
     def apply_ladder(self, to: "HxvSector", orbital: int, spin: int, create: bool, psi):
         """c / c^dagger on (orbital, spin) from this sector into `to` (ED_GF_NORMAL.f90:180-199); returns (vector, norm2)."""
         import torch
 
-        assert psi.is_cuda and psi.dtype == torch.complex128 and psi.numel() == self.Dim
-        out = torch.empty(to.Dim, dtype=torch.complex128, device=psi.device)
+        assert psi.is_cuda and psi.dtype == torch.complex128
+        contiguous = psi.numel() != self.localElems
+        if contiguous:
+            assert psi.numel() == self.Dim
+            psi = self.pad(psi)
+        out = torch.empty(to.localElems, dtype=torch.complex128, device=psi.device)
         torch.cuda.synchronize()
         n2 = C.c_double()
         _chk(load_library().hxv_apply_ladder(self._h, to._h, orbital, spin, int(bool(create)), psi.data_ptr(), out.data_ptr(), C.byref(n2)),
              "hxv_apply_ladder")
-        return out, n2.value
+        return (to.unpad(out) if contiguous else out), n2.value
 
     def time_lanczos(self, nrep: int) -> float:
         import torch
 
-        work = torch.empty(3 * self.Dim, dtype=torch.complex128, device="cuda")
+        work = torch.empty(3 * self.localElems, dtype=torch.complex128, device="cuda")
         torch.cuda.synchronize()
         ms = C.c_float()
         _chk(load_library().hxv_time_lanczos(self._h, work.data_ptr(), nrep, C.byref(ms)), "hxv_time_lanczos")

@@ -82,16 +82,23 @@ int hxv_dims(const hxv_handle *h, int32_t *dimup, int32_t *dimdw, int64_t *dim, 
 int hxv_apply_host(hxv_handle *h, int64_t nloc, const void *v, void *hv);
 
 /* Device-resident product.  d_v_full: the FULL vector in the ALL-GATHER LAYOUT: nranks slabs of
- * cmax*DimUp elements each, cmax = ceil(DimDw/nranks), slab r holding rank r's columns (ranks
- * that own one column less leave their last DimUp elements unused) -- exactly what an
+ * cmax*pitch elements each, cmax = ceil(DimDw/nranks), slab r holding rank r's columns (ranks
+ * that own one column less leave their last pitch elements unused) -- exactly what an
  * equal-count ncclAllGather / MPI_Allgather of the padded slabs produces; hxv_fullvec_elems()
- * elements in all.  For nranks==1 this is the plain vector (Dim elements).  d_hv_local: this
- * rank's slab (vecdim elements), overwritten.  Asynchronous on `stream` (a hipStream_t; NULL = the legacy
+ * elements in all.  d_hv_local: this rank's slab (hxv_localvec_elems() elements), overwritten.  Asynchronous on `stream` (a hipStream_t; NULL = the legacy
  * default stream, as in every HIP API), so it orders with the caller's other work on that
  * stream.  d_v_full and d_hv_local must not overlap.                                     */
 int hxv_apply_device(hxv_handle *h, const void *d_v_full, void *d_hv_local, void *stream);
-/* number of complex elements of the all-gather layout above (= Dim when nranks==1) */
+/* DEVICE VECTOR LAYOUT.  On the device every column of DimUp elements is padded to hxv_pitch(h) =
+ * DimUp rounded up to a multiple of 8 elements, so each column starts on a 128-byte line; element
+ * (iup, column slot k) lives at k*pitch + iup.  The pad rows are never read as sources and never written by
+ * the product; the Lanczos entries require them to be ZERO in the vectors they are given (dot products
+ * run over the padded arrays).  hxv_apply_host converts from/to the reference's contiguous host layout.
+ *   hxv_fullvec_elems : length of d_v_full  = nranks*cmax*pitch  (all-gather layout above)
+ *   hxv_localvec_elems: length of d_hv_local and of every Lanczos vector = qdw*pitch             */
 int64_t hxv_fullvec_elems(const hxv_handle *h);
+int64_t hxv_localvec_elems(const hxv_handle *h);
+int32_t hxv_pitch(const hxv_handle *h);
 
 /* Time `nrep` back-to-back device products with HIP events recorded on the stream the
  * kernels are launched on; returns the mean milliseconds per product.                    */
@@ -99,7 +106,8 @@ int hxv_time_apply(hxv_handle *h, const void *d_v_full, void *d_hv_local, int32_
 
 /* ---- Lanczos on device (SciFortran sp_lanc_tridiag / sp_lanc_eigh call shapes,
  * ED_GF_NORMAL.f90:215-220, ED_DIAG.f90:176-184).  nranks==1.
- * tridiag: d_vin = caller-normalised start vector (device, Dim); alanc[nlanc], blanc[nlanc]
+ * All vectors in the padded device layout (hxv_localvec_elems() elements, pad rows zero).
+ * tridiag: d_vin = caller-normalised start vector; alanc[nlanc], blanc[nlanc]
  *   filled as alanc(k)=<q_k|H|q_k>, blanc(k+1)=beta_{k+1}, blanc(1)=0 (ED_GF_NORMAL.f90:949-951);
  *   *nsteps = iterations done (early exit when beta < threshold).
  * eigh: lowest eigenvalue *egs and eigenvector d_vect (device, Dim, written) from a
@@ -109,7 +117,7 @@ int hxv_lanczos_tridiag(hxv_handle *h, const void *d_vin, int32_t nlanc, double 
                         int32_t *nsteps);
 int hxv_lanczos_eigh(hxv_handle *h, int32_t nitermax, double threshold, double *egs, void *d_vect, int32_t *niter);
 /* Time nrep full Lanczos iterations (HxV + recurrence + 2 reductions) on device. */
-int hxv_time_lanczos(hxv_handle *h, void *d_work3 /* 3*Dim complex */, int32_t nrep, float *ms_per_iter);
+int hxv_time_lanczos(hxv_handle *h, void *d_work3 /* 3*hxv_localvec_elems() complex */, int32_t nrep, float *ms_per_iter);
 
 /* ---- Green's-function start vectors (ED_GF_NORMAL.f90:174-214: the reference applies c / c^dagger to the
  * ground state serially on the master and scatters): d_out = c^(dagger)_{orbital,spin} d_psi, from the sector
@@ -117,7 +125,7 @@ int hxv_time_lanczos(hxv_handle *h, void *d_work3 /* 3*Dim complex */, int32_t n
  * (-1)^(# occupied orbitals of the SAME spin below `orbital`) (c/cdg, ED_SETUP.f90:807-833; no cross-spin sign,
  * as in the reference).  orbital is 0-based (= pos-1), spin 0 = up, 1 = dw, create 1 = c^dagger, 0 = c.
  * *norm2 = <out|out> (the reference normalises by it, ED_GF_NORMAL.f90:197-199).  Both handles from_model,
- * nranks==1, same device.                                                                                */
+ * nranks==1, same device; padded device layouts, d_out's pad rows are written as zero.                                                                               */
 int hxv_apply_ladder(hxv_handle *from, hxv_handle *to, int32_t orbital, int32_t spin, int32_t create, const void *d_psi,
                      void *d_out, double *norm2);
 

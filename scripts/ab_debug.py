@@ -5,7 +5,7 @@ import torch, hxv
 from hxv import models
 m = models.hm_2dsquare(Nbath=3)
 sec = hxv.HxvSector.from_model(m, 8, 8)
-v = torch.randn(sec.Dim, dtype=torch.float64, device="cuda") + 1j * torch.randn(sec.Dim, dtype=torch.float64, device="cuda")
+v = torch.randn(sec.fullElems, dtype=torch.float64, device="cuda") + 1j * torch.randn(sec.fullElems, dtype=torch.float64, device="cuda")
 hv = torch.empty_like(v)
 torch.cuda.synchronize()
 bits = [int(x) for x in sys.argv[1:]] or [0, 16]

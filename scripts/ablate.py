@@ -5,7 +5,7 @@ from hxv import models
 m = models.hm_2dsquare(Nbath=3)
 NUP, NDW = map(int, os.environ.get("SECTOR", "8,8").split(","))
 sec = hxv.HxvSector.from_model(m, NUP, NDW)
-v = torch.randn(sec.Dim, dtype=torch.float64, device="cuda") + 1j * torch.randn(sec.Dim, dtype=torch.float64, device="cuda")
+v = torch.randn(sec.fullElems, dtype=torch.float64, device="cuda") + 1j * torch.randn(sec.fullElems, dtype=torch.float64, device="cuda")
 hv = torch.empty_like(v)
 torch.cuda.synchronize()
 def t(nrep=3):

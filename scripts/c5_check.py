@@ -7,7 +7,7 @@ from hxv import models
 m = models.hm_ring(6, 2)
 t0 = time.time(); sec = hxv.HxvSector.from_model(m, 9, 9); print("build s", round(time.time() - t0, 2), "Dim", sec.Dim, sec.stats(), flush=True)
 print("bits", sec.get_option("tile_bits_up"), sec.get_option("tile_bits_dw"), "blocks", sec.get_option("nblocks_up"), sec.get_option("nblocks_dw"), flush=True)
-n = sec.Dim
+n = sec.fullElems
 v = torch.empty(n, dtype=torch.complex128, device="cuda")
 vr = torch.view_as_real(v)
 chunk = 1 << 28
@@ -28,4 +28,4 @@ assert err / mx < 1e-13
 for k in (1, 0):
     sec.set_option("kernel", k)
     ms = sec.time_apply(v, hv, 3)
-    print("kernel", k, "ms", round(ms, 2), "GB/s alg", round(32 * n / ms / 1e6, 1), flush=True)
+    print("kernel", k, "ms", round(ms, 2), "GB/s alg", round(32 * sec.Dim / ms / 1e6, 1), flush=True)

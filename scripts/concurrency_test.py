@@ -7,7 +7,7 @@ from hxv import models
 m = models.hm_2dsquare(Nbath=3)
 sa = hxv.HxvSector.from_model(m, 8, 8); sa.set_option("passes", 1)
 sb = hxv.HxvSector.from_model(m, 8, 8); sb.set_option("passes", 2)
-v = torch.randn(sa.Dim, dtype=torch.float64, device="cuda") + 1j * torch.randn(sa.Dim, dtype=torch.float64, device="cuda")
+v = torch.randn(sa.fullElems, dtype=torch.float64, device="cuda") + 1j * torch.randn(sa.fullElems, dtype=torch.float64, device="cuda")
 h1 = torch.empty_like(v); h2 = torch.empty_like(v)
 s1 = torch.cuda.Stream(); s2 = torch.cuda.Stream()
 def run(conc, n=5):

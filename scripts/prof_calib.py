@@ -9,7 +9,7 @@ m = models.hm_2dsquare(Nbath=3)
 sec = hxv.HxvSector.from_model(m, 8, 8)
 for k, val in (("lds_budget_kb_up", kbA), ("cols_per_tile", C), ("threads_up", TA), ("lds_budget_kb_dw", kbB), ("rows_per_tile", R), ("threads_dw", TB), ("sort_mode", srt)):
     sec.set_option(k, val)
-v = torch.randn(sec.Dim, dtype=torch.float64, device="cuda") + 1j * torch.randn(sec.Dim, dtype=torch.float64, device="cuda")
+v = torch.randn(sec.fullElems, dtype=torch.float64, device="cuda") + 1j * torch.randn(sec.fullElems, dtype=torch.float64, device="cuda")
 hv = torch.empty_like(v)
 torch.cuda.synchronize()
 for _ in range(2):

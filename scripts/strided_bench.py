@@ -9,8 +9,8 @@ sec = hxv.HxvSector.from_model(m, NUP, NDW)
 print("sector", NUP, NDW, sec.DimUp)
 L = hxv.load_library()
 L.hxv_debug_strided_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float)]
-v = torch.randn(sec.Dim, dtype=torch.float64, device="cuda") + 1j * torch.randn(sec.Dim, dtype=torch.float64, device="cuda")
-out = torch.zeros(sec.Dim, dtype=torch.complex128, device="cuda")
+v = torch.randn(sec.fullElems, dtype=torch.float64, device="cuda") + 1j * torch.randn(sec.fullElems, dtype=torch.float64, device="cuda")
+out = torch.zeros(sec.fullElems, dtype=torch.complex128, device="cuda")
 torch.cuda.synchronize()
 ms = C.c_float()
 names = {0: "read", 1: "read+lds", 2: "read+lds+store", 3: "read+lds+nt-store", 4: "read+lds+RMW", 5: "read+lds+nt-RMW"}

@@ -10,7 +10,7 @@ m = models.hm_2dsquare(Nbath=3)
 NUP, NDW = map(int, os.environ.get("SECTOR", "8,8").split(","))
 sec = hxv.HxvSector.from_model(m, NUP, NDW)
 print("sector", NUP, NDW, "DimUp", sec.DimUp, "DimDw", sec.DimDw)
-v = torch.randn(sec.Dim, dtype=torch.float64, device="cuda") + 1j * torch.randn(sec.Dim, dtype=torch.float64, device="cuda")
+v = torch.randn(sec.fullElems, dtype=torch.float64, device="cuda") + 1j * torch.randn(sec.fullElems, dtype=torch.float64, device="cuda")
 hv = torch.empty_like(v)
 torch.cuda.synchronize()
 alg = 32 * sec.Dim

@@ -139,7 +139,7 @@ def test_tiled_outer_path_and_shards_match_oracle(built, bits, shard):
             sec.set_option("sort_mode", srt)
             for kernel in (0, 1):
                 sec.set_option("kernel", kernel)
-                hv = sec.apply_device(dv)
+                hv = sec.unpad(sec.apply_device(dv))
                 torch.cuda.synchronize()
                 assert _rel(hv.cpu().numpy(), ref) <= TOL, (m.name, bits, shard, cols, rows, kernel)
         sec.close()
@@ -166,7 +166,7 @@ def test_full_size_slab_matches_oracle_matrices(built, config):
     dv = torch.from_numpy(sec.to_gather_layout(v, 64)).cuda()
     for kernel in (0, 1):
         sec.set_option("kernel", kernel)
-        hv = sec.apply_device(dv)
+        hv = sec.unpad(sec.apply_device(dv))
         torch.cuda.synchronize()
         assert _rel(hv.cpu().numpy(), ref) <= TOL, kernel
 
@@ -214,7 +214,7 @@ def test_create_from_csr_matches_oracle(built, shard):
         for kernel, kb in ((0, 64), (1, 64), (1, 8)):
             sec.set_option("lds_budget_kb", kb)
             sec.set_option("kernel", kernel)
-            hv = sec.apply_device(dv)
+            hv = sec.unpad(sec.apply_device(dv))
             torch.cuda.synchronize()
             assert _rel(hv.cpu().numpy(), ref) <= TOL, (m.name, shard, kernel, kb)
         # introspection round trip: the engine hands back the matrices it was given
