@@ -20,9 +20,9 @@ struct DevTiles {
   const uint32_t* start;   // [nblocks+1]
   const uint32_t* perm;    // [dim]   sorted position -> index
   const uint32_t* gstart;  // [nblocks+1] first 64-position group of each block
-  const uint32_t* gmax;    // [groups] k_in max | k_out max << 16
+  const uint32_t* gmax;    // [groups] longest in-block list of each 64-position group (low 16 bits)
   const uint32_t* ell_in;  // [k_in][dim]
-  const uint32_t* ell_out; // [k_out][dim]
+  const uint32_t* ell_out; // unused placeholder (the out-of-block part is bh/rs below)
   const double2* scoef;    // [nscoef] signed coefficients, last = 0
   const uint32_t* bh_ptr;  // block hops / row slots of the out-of-block part (hxv_tiles.hpp)
   const uint32_t* bh;
@@ -496,12 +496,12 @@ void build_spin_tiles(const SpinOp& op, const std::vector<uint32_t>& map, int lo
   // tables
   const uint32_t emptyz = (uint32_t)(2 * op.coef.size()) << TILE_COEF_SHIFT;
   h.ell_in.assign((size_t)t.k_in * dim, emptyz);
-  h.ell_out.assign((size_t)t.k_out * dim, emptyz);
+  h.ell_out.assign(1, emptyz);  // the flat outer table is superseded by block hops + row slots (below)
   std::vector<uint32_t> pos_of(dim);
   for (int q = 0; q < dim; ++q) pos_of[h.perm[q]] = (uint32_t)q;
   for (int i = 0; i < dim; ++i) {
     int a = 0, b = 0, k = 0;
-    const size_t qi = pos_of[i], qo = sorted_out ? pos_of[i] : (size_t)i;
+    const size_t qi = pos_of[i];
     for (int64_t p = op.rowptr[i]; p < op.rowptr[i + 1]; ++p, ++k) {
       const uint32_t e = op.ell[(size_t)k * dim + i];  // same order as the CSR row
       const uint32_t src = e & ELL_SRC_MASK;
@@ -509,7 +509,7 @@ void build_spin_tiles(const SpinOp& op, const std::vector<uint32_t>& map, int lo
       if (block_of[src] == block_of[i])
         h.ell_in[(size_t)(a++) * dim + qi] = ci | (src - h.start[block_of[i]]);
       else
-        h.ell_out[(size_t)(b++) * dim + qo] = ci | (vcol ? (*vcol)[src] : src);
+        ++b;  // out-of-block entry: handled by the structured part below
     }
   }
   // ---- structured out-of-block part: group by (block, source block)
