@@ -873,6 +873,49 @@ int hxv_lanczos_eigh(hxv_handle* h, int32_t nitermax, double threshold, double* 
   return HXV_OK;
 }
 
+namespace {
+int ensure_stage(hxv_handle* h) {
+  const size_t bytes = (size_t)h->host.pitch * h->host.dimdw * sizeof(double2);
+  if (!h->d_stage_v) {
+    HIPCHK(hipMalloc((void**)&h->d_stage_v, bytes));
+    HIPCHK(hipMalloc((void**)&h->d_stage_hv, bytes));
+    HIPCHK(hipMemset(h->d_stage_v, 0, bytes));
+    HIPCHK(hipMemset(h->d_stage_hv, 0, bytes));
+    h->device_bytes += 2 * (int64_t)bytes;
+  }
+  return HXV_OK;
+}
+}  // namespace
+
+int hxv_lanczos_tridiag_host(hxv_handle* h, const void* vin_host, int32_t nlanc, double* alanc, double* blanc, double threshold,
+                             int32_t* nsteps) {
+  if (!h || !vin_host) return fail(HXV_ERR_ARG, "hxv_lanczos_tridiag_host: NULL argument");
+  if (h->host.nranks != 1) return fail(HXV_ERR_STATE, "hxv_lanczos_tridiag_host needs nranks==1");
+  HIPCHK(hipSetDevice(h->device));
+  int rc = ensure_stage(h);
+  if (rc) return rc;
+  const size_t col = (size_t)h->host.dimup * sizeof(double2), pit = (size_t)h->host.pitch * sizeof(double2);
+  HIPCHK(hipMemcpy2DAsync(h->d_stage_v, pit, vin_host, col, col, (size_t)h->host.dimdw, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return hxv_lanczos_tridiag(h, h->d_stage_v, nlanc, alanc, blanc, threshold, nsteps);
+}
+
+int hxv_lanczos_eigh_host(hxv_handle* h, int32_t nitermax, double threshold, double* egs, void* vect_host, int32_t* niter) {
+  if (!h) return fail(HXV_ERR_ARG, "hxv_lanczos_eigh_host: NULL handle");
+  if (h->host.nranks != 1) return fail(HXV_ERR_STATE, "hxv_lanczos_eigh_host needs nranks==1");
+  HIPCHK(hipSetDevice(h->device));
+  int rc = ensure_stage(h);
+  if (rc) return rc;
+  rc = hxv_lanczos_eigh(h, nitermax, threshold, egs, vect_host ? h->d_stage_hv : nullptr, niter);
+  if (rc) return rc;
+  if (vect_host) {
+    const size_t col = (size_t)h->host.dimup * sizeof(double2), pit = (size_t)h->host.pitch * sizeof(double2);
+    HIPCHK(hipMemcpy2DAsync(vect_host, col, h->d_stage_hv, pit, col, (size_t)h->host.dimdw, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  return HXV_OK;
+}
+
 int hxv_apply_ladder(hxv_handle* from, hxv_handle* to, int32_t orbital, int32_t spin, int32_t create, const void* d_psi, void* d_out,
                      double* norm2) {
   if (!from || !to || !d_psi || !d_out) return fail(HXV_ERR_ARG, "hxv_apply_ladder: NULL argument");

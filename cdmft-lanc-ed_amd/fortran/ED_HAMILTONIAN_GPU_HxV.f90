@@ -17,6 +17,8 @@ module ED_HAMILTONIAN_GPU_HXV
   public :: gpu_vecDim_Hv_sector
   public :: gpuMatVec_main
   public :: gpu_lanc_tridiag_host
+  public :: gpu_sp_lanc_tridiag
+  public :: gpu_sp_lanc_eigh
 
   !> mirrors struct hxv_model of include/hxv.h
   type, bind(C) :: hxv_model
@@ -49,6 +51,24 @@ module ED_HAMILTONIAN_GPU_HXV
        complex(c_double_complex),intent(in) :: v(*)
        complex(c_double_complex)            :: hv(*)
      end function hxv_apply_host
+     integer(c_int) function hxv_lanczos_tridiag_host(h,vin,nlanc,alanc,blanc,threshold,nsteps) bind(C,name="hxv_lanczos_tridiag_host")
+       import :: c_int, c_int32_t, c_ptr, c_double, c_double_complex
+       type(c_ptr),value                    :: h
+       complex(c_double_complex),intent(in) :: vin(*)
+       integer(c_int32_t),value             :: nlanc
+       real(c_double)                       :: alanc(*),blanc(*)
+       real(c_double),value                 :: threshold
+       integer(c_int32_t)                   :: nsteps
+     end function hxv_lanczos_tridiag_host
+     integer(c_int) function hxv_lanczos_eigh_host(h,nitermax,threshold,egs,vect,niter) bind(C,name="hxv_lanczos_eigh_host")
+       import :: c_int, c_int32_t, c_ptr, c_double, c_double_complex
+       type(c_ptr),value                    :: h
+       integer(c_int32_t),value             :: nitermax
+       real(c_double),value                 :: threshold
+       real(c_double)                       :: egs
+       complex(c_double_complex)            :: vect(*)
+       integer(c_int32_t)                   :: niter
+     end function hxv_lanczos_eigh_host
      type(c_ptr) function hxv_last_error() bind(C,name="hxv_last_error")
        import :: c_ptr
      end function hxv_last_error
@@ -164,5 +184,49 @@ contains
     enddo
     deallocate(q,qm,w)
   end subroutine gpu_lanc_tridiag_host
+
+  !> Device-resident Lanczos with the SciFortran CALL SIGNATURES, so that the two call sites can switch by
+  !! changing one `use`:   sp_lanc_tridiag(MatVec,vin,alanc,blanc)        ED_GF_NORMAL.f90:215-220 (+7)
+  !!                        sp_lanc_eigh(MatVec,egs,vect,Nitermax,iverbose,threshold)   ED_DIAG.f90:176-184
+  !! MatVec is accepted for signature compatibility and not called: the product of the OPEN sector runs on the
+  !! device; vin/vect cross PCIe once per run instead of twice per iteration.
+  subroutine gpu_sp_lanc_tridiag(MatVec,vin,alanc,blanc,threshold)
+    interface
+       subroutine MatVec(Nloc,v,Hv)
+         integer                    :: Nloc
+         complex(8),dimension(Nloc) :: v,Hv
+       end subroutine MatVec
+    end interface
+    complex(8),intent(inout)    :: vin(:)
+    real(8),intent(inout)       :: alanc(:),blanc(:)
+    real(8),intent(in),optional :: threshold
+    real(8)                     :: thr
+    integer(c_int32_t)          :: nsteps
+    if(.not.c_associated(handle))stop "gpu_sp_lanc_tridiag ERROR: Hsector NOT set"
+    thr=1d-12; if(present(threshold))thr=threshold
+    call check(hxv_lanczos_tridiag_host(handle,vin,int(size(alanc),c_int32_t),alanc,blanc,thr,nsteps),"gpu_sp_lanc_tridiag")
+  end subroutine gpu_sp_lanc_tridiag
+
+  subroutine gpu_sp_lanc_eigh(MatVec,egs,vect,Nitermax,iverbose,threshold)
+    interface
+       subroutine MatVec(Nloc,v,Hv)
+         integer                    :: Nloc
+         complex(8),dimension(Nloc) :: v,Hv
+       end subroutine MatVec
+    end interface
+    real(8),intent(inout)       :: egs
+    complex(8),intent(inout)    :: vect(:)
+    integer,intent(in)          :: Nitermax
+    logical,intent(in),optional :: iverbose
+    real(8),intent(in),optional :: threshold
+    real(8)                     :: thr
+    integer(c_int32_t)          :: niter
+    if(.not.c_associated(handle))stop "gpu_sp_lanc_eigh ERROR: Hsector NOT set"
+    thr=1d-12; if(present(threshold))thr=max(threshold,1d-15)
+    call check(hxv_lanczos_eigh_host(handle,int(Nitermax,c_int32_t),thr,egs,vect,niter),"gpu_sp_lanc_eigh")
+    if(present(iverbose))then
+       if(iverbose)write(*,"(A,I6,A,F20.12)")"gpu_sp_lanc_eigh: iterations=",niter," E0=",egs
+    endif
+  end subroutine gpu_sp_lanc_eigh
 
 end module ED_HAMILTONIAN_GPU_HXV

@@ -82,6 +82,12 @@ contains
     call gpu_lanc_tridiag_host(spHtimesV_p,v,alanc,blanc)
     e0=lowest_tridiag(alanc,blanc)
     write(*,"(A,I8,A,F16.10)")"C2 chain sector(6,6) Dim=",dim," E0=",e0
+    !the same two calls as ED_GF_NORMAL.f90:215 / ED_DIAG.f90:176, SciFortran signatures, recurrence on the device
+    v=v/sqrt(dble(dot_product(v,v)))
+    call gpu_sp_lanc_tridiag(spHtimesV_p,v,alanc,blanc)
+    write(*,"(A,F16.10)")"C2 device tridiag E0=",lowest_tridiag(alanc,blanc)
+    call gpu_sp_lanc_eigh(spHtimesV_p,e0,hv,512,threshold=1d-14)
+    write(*,"(A,F16.10,A,ES12.4)")"C2 device eigh E0=",e0," |vec|^2-1=",dble(dot_product(hv,hv))-1d0
     spHtimesV_p => null()
     call gpu_delete_Hv_sector()
   end subroutine chain_ns12

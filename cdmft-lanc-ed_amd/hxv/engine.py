@@ -41,7 +41,7 @@ class _Stats(C.Structure):
 # every symbol include/hxv.h declares (tests check that the library exports all of them)
 EXPORTS = [
     "hxv_create_from_model", "hxv_create_from_csr", "hxv_destroy", "hxv_vecdim", "hxv_dims", "hxv_apply_host",
-    "hxv_apply_device", "hxv_fullvec_elems", "hxv_localvec_elems", "hxv_pitch", "hxv_time_apply", "hxv_lanczos_tridiag", "hxv_lanczos_eigh", "hxv_time_lanczos", "hxv_apply_ladder", "hxv_get_maps",
+    "hxv_apply_device", "hxv_fullvec_elems", "hxv_localvec_elems", "hxv_pitch", "hxv_time_apply", "hxv_lanczos_tridiag", "hxv_lanczos_eigh", "hxv_lanczos_tridiag_host", "hxv_lanczos_eigh_host", "hxv_time_lanczos", "hxv_apply_ladder", "hxv_get_maps",
     "hxv_nnz", "hxv_get_csr", "hxv_get_diag", "hxv_set_option", "hxv_get_option", "hxv_get_stats", "hxv_last_error",
     "hxv_version",
 ]
@@ -81,6 +81,8 @@ def load_library():
     L.hxv_time_apply.argtypes = [vp, vp, vp, i32, C.POINTER(C.c_float)]
     L.hxv_lanczos_tridiag.argtypes = [vp, vp, i32, pd, pd, dbl, pi32]
     L.hxv_lanczos_eigh.argtypes = [vp, i32, dbl, pd, vp, pi32]
+    L.hxv_lanczos_tridiag_host.argtypes = [vp, vp, i32, pd, pd, dbl, pi32]
+    L.hxv_lanczos_eigh_host.argtypes = [vp, i32, dbl, pd, vp, pi32]
     L.hxv_time_lanczos.argtypes = [vp, vp, i32, C.POINTER(C.c_float)]
     L.hxv_apply_ladder.argtypes = [vp, vp, i32, i32, i32, vp, vp, pd]
     L.hxv_get_maps.argtypes = [vp, pi32, pi32]
@@ -279,6 +281,26 @@ class HxvSector:
                                              C.byref(n)), "hxv_lanczos_eigh")
         if want_vector and not native:
             vec = self.unpad(vec)
+        return e.value, vec, n.value
+
+    def lanczos_tridiag_host(self, vin: np.ndarray, nlanc: int, threshold: float = 1e-12):
+        """sp_lanc_tridiag on a HOST start vector (reference layout): one PCIe copy per run."""
+        vin = np.ascontiguousarray(vin, dtype=np.complex128)
+        assert vin.size == self.Dim
+        a = np.zeros(nlanc)
+        b = np.zeros(nlanc)
+        n = C.c_int32()
+        _chk(load_library().hxv_lanczos_tridiag_host(self._h, vin.ctypes.data, nlanc, _p(a, C.c_double), _p(b, C.c_double), threshold,
+                                                     C.byref(n)), "hxv_lanczos_tridiag_host")
+        return a, b, n.value
+
+    def lanczos_eigh_host(self, nitermax: int = 512, threshold: float = 1e-12):
+        """sp_lanc_eigh with the eigenvector returned in a HOST array (reference layout)."""
+        e = C.c_double()
+        n = C.c_int32()
+        vec = np.zeros(self.Dim, dtype=np.complex128)
+        _chk(load_library().hxv_lanczos_eigh_host(self._h, nitermax, threshold, C.byref(e), vec.ctypes.data, C.byref(n)),
+             "hxv_lanczos_eigh_host")
         return e.value, vec, n.value
 
     def apply_ladder(self, to: "HxvSector", orbital: int, spin: int, create: bool, psi):

@@ -116,6 +116,13 @@ int hxv_time_apply(hxv_handle *h, const void *d_v_full, void *d_hv_local, int32_
 int hxv_lanczos_tridiag(hxv_handle *h, const void *d_vin, int32_t nlanc, double *alanc, double *blanc, double threshold,
                         int32_t *nsteps);
 int hxv_lanczos_eigh(hxv_handle *h, int32_t nitermax, double threshold, double *egs, void *d_vect, int32_t *niter);
+/* Same two drivers with HOST vectors in the reference's contiguous layout (what ED_DIAG / ED_GF_NORMAL hold):
+ * one PCIe copy per Lanczos RUN instead of two per iteration.  vin_host: Dim complex, normalised by the caller;
+ * vect_host: Dim complex, written (may be NULL).  These are what the Fortran glue's gpu_sp_lanc_tridiag /
+ * gpu_sp_lanc_eigh (SciFortran call signatures) forward to.                                                 */
+int hxv_lanczos_tridiag_host(hxv_handle *h, const void *vin_host, int32_t nlanc, double *alanc, double *blanc, double threshold,
+                             int32_t *nsteps);
+int hxv_lanczos_eigh_host(hxv_handle *h, int32_t nitermax, double threshold, double *egs, void *vect_host, int32_t *niter);
 /* Time nrep full Lanczos iterations (HxV + recurrence + 2 reductions) on device. */
 int hxv_time_lanczos(hxv_handle *h, void *d_work3 /* 3*hxv_localvec_elems() complex */, int32_t nrep, float *ms_per_iter);
 

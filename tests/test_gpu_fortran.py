@@ -35,3 +35,8 @@ def test_fortran_host_through_procedure_pointer(built):
     a, b = orc.lanc_tridiag(v / np.linalg.norm(v), 200)
     T = np.diag(a) + np.diag(b[1:], 1) + np.diag(b[1:], -1)
     assert abs(e0_c2 - np.linalg.eigvalsh(T)[0]) < 1e-9
+    # device Lanczos behind the SciFortran call signatures (gpu_sp_lanc_tridiag / gpu_sp_lanc_eigh)
+    e0_tri = float(re.search(r"C2 device tridiag E0=\s*([-\d.Ee+]+)", txt).group(1))
+    m2 = re.search(r"C2 device eigh E0=\s*([-\d.Ee+]+)\s*\|vec\|\^2-1=\s*([-\d.Ee+]+)", txt)
+    e0_eig, dn = float(m2.group(1)), float(m2.group(2))
+    assert abs(e0_tri - e0_c2) < 1e-9 and abs(e0_eig - e0_c2) < 1e-9 and abs(dn) < 1e-10

@@ -191,3 +191,25 @@ def test_ladder_operator_on_device_matches_host(built, spin, create):
         assert abs(n2 - np.vdot(ref, ref).real) <= 1e-12 * max(1.0, n2)
     with pytest.raises(hxv.HxvError):
         s0.apply_ladder(s0, 0, spin, create, torch.from_numpy(psi).cuda())   # wrong target sector
+
+
+def test_host_vector_lanczos_entries(built):
+    """hxv_lanczos_tridiag_host / _eigh_host: host vectors in the reference layout, one PCIe copy per run."""
+    import hxv
+    from hxv import models
+    from oracle.oracle import OracleSector
+
+    m = models.hm_2dsquare(Nbath=1)
+    sec = hxv.HxvSector.from_model(m, 4, 4)     # DimUp = 70: exercises the padded device pitch (72)
+    assert sec.pitch == 72
+    orc = OracleSector(m, 4, 4)
+    v = models.deterministic_vector(sec.Dim)
+    v /= np.linalg.norm(v)
+    # 25 steps: beyond ~30 the plain recurrence loses orthogonality and two fp64 implementations drift apart
+    a_ref, b_ref = orc.lanc_tridiag(v, 25)
+    a, b, n = sec.lanczos_tridiag_host(v, 25)
+    assert n == 25 and np.abs(a - a_ref).max() <= 1e-10 * np.abs(a_ref).max() and np.abs(b - b_ref).max() <= 1e-10 * np.abs(b_ref).max()
+    e0, vec, nit = sec.lanczos_eigh_host(512, 1e-14)
+    H = orc.dense()
+    assert abs(e0 - np.linalg.eigvalsh(H)[0]) <= 1e-10
+    assert np.abs(H @ vec - e0 * vec).max() < 1e-8 and abs(np.vdot(vec, vec).real - 1) < 1e-12
