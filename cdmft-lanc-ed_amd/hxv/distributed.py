@@ -59,7 +59,11 @@ class ShardedHxv:
                 self._send = torch.zeros(self.slab, dtype=v_local.dtype, device=v_local.device)
             self._send[: self.Nloc].copy_(v_local)
             send = self._send
-        self.dist.all_gather_into_tensor(self._vfull, send.contiguous(), group=self.group)
+        # the collective runs on the float64 view: RCCL/NCCL has no complex datatype, and a plain byte-for-byte
+        # gather is all that is needed
+        out_r = torch.view_as_real(self._vfull).view(-1) if self._vfull.is_complex() else self._vfull
+        in_r = torch.view_as_real(send.contiguous()).view(-1) if send.is_complex() else send.contiguous()
+        self.dist.all_gather_into_tensor(out_r, in_r, group=self.group)
         return self._vfull
 
     def unpad(self, v_gathered):
