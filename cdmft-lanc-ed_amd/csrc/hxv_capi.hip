@@ -189,6 +189,19 @@ int hxv_create_from_model(const hxv_model* model, int32_t nup, int32_t ndw, int3
   return finish_create(h, device, out);
 }
 
+int hxv_create_dw_panel(const hxv_model* model, int32_t nup, int32_t ndw, int32_t nrows, int32_t device, hxv_handle** out) {
+  if (!model || !out) return fail(HXV_ERR_ARG, "NULL model/out");
+  *out = nullptr;
+  if (nrows < 1) return fail(HXV_ERR_ARG, "hxv_create_dw_panel: nrows < 1");
+  hxv_handle* h = new hxv_handle();
+  std::string e = build_sector_from_model(*model, nup, ndw, 0, 1, h->host, nrows);
+  if (!e.empty()) {
+    delete h;
+    return fail(HXV_ERR_ARG, "hxv_create_dw_panel: " + e);
+  }
+  return finish_create(h, device, out);
+}
+
 int hxv_create_from_csr(int32_t dimup, int32_t dimdw, const int64_t* up_rowptr, const int32_t* up_cols, const double* up_vals,
                         const int64_t* dw_rowptr, const int32_t* dw_cols, const double* dw_vals, const double* diag, int32_t rank,
                         int32_t nranks, int32_t device, hxv_handle** out) {
@@ -239,6 +252,7 @@ int hxv_dims(const hxv_handle* h, int32_t* dimup, int32_t* dimdw, int64_t* dim, 
 
 int hxv_apply_device(hxv_handle* h, const void* d_v_full, void* d_hv_local, void* stream) {
   if (!h || !d_v_full || !d_hv_local) return fail(HXV_ERR_ARG, "hxv_apply_device: NULL argument");
+  if (h->host.panel_rows > 0) return fail(HXV_ERR_STATE, "hxv_apply_device: panel handles only do hxv_apply_dw_panel");
   hipStream_t st = (hipStream_t)stream;  // NULL = the legacy default stream, as everywhere in HIP
   hipError_t e;
   if (h->kernel == 0 || !h->plan.usable)
@@ -249,6 +263,30 @@ int hxv_apply_device(hxv_handle* h, const void* d_v_full, void* d_hv_local, void
     e = launch_hxv_tiled(h->dev, h->plan, (const double2*)d_v_full, h->d_wt, (double2*)d_hv_local, st);
   }
   if (e == hipSuccess && h->dev.nd.active) e = launch_hxv_nonlocal(h->dev, (const double2*)d_v_full, (double2*)d_hv_local, st);
+  if (e != hipSuccess) return fail(HXV_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+  h->n_apply++;
+  return HXV_OK;
+}
+
+int hxv_apply_dw_panel(hxv_handle* h, const void* d_x, void* d_y, void* stream) {
+  if (!h || !d_x || !d_y) return fail(HXV_ERR_ARG, "hxv_apply_dw_panel: NULL argument");
+  if (h->host.panel_rows <= 0) return fail(HXV_ERR_STATE, "hxv_apply_dw_panel needs a handle from hxv_create_dw_panel");
+  if (!h->plan.usable) return fail(HXV_ERR_UNSUPPORTED, "hxv_apply_dw_panel: tiled kernels unavailable (too many distinct amplitudes)");
+  hipError_t e = launch_hxv_tiled(h->dev, h->plan, (const double2*)d_x, (double2*)d_y, nullptr, (hipStream_t)stream, nullptr, 2, true);
+  if (e != hipSuccess) return fail(HXV_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+  h->n_apply++;
+  return HXV_OK;
+}
+
+int hxv_apply_up_add(hxv_handle* h, const void* d_v_local, const void* d_w, void* d_hv_local, void* stream) {
+  if (!h || !d_v_local || !d_w || !d_hv_local) return fail(HXV_ERR_ARG, "hxv_apply_up_add: NULL argument");
+  if (h->host.panel_rows > 0) return fail(HXV_ERR_STATE, "hxv_apply_up_add: panel handles have no up part");
+  if (h->dev.nd.active) return fail(HXV_ERR_UNSUPPORTED, "hxv_apply_up_add: the spH0nd block needs the gathered vector (use hxv_apply_device)");
+  if (!h->plan.usable) return fail(HXV_ERR_UNSUPPORTED, "hxv_apply_up_add: tiled kernels unavailable (too many distinct amplitudes)");
+  // pass A addresses its slab as column slots slab0.. of a gathered vector: shift the base so the local slab lands there
+  const double2* vbase = (const double2*)d_v_local - (int64_t)h->dev.slab0 * h->dev.pitch;
+  hipError_t e = launch_hxv_tiled(h->dev, h->plan, vbase, const_cast<double2*>((const double2*)d_w), (double2*)d_hv_local,
+                                  (hipStream_t)stream, nullptr, 1, true);
   if (e != hipSuccess) return fail(HXV_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
   h->n_apply++;
   return HXV_OK;

@@ -58,6 +58,7 @@ struct SectorHost {
   int dimup = 0, dimdw = 0;
   int pitch = 0;                    // device column pitch: DimUp rounded up to 8 elements (128-byte lines)
   int64_t dim = 0;
+  int panel_rows = 0;               // > 0: a dw-only row panel (all-to-all exchange): dimup = panel_rows, no H_up
   int rank = 0, nranks = 1, qdw = 0, dw0 = 0;
   int cmax = 0;                     // columns per rank in the padded all-gather layout
   std::vector<uint32_t> vcol;       // [dimdw] column -> column slot in the padded layout
@@ -72,7 +73,7 @@ struct SectorHost {
 };
 
 // host builders (hxv_sector.cpp); return "" on success, else an error message
-std::string build_sector_from_model(const hxv_model& m, int nup, int ndw, int rank, int nranks, SectorHost& out);
+std::string build_sector_from_model(const hxv_model& m, int nup, int ndw, int rank, int nranks, SectorHost& out, int panel_rows = 0);
 std::string build_sector_from_csr(int dimup, int dimdw, const int64_t* up_rp, const int32_t* up_cols, const double* up_vals,
                                   const int64_t* dw_rp, const int32_t* dw_cols, const double* dw_vals, const double* diag, int rank,
                                   int nranks, SectorHost& out);

@@ -223,7 +223,7 @@ std::string build_ell(SpinOp& op) {
   return "";
 }
 
-std::string build_sector_from_model(const hxv_model& m, int nup, int ndw, int rank, int nranks, SectorHost& s) {
+std::string build_sector_from_model(const hxv_model& m, int nup, int ndw, int rank, int nranks, SectorHost& s, int panel_rows) {
   if (m.nlat < 1 || m.norb < 1 || m.nspin < 1 || m.nspin > 2 || m.nbath < 0) return "bad Nlat/Norb/Nspin/Nbath";
   if (m.norb > 5) return "Norb > 5 (Uloc has 5 entries)";
   if (m.nlat > 16) return "Nlat > 16";
@@ -252,7 +252,22 @@ std::string build_sector_from_model(const hxv_model& m, int nup, int ndw, int ra
   if (!e.empty()) return e;
   e = one_body(mv, m.nspin - 1, hops_dw, eps_dw);            // spin index Nspin   (H_dw.f90:14)
   if (!e.empty()) return e;
-  apply_hops(s.map_up, hops_up, s.up);
+  if (panel_rows > 0) {
+    // dw-only row panel [panel_rows x DimDw] of the vector (all-to-all exchange): the up index is just a row
+    // count here -- no basis, no H_up, no diagonal
+    if (panel_rows > s.dimup) return "panel_rows > DimUp";
+    s.panel_rows = panel_rows;
+    s.dimup = panel_rows;
+    s.dim = (int64_t)panel_rows * s.dimdw;
+    s.map_up.assign(panel_rows, 0u);
+    s.ishift = 0;
+    make_vcol(s);
+    s.up = SpinOp();
+    s.up.dim = panel_rows;
+    s.up.rowptr.assign(panel_rows + 1, 0);
+  } else {
+    apply_hops(s.map_up, hops_up, s.up);
+  }
   apply_hops(s.map_dw, hops_dw, s.dw);
   e = build_ell(s.up);
   if (!e.empty()) return e;
@@ -291,7 +306,7 @@ std::string build_sector_from_model(const hxv_model& m, int nup, int ndw, int ra
   s.separable_diag = true;
   s.a_up.resize(s.dimup);
   s.a_dw.resize(s.dimdw);
-  for (int i = 0; i < s.dimup; ++i) s.a_up[i] = one_spin_diag(s.map_up[i], eps_up) + cst;
+  for (int i = 0; i < s.dimup; ++i) s.a_up[i] = panel_rows > 0 ? 0.0 : one_spin_diag(s.map_up[i], eps_up) + cst;
   for (int i = 0; i < s.dimdw; ++i) s.a_dw[i] = one_spin_diag(s.map_dw[i], eps_dw);
   s.nd = NonLocalParams();
   s.nd.active = (O > 1 && (m.jx != 0.0 || m.jp != 0.0)) ? 1 : 0;  // Jhflag, ED_SETUP.f90:200-201

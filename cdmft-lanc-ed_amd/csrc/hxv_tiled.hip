@@ -120,7 +120,12 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
   double au = 0.0;
   uint32_t mu = 0;
   if (p < n) {
-    if (wt) {
+    if (wt && wc == 0) {
+      // natural layout [local column][pitch] (all-to-all exchange: the dw part arrives assembled like hv)
+      const double2* __restrict__ wcol = wt + (int64_t)c0 * s.pitch + r0 + p;
+#pragma unroll
+      for (int cc = 0; cc < C; ++cc) acc[cc] = wcol[(int64_t)min(cc, nc - 1) * s.pitch];
+    } else if (wt) {
       const double2* __restrict__ wrow = wt + ((int64_t)(c0 / wc) * s.dimup + r0 + p) * wc + (c0 % wc);
 #pragma unroll
       for (int cc = 0; cc < C; ++cc) acc[cc] = wrow[min(cc, nc - 1)];
@@ -384,6 +389,15 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_dw(DevSector s, DevTiles t, 
   // WC columns of one group are R*WC*16 contiguous, aligned bytes -- strided WRITES need long aligned runs on this
   // memory system -- and pass A later reads its whole tile of wt as one contiguous run.
   const int cl0 = max(cb0, s.dw0) - s.dw0, cl1 = min(cb0 + n, s.dw0 + s.qdw) - s.dw0;  // local output columns [cl0,cl1)
+  if (wc == 0) {
+    // natural layout [local column][pitch], lanes along the R rows (row-panel product of the all-to-all exchange:
+    // 1/P of the data, so the short strided write runs do not matter)
+    for (int q = threadIdx.x; q < npairs; q += T) {
+      const int r = q % R, lc = cb0 + q / R - s.dw0;
+      if (lc >= cl0 && lc < cl1 && i0 + r < s.dimup) wt[(int64_t)lc * s.pitch + i0 + r] = lds[r * ns + q / R];
+    }
+    return;
+  }
   const int g0 = cl0 / wc, g1 = (cl1 + wc - 1) / wc;
   const int per = R * wc;
   for (int q = threadIdx.x; q < (g1 - g0) * per; q += T) {
@@ -681,7 +695,8 @@ std::string make_tile_plan(const SectorHost& s, TilePlan& plan, const PlanUpload
       return "upload of tile tables failed";
     return "";
   };
-  std::string e = one(s.up, s.map_up, s.nup, o.cols_per_tile, o.force_bits_up, o.lds_budget_kb_up, o.threads_up, nullptr, true, 0,
+  static const std::vector<uint32_t> no_map;  // panel handles have no up basis: plain index chunks (pass A never runs)
+  std::string e = one(s.up, s.panel_rows > 0 ? no_map : s.map_up, s.nup, o.cols_per_tile, o.force_bits_up, o.lds_budget_kb_up, o.threads_up, nullptr, true, 0,
                       plan.up);
   if (!e.empty()) return e;
   // pass B sorts by the inner count only: its outer table is read in natural column order
@@ -705,7 +720,7 @@ int64_t tiled_pass_up_workgroups(const DevSector& s, const TilePlan& plan) {
 }
 
 hipError_t launch_hxv_tiled(const DevSector& s, const TilePlan& plan, const double2* v, double2* wt, double2* hv, hipStream_t st,
-                            const LzEpilogue* lz) {
+                            const LzEpilogue* lz, int only_pass, bool wt_natural) {
   // wt: scratch of tiled_wt_elems() elements (dw-hop part, column-group-blocked), owned by the handle
   if (s.qdw == 0) return hipSuccess;
   DevTiles tu{plan.up.d_start, plan.up.d_perm, plan.up.d_gstart, plan.up.d_gmax, plan.up.d_ell_in, plan.up.d_ell_out,
@@ -715,20 +730,21 @@ hipError_t launch_hxv_tiled(const DevSector& s, const TilePlan& plan, const doub
               plan.d_scoef_dw, plan.dw.d_bh_ptr, plan.dw.d_bh, plan.dw.d_rs_ptr, plan.dw.d_rs_off, plan.dw.d_rs_tab,
               plan.dw.nblocks, 2 * plan.ncoef_dw + 1, plan.opt.debug};
   const int C = plan.opt.cols_per_tile, R = plan.opt.rows_per_tile;
-  const int wc = std::max(C, plan.opt.wt_cols);  // columns per group of the wt scratch (a multiple of C)
+  const int wc = wt_natural ? 0 : std::max(C, plan.opt.wt_cols);  // columns per group of the wt scratch; 0 = natural layout
+  const int passes = only_pass ? only_pass : plan.opt.passes;
   const int lds_a = std::max((plan.up.max_block * C + tu.nscoef) * 16, plan.opt.lds_min_kb_up * 1024);
   const int lds_b = std::max(((((plan.dw.max_block + 15) & ~15) + 16 / R) * R + td.nscoef) * 16, plan.opt.lds_min_kb_dw * 1024);
   const int ta = plan.opt.threads_up, tb = plan.opt.threads_dw;
   const bool norb1 = s.diag.mode == 0 && s.diag.cross.norb == 1;
   hipError_t e = hipSuccess;
-  if (plan.opt.passes & 2) switch (R) {
+  if (passes & 2) switch (R) {
       case 2: e = launch_dw<2>(s, td, plan.dw.max_block, lds_b, tb, wc, v, wt, st); break;
       case 4: e = launch_dw<4>(s, td, plan.dw.max_block, lds_b, tb, wc, v, wt, st); break;
       default: e = launch_dw<8>(s, td, plan.dw.max_block, lds_b, tb, wc, v, wt, st); break;
     }
   if (e != hipSuccess) return e;
-  const double2* wta = (plan.opt.passes & 2) ? wt : nullptr;
-  if (plan.opt.passes & 1) switch (C) {
+  const double2* wta = ((passes & 2) || only_pass == 1) ? wt : nullptr;
+  if (passes & 1) switch (C) {
       case 2: e = launch_up<2>(s, tu, lds_a, ta, norb1, wc, v, wta, hv, lz, st); break;
       case 4: e = launch_up<4>(s, tu, lds_a, ta, norb1, wc, v, wta, hv, lz, st); break;
       default: e = launch_up<8>(s, tu, lds_a, ta, norb1, wc, v, wta, hv, lz, st); break;

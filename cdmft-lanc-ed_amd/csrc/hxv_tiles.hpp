@@ -87,6 +87,6 @@ struct PlanUploader {
 };
 std::string make_tile_plan(const SectorHost& s, TilePlan& plan, const PlanUploader& up);
 hipError_t launch_hxv_tiled(const DevSector& s, const TilePlan& plan, const double2* v_full, double2* wt_scratch, double2* hv_local,
-                            hipStream_t st, const LzEpilogue* lz = nullptr);
+                            hipStream_t st, const LzEpilogue* lz = nullptr, int only_pass = 0, bool wt_natural = false);
 
 }  // namespace hxv

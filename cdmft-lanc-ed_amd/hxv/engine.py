@@ -40,7 +40,7 @@ class _Stats(C.Structure):
 
 # every symbol include/hxv.h declares (tests check that the library exports all of them)
 EXPORTS = [
-    "hxv_create_from_model", "hxv_create_from_csr", "hxv_destroy", "hxv_vecdim", "hxv_dims", "hxv_apply_host",
+    "hxv_create_from_model", "hxv_create_from_csr", "hxv_create_dw_panel", "hxv_apply_dw_panel", "hxv_apply_up_add", "hxv_destroy", "hxv_vecdim", "hxv_dims", "hxv_apply_host",
     "hxv_apply_device", "hxv_fullvec_elems", "hxv_localvec_elems", "hxv_pitch", "hxv_time_apply", "hxv_lanczos_tridiag", "hxv_lanczos_eigh", "hxv_lanczos_tridiag_host", "hxv_lanczos_eigh_host", "hxv_time_lanczos", "hxv_apply_ladder", "hxv_get_maps",
     "hxv_nnz", "hxv_get_csr", "hxv_get_diag", "hxv_set_option", "hxv_get_option", "hxv_get_stats", "hxv_last_error",
     "hxv_version",
@@ -66,6 +66,9 @@ def load_library():
     pd, pi32, pi64 = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
     L.hxv_create_from_model.argtypes = [C.POINTER(_Model), i32, i32, i32, i32, i32, C.POINTER(vp)]
     L.hxv_create_from_csr.argtypes = [i32, i32, pi64, pi32, pd, pi64, pi32, pd, pd, i32, i32, i32, C.POINTER(vp)]
+    L.hxv_create_dw_panel.argtypes = [C.POINTER(_Model), i32, i32, i32, i32, C.POINTER(vp)]
+    L.hxv_apply_dw_panel.argtypes = [vp, vp, vp, vp]
+    L.hxv_apply_up_add.argtypes = [vp, vp, vp, vp, vp]
     L.hxv_destroy.argtypes = [vp]
     L.hxv_vecdim.argtypes = [vp]
     L.hxv_vecdim.restype = i64
@@ -130,6 +133,53 @@ class HxvSector:
         self.ncolsFull = self.fullElems // self.pitch
 
     # -- constructors ---------------------------------------------------------------------
+    @staticmethod
+    def _model_struct(model):
+        m = _Model()
+        m.nlat, m.norb, m.nspin, m.nbath = model.Nlat, model.Norb, model.Nspin, model.Nbath
+        m.hfmode = int(bool(model.hfmode))
+        for i in range(5):
+            m.uloc[i] = float(model.Uloc[i])
+        m.ust, m.jh, m.jx, m.jp, m.xmu = float(model.Ust), float(model.Jh), float(model.Jx), float(model.Jp), float(model.xmu)
+        h = np.ascontiguousarray(model.impHloc.ravel(order="F")).view(np.float64)
+        hb = np.ascontiguousarray(model.Hbath.ravel(order="F")).view(np.float64)
+        vb = np.ascontiguousarray(model.Vbath.ravel(order="F"))
+        m.imphloc = h.ctypes.data
+        m.hbath = hb.ctypes.data if model.Nbath > 0 else None
+        m.vbath = vb.ctypes.data if model.Nbath > 0 else None
+        return m, (h, hb, vb)
+
+    @classmethod
+    def dw_panel(cls, model, nup: int, ndw: int, nrows: int, device: int = 0) -> "HxvSector":
+        """Handle for a row panel [nrows x DimDw] (dw hops only): the middle step of the all-to-all exchange."""
+        L = load_library()
+        m, keep = cls._model_struct(model)
+        out = C.c_void_p()
+        _chk(L.hxv_create_dw_panel(C.byref(m), nup, ndw, nrows, device, C.byref(out)), "hxv_create_dw_panel")
+        return cls(out, keep=keep)
+
+    def apply_dw_panel(self, x, y=None):
+        """y = x H_dw^T on a panel handle; x, y: [DimDw columns][pitch] torch complex128 CUDA tensors."""
+        import torch
+
+        assert x.is_cuda and x.dtype == torch.complex128 and x.is_contiguous() and x.numel() == self.localElems
+        if y is None:
+            y = torch.zeros(self.localElems, dtype=torch.complex128, device=x.device)
+        st = torch.cuda.current_stream(x.device).cuda_stream
+        _chk(load_library().hxv_apply_dw_panel(self._h, x.data_ptr(), y.data_ptr(), st), "hxv_apply_dw_panel")
+        return y
+
+    def apply_up_add(self, v_local, w, hv_local=None):
+        """hv_local = D.v + H_up v + w on the local slab; all three [qdw columns][pitch]."""
+        import torch
+
+        assert v_local.is_cuda and v_local.numel() == self.localElems and w.numel() == self.localElems
+        if hv_local is None:
+            hv_local = torch.zeros(self.localElems, dtype=torch.complex128, device=v_local.device)
+        st = torch.cuda.current_stream(v_local.device).cuda_stream
+        _chk(load_library().hxv_apply_up_add(self._h, v_local.data_ptr(), w.data_ptr(), hv_local.data_ptr(), st), "hxv_apply_up_add")
+        return hv_local
+
     @classmethod
     def from_model(cls, model, nup: int, ndw: int, rank: int = 0, nranks: int = 1, device: int = 0) -> "HxvSector":
         L = load_library()

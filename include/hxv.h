@@ -100,6 +100,20 @@ int64_t hxv_fullvec_elems(const hxv_handle *h);
 int64_t hxv_localvec_elems(const hxv_handle *h);
 int32_t hxv_pitch(const hxv_handle *h);
 
+/* ---- the two halves of the product, for the reference's own all-to-all exchange (ED_HAMILTONIAN_SPARSE_HxV.f90:272-296)
+ * instead of the all-gather: rank r first receives the row panel X = v[rows U_r, ALL columns] (rows split like the
+ * columns, mpiQup :274-275), computes Y = X H_dw^T with a PANEL handle, sends Y's column ranges back to their owners, and
+ * finishes with  hv = D.v + H_up v + (assembled dw part)  on its own slab.  Each transpose moves (P-1)/P of a slab
+ * instead of (P-1) slabs.
+ * hxv_create_dw_panel : handle for a panel of `nrows` rows (dw-only: no basis/H_up/diagonal for the up index);
+ *                       vectors are [DimDw columns][pitch = roundup8(nrows)].
+ * hxv_apply_dw_panel  : d_y = d_x H_dw^T, same layout in and out.
+ * hxv_apply_up_add    : d_hv_local = D.v + H_up v + d_w on the local slab; d_v_local and d_w are [qdw columns][pitch]
+ *                       (d_v_local = this rank's slab only -- no gathered vector); not available with spH0nd (Jx/Jp). */
+int hxv_create_dw_panel(const hxv_model *model, int32_t nup, int32_t ndw, int32_t nrows, int32_t device, hxv_handle **out);
+int hxv_apply_dw_panel(hxv_handle *panel, const void *d_x, void *d_y, void *stream);
+int hxv_apply_up_add(hxv_handle *h, const void *d_v_local, const void *d_w, void *d_hv_local, void *stream);
+
 /* Time `nrep` back-to-back device products with HIP events recorded on the stream the
  * kernels are launched on; returns the mean milliseconds per product.                    */
 int hxv_time_apply(hxv_handle *h, const void *d_v_full, void *d_hv_local, int32_t nrep, float *ms_per_apply);

@@ -254,3 +254,42 @@ def test_edcontext_mirrors_reference_interface(built):
         ctx.spHtimesV_p(ctx.Dim - 1, v[:-1].copy(), hv[:-1].copy())   # Nloc /= Dim
     ctx.delete_Hv_sector()
     assert ctx.spHtimesV_p is None and not ctx.Hstatus
+
+
+@pytest.mark.parametrize("P", [2, 3])
+def test_alltoall_halves_reproduce_the_product(built, P):
+    """hxv_apply_dw_panel + hxv_apply_up_add (the two halves used by the all-to-all exchange), all 'ranks' emulated on
+    one GPU: row panels X_r = v[rows U_r, all columns] -> Y_r = X_r H_dw^T -> columns back to their owners ->
+    hv_slab = D.v + H_up v + Y[:, slab].  Must equal the oracle's full product."""
+    import torch
+    import hxv
+    from hxv import models, dw_split
+    from oracle.oracle import OracleSector
+
+    for m, (nup, ndw) in ((models.hm_2dsquare(Nbath=1), (4, 3)), (models.bhz_2d(Nbath=0, Ust=0.4, Jh=0.1), (3, 5))):
+        orc = OracleSector(m, nup, ndw)
+        du, dd = orc.DimUp, orc.DimDw
+        v = models.deterministic_vector(orc.Dim)
+        ref = orc.spMatVec_main(v)
+        V = torch.from_numpy(v.reshape(dd, du)).cuda()          # [column][row]
+        Y = torch.zeros_like(V)                                   # (v H_dw^T) assembled from the panels
+        for r in range(P):
+            nr, u0 = dw_split(du, r, P)                           # row range of rank r: same rule as the column split
+            pan = hxv.HxvSector.dw_panel(m, nup, ndw, nr)
+            assert pan.DimUp == nr and pan.localElems == dd * pan.pitch
+            x = torch.zeros(dd, pan.pitch, dtype=torch.complex128, device="cuda")
+            x[:, :nr] = V[:, u0:u0 + nr]
+            y = pan.apply_dw_panel(x.reshape(-1)).view(dd, pan.pitch)
+            Y[:, u0:u0 + nr] = y[:, :nr]
+            pan.close()
+        for r in range(P):
+            sec = hxv.HxvSector.from_model(m, nup, ndw, rank=r, nranks=P)
+            q, c0 = sec.mpiQdw, sec.mpiIshift // du
+            vl = torch.zeros(q, sec.pitch, dtype=torch.complex128, device="cuda")
+            wl = torch.zeros_like(vl)
+            vl[:, :du] = V[c0:c0 + q]
+            wl[:, :du] = Y[c0:c0 + q]
+            hv = sec.apply_up_add(vl.reshape(-1), wl.reshape(-1)).view(q, sec.pitch)[:, :du].reshape(-1)
+            torch.cuda.synchronize()
+            assert _rel(hv.cpu().numpy(), ref[sec.mpiIshift: sec.mpiIshift + sec.vecDim]) <= TOL, (m.name, P, r)
+            sec.close()
