@@ -69,6 +69,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lanczos", action="store_true", help="also time full Lanczos iterations (N=1)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 path on one GPU)")
+    ap.add_argument("--exchange", default="allgather", choices=["allgather", "alltoall"],
+                    help="N>1: allgather = one RCCL all-gather per product (BASELINE's mandated exchange, default); "
+                         "alltoall = the reference's own two transposes per product (lower traffic)")
     ap.add_argument("--check", action="store_true", help="N>1 rehearsal: verify the sharded product against the unsharded one on rank 0")
     args = ap.parse_args()
 
@@ -109,9 +112,17 @@ def main():
     v_local = torch.randn(Nloc, dtype=torch.float64, device=dev, generator=g) + 1j * torch.randn(Nloc, dtype=torch.float64, device=dev, generator=g)
     hv_local = torch.empty(Nloc, dtype=torch.complex128, device=dev)
     sh = hxv.ShardedHxv(sec.DimUp, sec.DimDw, rank, world, sec.apply_device, pitch=sec.pitch)
+    if world > 1 and args.exchange == "alltoall":
+        nrows = hxv.dw_split(sec.DimUp, rank, world)[0]
+        panel = hxv.HxvSector.dw_panel(model, nup, ndw, nrows, device=local_rank)
+        th = hxv.TransposedHxv(sec.DimUp, sec.DimDw, rank, world, panel.apply_dw_panel, sec.apply_up_add, pitch=sec.pitch,
+                               pitch_panel=panel.pitch, stage_on_host=(args.backend != "nccl"))
 
     def step():
-        sh(Nloc, v_local, hv_local)
+        if world > 1 and args.exchange == "alltoall":
+            th(Nloc, v_local, hv_local)
+        else:
+            sh(Nloc, v_local, hv_local)
 
     if args.check and world > 1:
         # rehearsal: every rank's slab of the sharded product == the same slab of the unsharded product
@@ -166,7 +177,8 @@ def main():
            "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "complex128 (f64)", "data": "synthetic",
            "config": {"workload": f"{args.workload}: {model.name} sector ({nup},{ndw}) Dim={Dim}", "DimUp": sec.DimUp, "DimDw": sec.DimDw,
-                      "parallelism": f"DimDw split x{world}" + (" + RCCL allgather per product" if world > 1 else ""),
+                      "parallelism": f"DimDw split x{world}" + ((" + RCCL allgather per product" if args.exchange == "allgather"
+                                                                 else " + 2 RCCL all-to-all transposes per product") if world > 1 else ""),
                       "matvecs_per_s": round(1e3 / ms_step, 2)},
            "roofline": roofline}
     if args.lanczos and world == 1:

@@ -73,3 +73,58 @@ def test_sharded_product_gloo(world, sector, tmp_path):
     ref = s.spMatVec_main(models.deterministic_vector(s.Dim))
     got = np.concatenate([np.load(tmp_path / f"hv_{r}.npy") for r in range(world)])
     assert np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max()
+
+
+def _worker_a2a(rank, world, port, nup, ndw, out):
+    import torch
+    import torch.distributed as dist
+    import scipy.sparse as sp
+    import hxv
+    from hxv import models
+    from oracle.oracle import OracleSector
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = models.hm_1dchain(Nlat=2, Nbath=2, eps_bath=[0.3, 0.6])
+    orc = OracleSector(m, nup, ndw, rank, world)
+    du, dd = orc.DimUp, orc.DimDw
+    rp, cols, vals = orc.csr("up")
+    Hup = sp.csr_matrix((vals, cols - 1, rp), shape=(du, du))
+    rp, cols, vals = orc.csr("dw")
+    Hdw = sp.csr_matrix((vals, cols - 1, rp), shape=(dd, dd))
+    c0 = orc.mpiIshift // du
+
+    def apply_panel(x):      # CPU stand-in for HxvSector.apply_dw_panel: Y = X H_dw^T on [DimDw x nrows]
+        X = x.numpy().reshape(dd, -1)
+        return torch.from_numpy(np.ascontiguousarray(Hdw @ X).reshape(-1))
+
+    def apply_up_add(v_local, w, hv_local):   # CPU stand-in for HxvSector.apply_up_add
+        Vl = v_local.numpy().reshape(orc.mpiQdw, du)
+        res = orc.diag().reshape(orc.mpiQdw, du) * Vl + (Hup @ Vl.T).T + w.numpy().reshape(orc.mpiQdw, du)
+        hv_local.copy_(torch.from_numpy(np.ascontiguousarray(res).reshape(-1)))
+        return hv_local
+
+    th = hxv.TransposedHxv(du, dd, rank, world, apply_panel, apply_up_add)
+    v_full = models.deterministic_vector(orc.Dim)
+    v_local = torch.from_numpy(v_full[orc.mpiIshift: orc.mpiIshift + orc.vecDim].copy())
+    hv_local = torch.empty(orc.vecDim, dtype=torch.complex128)
+    th(th.Nloc, v_local, hv_local)
+    np.save(os.path.join(out, f"hv_{rank}.npy"), hv_local.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,sector", [(2, (3, 3)), (3, (3, 2)), (3, (2, 4))])
+def test_transposed_exchange_gloo(world, sector, tmp_path):
+    """The all-to-all exchange (the reference's own scheme) with uneven row and column splits."""
+    import torch.multiprocessing as mp
+    from hxv import models
+    from oracle.oracle import OracleSector
+
+    nup, ndw = sector
+    mp.spawn(_worker_a2a, args=(world, _free_port(), nup, ndw, str(tmp_path)), nprocs=world, join=True)
+    m = models.hm_1dchain(Nlat=2, Nbath=2, eps_bath=[0.3, 0.6])
+    s = OracleSector(m, nup, ndw)
+    ref = s.spMatVec_main(models.deterministic_vector(s.Dim))
+    got = np.concatenate([np.load(tmp_path / f"hv_{r}.npy") for r in range(world)])
+    assert np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max()
