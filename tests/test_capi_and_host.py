@@ -110,3 +110,34 @@ def test_model_arrays_follow_reference_layout():
         assert np.abs(hl - hl.conj().T).max() == 0
     v = models.deterministic_vector(5, offset=3)
     assert np.allclose(v[0], np.sin(0.37 * 3 + 0.11) + 1j * np.cos(0.23 * 3 + 0.05))
+
+
+def test_create_from_csr_validates_before_touching_the_device(built):
+    import hxv
+
+    rp = np.array([0, 1, 2], dtype=np.int64)
+    ok_cols = np.array([2, 1], dtype=np.int32)
+    vals = np.array([1.0 + 0j, 1.0 + 0j])
+    diag = np.zeros(4, dtype=np.complex128)
+    with pytest.raises(hxv.HxvError, match=r"column index outside"):
+        hxv.HxvSector.from_csr(2, 2, (rp, np.array([3, 1], dtype=np.int32), vals), (rp, ok_cols, vals), diag)
+    with pytest.raises(hxv.HxvError, match=r"rowptr"):
+        hxv.HxvSector.from_csr(2, 2, (np.array([1, 1, 2], dtype=np.int64), ok_cols, vals), (rp, ok_cols, vals), diag)
+    with pytest.raises(hxv.HxvError, match=r"complex diagonal"):
+        hxv.HxvSector.from_csr(2, 2, (rp, ok_cols, vals), (rp, ok_cols, vals), diag + 1j)
+    with pytest.raises(hxv.HxvError, match=r"rank"):
+        hxv.HxvSector.from_csr(2, 2, (rp, ok_cols, vals), (rp, ok_cols, vals), diag, rank=0, nranks=3)
+
+
+def test_model_validation_messages(built):
+    import hxv
+    from hxv import models
+
+    m = models.plaquette_2x2_nobath()
+    m2 = models.Model(4, 1, 1, 0, m.impHloc + 1j * np.eye(4).reshape(4, 4, 1, 1, 1, 1), m.Hbath, m.Vbath)
+    with pytest.raises(hxv.HxvError, match="complex diagonal"):
+        hxv.HxvSector.from_model(m2, 2, 2)
+    with pytest.raises(hxv.HxvError, match="nranks > DimDw"):
+        hxv.HxvSector.from_model(m, 2, 4, rank=0, nranks=2)      # DimDw = 1: shrink the communicator first
+    with pytest.raises(hxv.HxvError, match="panel_rows|nrows"):
+        hxv.HxvSector.dw_panel(m, 2, 2, 100)                      # more rows than DimUp
