@@ -11,66 +11,21 @@
 
 using namespace hxv;
 
+#include "hxv_handle.hpp"
+
+namespace hxv {
 namespace {
 thread_local std::string g_err;
+}
 int fail(int code, const std::string& msg) {
   g_err = msg;
   return code;
 }
-#define HIPCHK(expr)                                                                                   \
-  do {                                                                                                 \
-    hipError_t _e = (expr);                                                                            \
-    if (_e != hipSuccess)                                                                              \
-      return fail(HXV_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));                     \
-  } while (0)
-}  // namespace
-
-struct hxv_handle {
-  SectorHost host;
-  int device = 0;
-  hipStream_t stream = nullptr;
-  std::vector<void*> allocs;
-  DevSector dev{};
-  TilePlan plan;
-  // staging for hxv_apply_host
-  double2* d_stage_v = nullptr;
-  double2* d_stage_hv = nullptr;
-  double2* d_wt = nullptr;  // dw-hop scratch of the tiled kernels (column-group-blocked, tiled_wt_elems())
-  int64_t wt_elems = 0;
-  // lanczos scratch
-  double* d_partials = nullptr;  // [2][RED_BLOCKS]
-  double* d_scalars = nullptr;   // [8]
-  double2* d_lz[3] = {nullptr, nullptr, nullptr};
-  double* d_lz_partial = nullptr;  // per-workgroup partial sums of the fused Lanczos epilogue
-  int64_t lz_partial_n = 0;
-  int lz_fused = 1;                // option "lanczos_fused"
-  int kernel = 1;
-  int64_t n_apply = 0;
-  int64_t device_bytes = 0;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-
-  template <typename T>
-  hipError_t alloc(T** p, size_t n) {
-    size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
-    hipError_t e = hipMalloc((void**)p, bytes);
-    if (e == hipSuccess) {
-      allocs.push_back((void*)*p);
-      device_bytes += (int64_t)bytes;
-    }
-    return e;
-  }
-  template <typename T>
-  hipError_t upload(T** p, const std::vector<T>& src) {
-    hipError_t e = alloc(p, src.size());
-    if (e != hipSuccess) return e;
-    if (!src.empty()) e = hipMemcpy(*p, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice);
-    return e;
-  }
-};
+}  // namespace hxv
 
 namespace {
 
-constexpr int RED_BLOCKS = 1024;
+
 
 int ensure_wt(hxv_handle* h) {
   const int64_t need = std::max<int64_t>(tiled_wt_elems(h->dev, h->plan), 1);

@@ -1,0 +1,417 @@
+// hxv_eigh_lowest: the `neigen` lowest eigenpairs of the open sector, entirely on the device.
+//
+// It stands where the reference calls SciFortran's sp_eigh (P-ARPACK: implicitly restarted Lanczos with a
+// Krylov basis of Nblock = ncv vectors) at ED_DIAG.f90:152-160.  Thick-restart Lanczos (Wu & Simon 2000) is
+// the explicit-restart form of the same method for Hermitian operators: build the basis up to ncv vectors
+// with full re-orthogonalisation (classical Gram-Schmidt + one DGKS refinement when the norm drops, as
+// ARPACK does), diagonalise the small projected matrix on the host, keep the lowest Ritz vectors by a
+// tall-skinny rotation of the basis in place, continue.  Convergence test = ARPACK's:
+// |beta_m * s_mi| <= tol * max(eps^(2/3), |theta_i|).
+//
+// Everything Dim-sized stays in HBM: ncv+1 basis vectors (C3, ncv=20: 56 GB of the 288 GB).  The vector
+// kernels are plain streaming kernels (HBM-bound); per Lanczos step they read the j+1 basis vectors twice
+// (multi-dot, multi-axpy), which dominates the HxV itself -- the same trade ARPACK makes on the host.
+#include <cmath>
+#include <cstring>
+
+#include "hxv_handle.hpp"
+
+using namespace hxv;
+
+namespace {
+
+constexpr int JB = 8;       // basis vectors per multi-dot pass (w is re-read once per JB vectors)
+constexpr int TR_BLOCKS = 4096;  // workgroups of the streaming kernels (16 per CU)
+constexpr int MAXCV = 64;   // largest Krylov basis (the rotation keeps one element of every vector in registers)
+
+__device__ inline double wave_sum(double x) {
+  for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+  return x;
+}
+
+// partial[blockIdx][2*j..2*j+1] = sum_i conj(V_j[i]) * w[i]   for j < nb (nb <= JB)
+__global__ void __launch_bounds__(256) tr_mdot(int64_t n, const double2* __restrict__ V, int64_t stride, int nb,
+                                               const double2* __restrict__ w, double* __restrict__ partial) {
+  double re[JB], im[JB];
+#pragma unroll
+  for (int j = 0; j < JB; ++j) re[j] = im[j] = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const double2 x = w[i];
+#pragma unroll
+    for (int j = 0; j < JB; ++j)
+      if (j < nb) {
+        const double2 y = V[(int64_t)j * stride + i];
+        re[j] += y.x * x.x + y.y * x.y;
+        im[j] += y.x * x.y - y.y * x.x;
+      }
+  }
+  __shared__ double red[4][2 * JB];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int j = 0; j < JB; ++j) {
+    const double a = wave_sum(re[j]), b = wave_sum(im[j]);
+    if (lane == 0) {
+      red[wave][2 * j] = a;
+      red[wave][2 * j + 1] = b;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * JB)
+    partial[(int64_t)blockIdx.x * 2 * JB + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// out[t] = sum_b partial[b][t]  (t < nval), partial rows of `ld` values
+__global__ void __launch_bounds__(256) tr_colsum(const double* __restrict__ partial, int nblocks, int ld, int nval, double* __restrict__ out) {
+  __shared__ double red[256];
+  for (int t = 0; t < nval; ++t) {
+    double acc = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) acc += partial[(int64_t)b * ld + t];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out[t] = red[0];
+    __syncthreads();
+  }
+}
+
+// w -= sum_{j<nj} c_j V_j ; partial[blockIdx] = sum |w|^2
+__global__ void __launch_bounds__(256) tr_maxpy(int64_t n, const double2* __restrict__ V, int64_t stride, int nj,
+                                                const double* __restrict__ coef, double2* __restrict__ w, double* __restrict__ partial) {
+  __shared__ double sc[2 * (MAXCV + 1)];
+  for (int t = threadIdx.x; t < 2 * nj; t += 256) sc[t] = coef[t];
+  __syncthreads();
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    double2 x = w[i];
+#pragma unroll 4
+    for (int j = 0; j < nj; ++j) {
+      const double2 y = V[(int64_t)j * stride + i];
+      const double cr = sc[2 * j], ci = sc[2 * j + 1];
+      x.x -= cr * y.x - ci * y.y;
+      x.y -= cr * y.y + ci * y.x;
+    }
+    w[i] = x;
+    acc += x.x * x.x + x.y * x.y;
+  }
+  __shared__ double red[4];
+  const double a = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// x *= r ; also usable for the norm alone (r == 1 skips the store)
+__global__ void __launch_bounds__(256) tr_scale_nrm(int64_t n, double2* __restrict__ x, double r, double* __restrict__ partial) {
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    double2 a = x[i];
+    acc += a.x * a.x + a.y * a.y;
+    if (r != 1.0) x[i] = make_double2(a.x * r, a.y * r);
+  }
+  __shared__ double red[4];
+  const double a = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0 && partial) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// deterministic start vector (same hash as the single-vector Lanczos in hxv_capi.hip): pad rows stay zero
+__global__ void __launch_bounds__(256) tr_init(int64_t n, double2* __restrict__ q, uint64_t seed, int dimup, int pitch) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t col = i / pitch;
+    const int row = (int)(i - col * pitch);
+    if (row >= dimup) {
+      q[i] = make_double2(0.0, 0.0);
+      continue;
+    }
+    const uint64_t z = (uint64_t)(col * dimup + row) * 2 + seed;
+    double r[2];
+    for (int k = 0; k < 2; ++k) {
+      uint64_t x = z + (uint64_t)k + 0x9E3779B97F4A7C15ull;
+      x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+      x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+      x = x ^ (x >> 31);
+      r[k] = (double)(x >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+    }
+    q[i] = make_double2(r[0], r[1]);
+  }
+}
+
+// In-place basis rotation  V[:, 0..k) <- V[:, 0..m) * S  (S real m x k, column-major S[l + j*m]).
+// Each thread keeps one element of all m vectors in registers, so every vector is read once and the
+// first k are written once: (m + k) vector passes instead of m*k.
+template <int MAXM>
+__global__ void __launch_bounds__(256) tr_rotate(int64_t n, double2* __restrict__ V, int64_t stride, int m, int k,
+                                                 const double* __restrict__ S) {
+  __shared__ double sS[MAXM * MAXM];
+  for (int t = threadIdx.x; t < m * k; t += 256) sS[t] = S[t];
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    double2 x[MAXM];
+#pragma unroll
+    for (int l = 0; l < MAXM; ++l)
+      if (l < m) x[l] = V[(int64_t)l * stride + i];
+    for (int j = 0; j < k; ++j) {
+      double yr = 0.0, yi = 0.0;
+#pragma unroll
+      for (int l = 0; l < MAXM; ++l)
+        if (l < m) {
+          const double s = sS[l + j * m];
+          yr += s * x[l].x;
+          yi += s * x[l].y;
+        }
+      V[(int64_t)j * stride + i] = make_double2(yr, yi);
+    }
+  }
+}
+
+void launch_rotate(int grid, hipStream_t st, int64_t n, double2* V, int64_t stride, int m, int k, const double* S) {
+  if (m <= 8)
+    hipLaunchKernelGGL(tr_rotate<8>, dim3(grid), dim3(256), 0, st, n, V, stride, m, k, S);
+  else if (m <= 16)
+    hipLaunchKernelGGL(tr_rotate<16>, dim3(grid), dim3(256), 0, st, n, V, stride, m, k, S);
+  else if (m <= 32)
+    hipLaunchKernelGGL(tr_rotate<32>, dim3(grid), dim3(256), 0, st, n, V, stride, m, k, S);
+  else
+    hipLaunchKernelGGL(tr_rotate<MAXCV>, dim3(grid), dim3(256), 0, st, n, V, stride, m, k, S);
+}
+
+// Cyclic Jacobi for a small dense real symmetric matrix (column-major n x n in A, destroyed).
+// On exit w = eigenvalues ascending, Z[:, i] = eigenvector i.
+bool jacobi_eigh(int n, std::vector<double>& A, std::vector<double>& w, std::vector<double>& Z) {
+  Z.assign((size_t)n * n, 0.0);
+  for (int i = 0; i < n; ++i) Z[i + (size_t)i * n] = 1.0;
+  auto a = [&](int i, int j) -> double& { return A[i + (size_t)j * n]; };
+  double scale = 0.0;
+  for (double x : A) scale = std::max(scale, std::fabs(x));
+  if (scale == 0.0) scale = 1.0;
+  bool done = false;
+  for (int sweep = 0; sweep < 100 && !done; ++sweep) {
+    double off = 0.0;
+    for (int p = 0; p < n; ++p)
+      for (int q = p + 1; q < n; ++q) off += a(p, q) * a(p, q);
+    if (std::sqrt(off) <= 1e-15 * scale) {
+      done = true;
+      break;
+    }
+    for (int p = 0; p < n - 1; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        const double apq = a(p, q);
+        if (std::fabs(apq) <= 1e-300) continue;
+        const double tau = (a(q, q) - a(p, p)) / (2.0 * apq);
+        const double t = (tau >= 0 ? 1.0 : -1.0) / (std::fabs(tau) + std::sqrt(1.0 + tau * tau));
+        const double c = 1.0 / std::sqrt(1.0 + t * t), s = t * c;
+        for (int r = 0; r < n; ++r) {  // columns p, q
+          const double arp = a(r, p), arq = a(r, q);
+          a(r, p) = c * arp - s * arq;
+          a(r, q) = s * arp + c * arq;
+        }
+        for (int r = 0; r < n; ++r) {  // rows p, q
+          const double apr = a(p, r), aqr = a(q, r);
+          a(p, r) = c * apr - s * aqr;
+          a(q, r) = s * apr + c * aqr;
+        }
+        a(p, q) = a(q, p) = 0.0;
+        for (int r = 0; r < n; ++r) {
+          const double zrp = Z[r + (size_t)p * n], zrq = Z[r + (size_t)q * n];
+          Z[r + (size_t)p * n] = c * zrp - s * zrq;
+          Z[r + (size_t)q * n] = s * zrp + c * zrq;
+        }
+      }
+  }
+  std::vector<int> idx(n);
+  for (int i = 0; i < n; ++i) idx[i] = i;
+  std::sort(idx.begin(), idx.end(), [&](int x, int y) { return a(x, x) < a(y, y); });
+  w.resize(n);
+  std::vector<double> Zs((size_t)n * n);
+  for (int i = 0; i < n; ++i) {
+    w[i] = a(idx[i], idx[i]);
+    std::memcpy(&Zs[(size_t)i * n], &Z[(size_t)idx[i] * n], (size_t)n * sizeof(double));
+  }
+  Z.swap(Zs);
+  return done;
+}
+
+int keep_count(int m, int neigen, int nconv) {
+  int k = neigen + std::min(nconv, (m - neigen) / 2) + std::max(1, (m - neigen) / 4);
+  return std::max(1, std::min(k, m - 1));
+}
+
+struct DevFree {
+  std::vector<void*> p;
+  ~DevFree() {
+    for (void* q : p)
+      if (q) (void)hipFree(q);
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxrestart, double tol, double* evals, void* d_evecs,
+                    int32_t* nconv_out, int32_t* nmatvec_out) {
+  if (!h || !evals || neigen < 1 || maxrestart < 0) return fail(HXV_ERR_ARG, "hxv_eigh_lowest: bad argument");
+  if (h->host.nranks != 1)
+    return fail(HXV_ERR_STATE, "hxv_eigh_lowest needs nranks==1 (global dots belong to the caller's communicator)");
+  const int64_t dim = h->host.dim;
+  if (neigen > dim) return fail(HXV_ERR_ARG, "hxv_eigh_lowest: neigen > Dim");
+  if (ncv <= 0) ncv = 10 * neigen;  // the reference's default: lanc_ncv_factor=10, lanc_ncv_add=0 (ED_INPUT_VARS.f90:174-175)
+  const int m = (int)std::min<int64_t>(std::max(ncv, neigen + 1), dim);
+  if (m > MAXCV) return fail(HXV_ERR_ARG, "hxv_eigh_lowest: ncv > 64 is not supported");
+  HIPCHK(hipSetDevice(h->device));
+  const int64_t n = (int64_t)h->host.pitch * h->host.dimdw;  // padded local vector (pads are zero and stay zero)
+  const int g = (int)std::min<int64_t>((n + 255) / 256, TR_BLOCKS);
+  const double eps = 2.220446049250313e-16, eps23 = std::pow(eps, 2.0 / 3.0);
+  tol = std::max(tol, eps);
+
+  size_t free_b = 0, total_b = 0;
+  HIPCHK(hipMemGetInfo(&free_b, &total_b));
+  const size_t need = (size_t)(m + 1) * (size_t)n * sizeof(double2);
+  if (need + ((size_t)n * sizeof(double2)) > free_b)
+    return fail(HXV_ERR_HIP, "hxv_eigh_lowest: the Krylov basis needs " + std::to_string(need >> 20) + " MiB of HBM for ncv=" + std::to_string(m) +
+                                 " but only " + std::to_string(free_b >> 20) + " MiB are free: lower ncv or use hxv_lanczos_eigh (3 vectors)");
+  DevFree mem;
+  double2* V = nullptr;
+  double *d_part = nullptr, *d_coef = nullptr, *d_S = nullptr;
+  HIPCHK(hipMalloc((void**)&V, need));
+  mem.p.push_back(V);
+  HIPCHK(hipMemsetAsync(V, 0, need, h->stream));  // pad rows must be zero: the products never write them, the dots read them
+  HIPCHK(hipMalloc((void**)&d_part, (size_t)TR_BLOCKS * (2 * JB + 1) * sizeof(double)));
+  mem.p.push_back(d_part);
+  HIPCHK(hipMalloc((void**)&d_coef, (size_t)(2 * (MAXCV + 1) + 2) * sizeof(double)));
+  mem.p.push_back(d_coef);
+  HIPCHK(hipMalloc((void**)&d_S, (size_t)MAXCV * MAXCV * sizeof(double)));
+  mem.p.push_back(d_S);
+  double* d_npart = d_part + (size_t)TR_BLOCKS * 2 * JB;
+  double* d_nrm = d_coef + 2 * (MAXCV + 1);
+  hipStream_t st = h->stream;
+  auto vec = [&](int j) { return V + (int64_t)j * n; };
+
+  // start vector
+  hipLaunchKernelGGL(tr_init, dim3(g), dim3(256), 0, st, n, vec(0), (uint64_t)0x5EED5EEDull, h->host.dimup, h->host.pitch);
+  double nrm2 = 0.0;
+  hipLaunchKernelGGL(tr_scale_nrm, dim3(g), dim3(256), 0, st, n, vec(0), 1.0, d_npart);
+  hipLaunchKernelGGL(tr_colsum, dim3(1), dim3(256), 0, st, d_npart, g, 1, 1, d_nrm);
+  HIPCHK(hipMemcpyAsync(&nrm2, d_nrm, sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  hipLaunchKernelGGL(tr_scale_nrm, dim3(g), dim3(256), 0, st, n, vec(0), 1.0 / std::sqrt(nrm2), (double*)nullptr);
+
+  // one Gram-Schmidt pass of w = V[j+1] against V[0..j]: coefficients to host, returns |w|^2 after the update
+  std::vector<double> c(2 * (MAXCV + 1));
+  auto gs_pass = [&](int j, double* nrm2_after) -> int {
+    const int nj = j + 1;
+    for (int g0 = 0; g0 < nj; g0 += JB) {
+      const int nb = std::min(JB, nj - g0);
+      hipLaunchKernelGGL(tr_mdot, dim3(g), dim3(256), 0, st, n, vec(g0), n, nb, vec(j + 1), d_part);
+      hipLaunchKernelGGL(tr_colsum, dim3(1), dim3(256), 0, st, d_part, g, 2 * JB, 2 * nb, d_coef + 2 * g0);
+    }
+    hipLaunchKernelGGL(tr_maxpy, dim3(g), dim3(256), 0, st, n, V, n, nj, d_coef, vec(j + 1), d_npart);
+    hipLaunchKernelGGL(tr_colsum, dim3(1), dim3(256), 0, st, d_npart, g, 1, 1, d_nrm);
+    HIPCHK(hipMemcpyAsync(c.data(), d_coef, (size_t)2 * nj * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(nrm2_after, d_nrm, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return HXV_OK;
+  };
+
+  std::vector<double> T((size_t)m * m, 0.0), A, theta, S;
+  auto t_at = [&](int i, int j) -> double& { return T[i + (size_t)j * m]; };
+  int k = 0, nmv = 0, meff = m, nconv = 0, ne = neigen;
+  double beta_last = 0.0;
+  for (int it = 0;; ++it) {
+    meff = m;
+    beta_last = 0.0;
+    for (int j = k; j < m; ++j) {
+      int rc = hxv_apply_device(h, vec(j), vec(j + 1), st);
+      if (rc) return rc;
+      ++nmv;
+      double w2 = 0.0;
+      rc = gs_pass(j, &w2);
+      if (rc) return rc;
+      t_at(j, j) = c[2 * j];
+      double c2sum = 0.0;
+      for (int t = 0; t < 2 * (j + 1); ++t) c2sum += c[t] * c[t];
+      double nrm = std::sqrt(std::max(w2, 0.0));
+      if (w2 < 0.5 * (c2sum + w2)) {  // DGKS: the norm dropped by more than 1/sqrt(2) -> one refinement pass
+        double w3 = 0.0;
+        rc = gs_pass(j, &w3);
+        if (rc) return rc;
+        t_at(j, j) += c[2 * j];
+        double nrm_b = std::sqrt(std::max(w3, 0.0));
+        if (nrm_b < 0.5 * nrm) nrm_b = 0.0;  // w lies in span(V): invariant subspace
+        nrm = nrm_b;
+      }
+      double tscale = 1.0;
+      for (int a = 0; a <= j; ++a)
+        for (int b = 0; b <= j; ++b) tscale = std::max(tscale, std::fabs(t_at(a, b)));
+      if (nrm <= 1e-13 * tscale) {
+        meff = j + 1;
+        beta_last = 0.0;
+        break;
+      }
+      if (j + 1 < m) t_at(j + 1, j) = t_at(j, j + 1) = nrm;
+      beta_last = nrm;
+      hipLaunchKernelGGL(tr_scale_nrm, dim3(g), dim3(256), 0, st, n, vec(j + 1), 1.0 / nrm, (double*)nullptr);
+    }
+    A.assign((size_t)meff * meff, 0.0);
+    for (int a = 0; a < meff; ++a)
+      for (int b = 0; b < meff; ++b) A[a + (size_t)b * meff] = t_at(a, b);
+    if (!jacobi_eigh(meff, A, theta, S)) return fail(HXV_ERR_STATE, "hxv_eigh_lowest: projected eigenproblem did not converge");
+    ne = std::min(neigen, meff);
+    nconv = 0;
+    for (int i = 0; i < ne; ++i) {
+      const double res = std::fabs(beta_last * S[(meff - 1) + (size_t)i * meff]);
+      if (res <= tol * std::max(eps23, std::fabs(theta[i]))) ++nconv;
+    }
+    if (nconv == ne || meff < m || it >= maxrestart) break;
+    k = keep_count(m, neigen, nconv);
+    HIPCHK(hipMemcpyAsync(d_S, S.data(), (size_t)m * k * sizeof(double), hipMemcpyHostToDevice, st));
+    launch_rotate(g, st, n, V, n, m, k, d_S);
+    HIPCHK(hipMemcpyAsync(vec(k), vec(m), (size_t)n * sizeof(double2), hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));  // S (host) is reused below
+    std::fill(T.begin(), T.end(), 0.0);
+    for (int i = 0; i < k; ++i) {
+      t_at(i, i) = theta[i];
+      t_at(k, i) = t_at(i, k) = beta_last * S[(m - 1) + (size_t)i * m];
+    }
+  }
+  for (int i = 0; i < neigen; ++i) evals[i] = i < ne ? theta[i] : 0.0;
+  if (nconv_out) *nconv_out = nconv;
+  if (nmatvec_out) *nmatvec_out = nmv;
+  if (d_evecs) {
+    HIPCHK(hipMemcpyAsync(d_S, S.data(), (size_t)meff * ne * sizeof(double), hipMemcpyHostToDevice, st));
+    launch_rotate(g, st, n, V, n, meff, ne, d_S);
+    HIPCHK(hipMemcpyAsync(d_evecs, V, (size_t)ne * n * sizeof(double2), hipMemcpyDeviceToDevice, st));
+    if (ne < neigen) HIPCHK(hipMemsetAsync((double2*)d_evecs + (int64_t)ne * n, 0, (size_t)(neigen - ne) * n * sizeof(double2), st));
+  }
+  HIPCHK(hipStreamSynchronize(st));
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(HXV_ERR_HIP, std::string("hxv_eigh_lowest kernels: ") + hipGetErrorString(e));
+  return HXV_OK;
+}
+
+int hxv_eigh_lowest_host(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxrestart, double tol, double* evals, void* evecs_host,
+                         int32_t* nconv_out, int32_t* nmatvec_out) {
+  if (!h || neigen < 1) return fail(HXV_ERR_ARG, "hxv_eigh_lowest_host: bad argument");
+  if (!evecs_host) return hxv_eigh_lowest(h, neigen, ncv, maxrestart, tol, evals, nullptr, nconv_out, nmatvec_out);
+  HIPCHK(hipSetDevice(h->device));
+  const int64_t n = (int64_t)h->host.pitch * h->host.dimdw;
+  DevFree mem;
+  double2* d = nullptr;
+  HIPCHK(hipMalloc((void**)&d, (size_t)neigen * n * sizeof(double2)));
+  mem.p.push_back(d);
+  int rc = hxv_eigh_lowest(h, neigen, ncv, maxrestart, tol, evals, d, nconv_out, nmatvec_out);
+  if (rc) return rc;
+  // eig_basis(vecDim, Neigen) in the reference's layout: columns unpadded, eigenvectors consecutive (ED_DIAG.f90:145)
+  const size_t col = (size_t)h->host.dimup * sizeof(double2), pit = (size_t)h->host.pitch * sizeof(double2);
+  for (int i = 0; i < neigen; ++i)
+    HIPCHK(hipMemcpy2DAsync((char*)evecs_host + (size_t)i * h->host.dim * sizeof(double2), col, d + (int64_t)i * n, pit, col,
+                            (size_t)h->host.dimdw, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return HXV_OK;
+}
+
+}  // extern "C"

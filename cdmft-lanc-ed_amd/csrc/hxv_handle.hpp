@@ -1,0 +1,64 @@
+// The opaque handle behind include/hxv.h and the error helpers shared by the translation units
+// that implement the C-ABI (hxv_capi.hip: products + Lanczos; hxv_eigh.hip: thick-restart eigensolver).
+#pragma once
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "hxv_internal.hpp"
+#include "hxv_tiles.hpp"
+
+namespace hxv {
+int fail(int code, const std::string& msg);  // records the message hxv_last_error() returns; returns code
+constexpr int RED_BLOCKS = 1024;             // workgroups of the grid-stride reduction kernels
+}  // namespace hxv
+
+#define HIPCHK(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t _e = (expr);                                                                            \
+    if (_e != hipSuccess)                                                                              \
+      return hxv::fail(HXV_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));                \
+  } while (0)
+
+struct hxv_handle {
+  hxv::SectorHost host;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::vector<void*> allocs;
+  hxv::DevSector dev{};
+  hxv::TilePlan plan;
+  // staging for hxv_apply_host
+  double2* d_stage_v = nullptr;
+  double2* d_stage_hv = nullptr;
+  double2* d_wt = nullptr;  // dw-hop scratch of the tiled kernels (column-group-blocked, tiled_wt_elems())
+  int64_t wt_elems = 0;
+  // lanczos scratch
+  double* d_partials = nullptr;  // [2][RED_BLOCKS]
+  double* d_scalars = nullptr;   // [8]
+  double2* d_lz[3] = {nullptr, nullptr, nullptr};
+  double* d_lz_partial = nullptr;  // per-workgroup partial sums of the fused Lanczos epilogue
+  int64_t lz_partial_n = 0;
+  int lz_fused = 1;                // option "lanczos_fused"
+  int kernel = 1;
+  int64_t n_apply = 0;
+  int64_t device_bytes = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+  template <typename T>
+  hipError_t alloc(T** p, size_t n) {
+    size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    hipError_t e = hipMalloc((void**)p, bytes);
+    if (e == hipSuccess) {
+      allocs.push_back((void*)*p);
+      device_bytes += (int64_t)bytes;
+    }
+    return e;
+  }
+  template <typename T>
+  hipError_t upload(T** p, const std::vector<T>& src) {
+    hipError_t e = alloc(p, src.size());
+    if (e != hipSuccess) return e;
+    if (!src.empty()) e = hipMemcpy(*p, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice);
+    return e;
+  }
+};

@@ -19,6 +19,7 @@ module ED_HAMILTONIAN_GPU_HXV
   public :: gpu_lanc_tridiag_host
   public :: gpu_sp_lanc_tridiag
   public :: gpu_sp_lanc_eigh
+  public :: gpu_sp_eigh
 
   !> mirrors struct hxv_model of include/hxv.h
   type, bind(C) :: hxv_model
@@ -69,6 +70,15 @@ module ED_HAMILTONIAN_GPU_HXV
        complex(c_double_complex)            :: vect(*)
        integer(c_int32_t)                   :: niter
      end function hxv_lanczos_eigh_host
+     integer(c_int) function hxv_eigh_lowest_host(h,neigen,ncv,maxrestart,tol,evals,evecs,nconv,nmatvec) bind(C,name="hxv_eigh_lowest_host")
+       import :: c_int, c_int32_t, c_ptr, c_double, c_double_complex
+       type(c_ptr),value                    :: h
+       integer(c_int32_t),value             :: neigen,ncv,maxrestart
+       real(c_double),value                 :: tol
+       real(c_double)                       :: evals(*)
+       complex(c_double_complex)            :: evecs(*)
+       integer(c_int32_t)                   :: nconv,nmatvec
+     end function hxv_eigh_lowest_host
      type(c_ptr) function hxv_last_error() bind(C,name="hxv_last_error")
        import :: c_ptr
      end function hxv_last_error
@@ -228,5 +238,32 @@ contains
        if(iverbose)write(*,"(A,I6,A,F20.12)")"gpu_sp_lanc_eigh: iterations=",niter," E0=",egs
     endif
   end subroutine gpu_sp_lanc_eigh
+
+  !> sp_eigh(MatVec,eval,evec,Nblock,Nitermax,tol,iverbose) -- the default (lanc_method="arpack") spectrum call at
+  !! ED_DIAG.f90:152-160 -- on the device: size(eval) lowest eigenpairs, Krylov basis of Nblock vectors in HBM.
+  subroutine gpu_sp_eigh(MatVec,eval,evec,Nblock,Nitermax,tol,iverbose)
+    interface
+       subroutine MatVec(Nloc,v,Hv)
+         integer                    :: Nloc
+         complex(8),dimension(Nloc) :: v,Hv
+       end subroutine MatVec
+    end interface
+    real(8),intent(inout)       :: eval(:)
+    complex(8),intent(inout)    :: evec(:,:)
+    integer,intent(in),optional :: Nblock,Nitermax
+    real(8),intent(in),optional :: tol
+    logical,intent(in),optional :: iverbose
+    integer(c_int32_t)          :: ncv,nit,nconv,nmv
+    real(8)                     :: tl
+    if(.not.c_associated(handle))stop "gpu_sp_eigh ERROR: Hsector NOT set"
+    if(size(evec,2)<size(eval))stop "gpu_sp_eigh ERROR: size(evec,2) < size(eval)"
+    ncv=0;   if(present(Nblock))ncv=int(Nblock,c_int32_t)
+    nit=512; if(present(Nitermax))nit=int(Nitermax,c_int32_t)
+    tl=0d0;  if(present(tol))tl=tol
+    call check(hxv_eigh_lowest_host(handle,int(size(eval),c_int32_t),ncv,nit,tl,eval,evec,nconv,nmv),"gpu_sp_eigh")
+    if(present(iverbose))then
+       if(iverbose)write(*,"(A,I4,A,I6,A,F20.12)")"gpu_sp_eigh: converged=",nconv," matvecs=",nmv," E0=",eval(1)
+    endif
+  end subroutine gpu_sp_eigh
 
 end module ED_HAMILTONIAN_GPU_HXV

@@ -53,7 +53,8 @@ contains
     integer,parameter :: Nlat=4,Norb=1,Nspin=1,Nbath=2
     complex(8) :: impHloc(Nlat,Nlat,Nspin,Nspin,Norb,Norb),Hbath(Nlat,Nlat,Nspin,Nspin,Norb,Norb,Nbath)
     real(8)    :: Vbath(Nlat,Nspin,Norb,Nbath),Uloc(5),eps(Nbath)
-    complex(8),allocatable :: v(:),hv(:)
+    complex(8),allocatable :: v(:),hv(:),eig_basis(:,:)
+    real(8),allocatable    :: eig_values(:)
     real(8)    :: alanc(200),blanc(200),e0
     integer    :: dim,i,ib
     impHloc=(0d0,0d0); Hbath=(0d0,0d0)
@@ -88,6 +89,13 @@ contains
     write(*,"(A,F16.10)")"C2 device tridiag E0=",lowest_tridiag(alanc,blanc)
     call gpu_sp_lanc_eigh(spHtimesV_p,e0,hv,512,threshold=1d-14)
     write(*,"(A,F16.10,A,ES12.4)")"C2 device eigh E0=",e0," |vec|^2-1=",dble(dot_product(hv,hv))-1d0
+    !the default spectrum call of ED_DIAG.f90:152-160: sp_eigh(spHtimesV_p,eig_values,eig_basis,Nblock,Nitermax,tol=...)
+    allocate(eig_values(2),eig_basis(dim,2))
+    call gpu_sp_eigh(spHtimesV_p,eig_values,eig_basis,20,512,tol=1d-18)
+    call spHtimesV_p(dim,eig_basis(:,2),hv)
+    write(*,"(A,2F16.10,A,ES12.4)")"C2 device sp_eigh E=",eig_values," resid2=",&
+         sqrt(dble(dot_product(hv-eig_values(2)*eig_basis(:,2),hv-eig_values(2)*eig_basis(:,2))))
+    deallocate(eig_values,eig_basis)
     spHtimesV_p => null()
     call gpu_delete_Hv_sector()
   end subroutine chain_ns12

@@ -41,7 +41,7 @@ class _Stats(C.Structure):
 # every symbol include/hxv.h declares (tests check that the library exports all of them)
 EXPORTS = [
     "hxv_create_from_model", "hxv_create_from_csr", "hxv_create_dw_panel", "hxv_apply_dw_panel", "hxv_apply_up_add", "hxv_destroy", "hxv_vecdim", "hxv_dims", "hxv_apply_host",
-    "hxv_apply_device", "hxv_fullvec_elems", "hxv_localvec_elems", "hxv_pitch", "hxv_time_apply", "hxv_lanczos_tridiag", "hxv_lanczos_eigh", "hxv_lanczos_tridiag_host", "hxv_lanczos_eigh_host", "hxv_time_lanczos", "hxv_apply_ladder", "hxv_get_maps",
+    "hxv_apply_device", "hxv_fullvec_elems", "hxv_localvec_elems", "hxv_pitch", "hxv_time_apply", "hxv_lanczos_tridiag", "hxv_lanczos_eigh", "hxv_lanczos_tridiag_host", "hxv_lanczos_eigh_host", "hxv_eigh_lowest", "hxv_eigh_lowest_host", "hxv_time_lanczos", "hxv_apply_ladder", "hxv_get_maps",
     "hxv_nnz", "hxv_get_csr", "hxv_get_diag", "hxv_set_option", "hxv_get_option", "hxv_get_stats", "hxv_last_error",
     "hxv_version",
 ]
@@ -86,6 +86,8 @@ def load_library():
     L.hxv_lanczos_eigh.argtypes = [vp, i32, dbl, pd, vp, pi32]
     L.hxv_lanczos_tridiag_host.argtypes = [vp, vp, i32, pd, pd, dbl, pi32]
     L.hxv_lanczos_eigh_host.argtypes = [vp, i32, dbl, pd, vp, pi32]
+    L.hxv_eigh_lowest.argtypes = [vp, i32, i32, i32, dbl, pd, vp, pi32, pi32]
+    L.hxv_eigh_lowest_host.argtypes = [vp, i32, i32, i32, dbl, pd, vp, pi32, pi32]
     L.hxv_time_lanczos.argtypes = [vp, vp, i32, C.POINTER(C.c_float)]
     L.hxv_apply_ladder.argtypes = [vp, vp, i32, i32, i32, vp, vp, pd]
     L.hxv_get_maps.argtypes = [vp, pi32, pi32]
@@ -352,6 +354,33 @@ class HxvSector:
         _chk(load_library().hxv_lanczos_eigh_host(self._h, nitermax, threshold, C.byref(e), vec.ctypes.data, C.byref(n)),
              "hxv_lanczos_eigh_host")
         return e.value, vec, n.value
+
+    def eigh_lowest(self, neigen: int = 1, ncv: int = 0, maxrestart: int = 512, tol: float = 0.0, want_vectors: bool = True,
+                    native: bool = False):
+        """sp_eigh(MatVec, eig_values, eig_basis, Nblock, Nitermax, tol) on the device (ED_DIAG.f90:152-160): the `neigen`
+        lowest eigenpairs by thick-restart Lanczos.  -> (evals[neigen], evecs [neigen, Dim] (or padded if native), nconv, nmatvec)."""
+        import torch
+
+        torch.cuda.synchronize()
+        ev = np.zeros(neigen)
+        nc, nmv = C.c_int32(), C.c_int32()
+        vecs = torch.zeros(neigen * self.localElems, dtype=torch.complex128, device="cuda") if want_vectors else None
+        _chk(load_library().hxv_eigh_lowest(self._h, neigen, ncv, maxrestart, tol, _p(ev, C.c_double),
+                                            vecs.data_ptr() if want_vectors else None, C.byref(nc), C.byref(nmv)), "hxv_eigh_lowest")
+        if want_vectors:
+            vecs = vecs.view(neigen, self.localElems)
+            if not native:
+                vecs = torch.stack([self.unpad(vecs[i]) for i in range(neigen)])
+        return ev, vecs, nc.value, nmv.value
+
+    def eigh_lowest_host(self, neigen: int = 1, ncv: int = 0, maxrestart: int = 512, tol: float = 0.0):
+        """Same with eig_basis returned in a HOST array, Fortran shape (Dim, neigen)."""
+        ev = np.zeros(neigen)
+        nc, nmv = C.c_int32(), C.c_int32()
+        basis = np.zeros((self.Dim, neigen), dtype=np.complex128, order="F")
+        _chk(load_library().hxv_eigh_lowest_host(self._h, neigen, ncv, maxrestart, tol, _p(ev, C.c_double), basis.ctypes.data,
+                                                 C.byref(nc), C.byref(nmv)), "hxv_eigh_lowest_host")
+        return ev, basis, nc.value, nmv.value
 
     def apply_ladder(self, to: "HxvSector", orbital: int, spin: int, create: bool, psi):
         """c / c^dagger on (orbital, spin) from this sector into `to` (ED_GF_NORMAL.f90:180-199); returns (vector, norm2)."""

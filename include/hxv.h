@@ -137,6 +137,24 @@ int hxv_lanczos_eigh(hxv_handle *h, int32_t nitermax, double threshold, double *
 int hxv_lanczos_tridiag_host(hxv_handle *h, const void *vin_host, int32_t nlanc, double *alanc, double *blanc, double threshold,
                              int32_t *nsteps);
 int hxv_lanczos_eigh_host(hxv_handle *h, int32_t nitermax, double threshold, double *egs, void *vect_host, int32_t *niter);
+/* ---- Several lowest eigenpairs on device: the call SciFortran's sp_eigh (P-ARPACK) serves at ED_DIAG.f90:152-160,
+ *   call sp_eigh(spHtimesV_p, eig_values(Neigen), eig_basis(vecDim,Neigen), Nblock, Nitermax, tol=lanc_tolerance)
+ * as a thick-restart Lanczos (the explicit-restart form of ARPACK's implicitly restarted Lanczos for Hermitian
+ * operators) with a Krylov basis of ncv (= Nblock) vectors resident in HBM, full re-orthogonalisation and ARPACK's
+ * convergence test |beta*s_mi| <= tol*max(eps^(2/3),|theta_i|)  (tol below machine epsilon -- the reference's default
+ * lanc_tolerance=1e-18 -- is raised to epsilon).  nranks==1.
+ *   neigen       : number of lowest eigenpairs wanted (Neigen)
+ *   ncv          : basis size (Nblock = lanc_ncv_factor*Neigen+lanc_ncv_add, ED_DIAG.f90:96); <=0 -> 10*neigen; max 64
+ *   maxrestart   : restart limit (Nitermax)
+ *   evals        : [neigen] ascending
+ *   d_evecs      : device, neigen consecutive vectors of hxv_localvec_elems() elements (padded layout), or NULL
+ *   evecs_host   : host, eig_basis(Dim,neigen) in the reference's contiguous layout, or NULL
+ *   *nconv       : how many of the neigen pairs met the test; *nmatvec: H x V products spent.
+ * Needs (ncv+1) vectors of HBM; fails with HXV_ERR_HIP and a message naming the shortfall otherwise.          */
+int hxv_eigh_lowest(hxv_handle *h, int32_t neigen, int32_t ncv, int32_t maxrestart, double tol, double *evals, void *d_evecs,
+                    int32_t *nconv, int32_t *nmatvec);
+int hxv_eigh_lowest_host(hxv_handle *h, int32_t neigen, int32_t ncv, int32_t maxrestart, double tol, double *evals,
+                         void *evecs_host, int32_t *nconv, int32_t *nmatvec);
 /* Time nrep full Lanczos iterations (HxV + recurrence + 2 reductions) on device. */
 int hxv_time_lanczos(hxv_handle *h, void *d_work3 /* 3*hxv_localvec_elems() complex */, int32_t nrep, float *ms_per_iter);
 

@@ -1,0 +1,27 @@
+"""C3 (Ns=16, Dim=165 636 900): the default spectrum call of ED_DIAG (sp_eigh, Neigen=2, Nblock=20) on one MI355X,
+next to the single-vector Lanczos (sp_lanc_eigh)."""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "cdmft-lanc-ed_amd"))
+import torch
+import hxv
+from hxv import models
+
+wl = os.environ.get("SECTOR", "C3")
+m, (nup, ndw) = (models.hm_2dsquare(Nbath=3), (8, 8)) if wl == "C3" else (models.bhz_2d(Nbath=1), (8, 8)) if wl == "C4" else (models.hm_1dchain(), (6, 6))
+sec = hxv.HxvSector.from_model(m, nup, ndw)
+neigen, ncv = int(os.environ.get("NEIGEN", 2)), int(os.environ.get("NCV", 20))
+t = time.time()
+ev, X, nconv, nmv = sec.eigh_lowest(neigen, ncv, native=True)
+torch.cuda.synchronize()
+dt = time.time() - t
+print(f"{wl} eigh_lowest neigen={neigen} ncv={ncv}: E={ev} nconv={nconv} matvecs={nmv} {dt:.2f}s ({dt / nmv * 1e3:.1f} ms per Lanczos step)", flush=True)
+hv = sec.apply_device(X[0].contiguous())
+r = (hv - ev[0] * X[0]).norm().item()
+print(f"  residual |H x0 - E0 x0| = {r:.2e}", flush=True)
+del X, hv
+torch.cuda.empty_cache()
+t = time.time()
+e0, vec, nit = sec.lanczos_eigh(512, 1e-13, native=True)
+torch.cuda.synchronize()
+dt = time.time() - t
+print(f"{wl} lanczos_eigh: E0={e0:.12f} iterations={nit} {dt:.2f}s   |E0 - eigh_lowest| = {abs(e0 - ev[0]):.2e}", flush=True)

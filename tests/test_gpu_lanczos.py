@@ -213,3 +213,82 @@ def test_host_vector_lanczos_entries(built):
     H = orc.dense()
     assert abs(e0 - np.linalg.eigvalsh(H)[0]) <= 1e-10
     assert np.abs(H @ vec - e0 * vec).max() < 1e-8 and abs(np.vdot(vec, vec).real - 1) < 1e-12
+
+
+# ---- several lowest eigenpairs: the sp_eigh (P-ARPACK) call of ED_DIAG.f90:152-160 on the device ----------------
+@pytest.mark.parametrize("case,neigen,ncv", [("C1", 1, 10), ("C1", 2, 20), ("C1", 4, 36), ("chain", 2, 20), ("chain", 3, 12),
+                                              ("bhz", 2, 20), ("chain8", 4, 20), ("kanamori", 2, 20)])
+def test_eigh_lowest_vs_lapack(built, case, neigen, ncv):
+    import torch
+    import hxv
+    from hxv import models
+    from oracle.oracle import OracleSector
+
+    if case == "C1":
+        m, (nup, ndw) = models.plaquette_2x2_nobath(U=4.0, t=1.0, hfmode=False), (2, 2)
+    elif case == "chain":
+        m, (nup, ndw) = models.hm_1dchain(Nlat=2, Nbath=2, eps_bath=[0.3, 0.6]), (3, 3)
+    elif case == "chain8":
+        m, (nup, ndw) = models.hm_1dchain(Nlat=2, Nbath=3), (4, 4)
+    elif case == "kanamori":
+        m, (nup, ndw) = models.bhz_2d(Nbath=0, Jx=0.3, Jp=0.2, Jh=0.3, Ust=1.0), (4, 4)
+    else:
+        m, (nup, ndw) = models.bhz_2d(Nbath=0), (4, 4)
+    sec = hxv.HxvSector.from_model(m, nup, ndw)
+    Hd = OracleSector(m, nup, ndw).dense()
+    ref = np.linalg.eigvalsh(Hd)
+    ev, X, nconv, nmv = sec.eigh_lowest(neigen, ncv)
+    assert nconv == neigen and nmv > 0
+    assert np.abs(ev - ref[:neigen]).max() < 1e-10                      # BASELINE: E within 1e-10 of the CPU reference
+    X = X.cpu().numpy().T                                               # (Dim, neigen)
+    assert np.abs(X.conj().T @ X - np.eye(neigen)).max() < 1e-11
+    assert np.linalg.norm(Hd @ X - X * ev, axis=0).max() < 1e-9
+    if case == "C1" and neigen == 1:
+        assert abs(ev[0] - (-2.10274848)) < 5e-9                        # survey-recorded reference value
+    # host variant: eig_basis(Dim, Neigen) in the reference's layout
+    ev_h, basis, nconv_h, _ = sec.eigh_lowest_host(neigen, ncv)
+    assert np.abs(ev_h - ev).max() < 1e-12 and basis.shape == (sec.Dim, neigen)
+    assert np.linalg.norm(Hd @ basis - basis * ev_h, axis=0).max() < 1e-9
+
+
+def test_eigh_lowest_matches_numpy_restatement_and_arpack_C2(built):
+    """C2 (Dim = 853 776): device thick-restart Lanczos == its numpy restatement (same start vector, same restart rule)
+    and == scipy ARPACK (the algorithm family of sp_eigh) on the oracle's matrices."""
+    import scipy.sparse.linalg as sla
+    import hxv
+    from hxv import models
+    from oracle.oracle import OracleSector
+    from helpers_matrix import oracle_full_matrix
+    from trlan_numpy import trlan_lowest
+
+    m = models.hm_1dchain()
+    sec = hxv.HxvSector.from_model(m, 6, 6)
+    ev, X, nconv, nmv = sec.eigh_lowest(2, 20)
+    assert nconv == 2
+    H = oracle_full_matrix(OracleSector(m, 6, 6))
+    ref = np.sort(sla.eigsh(H, k=2, which="SA", ncv=20, tol=1e-13)[0])
+    assert np.abs(ev - ref).max() < 1e-10
+    Xh = X.cpu().numpy().T
+    assert np.linalg.norm(H @ Xh - Xh * ev, axis=0).max() < 1e-9
+    ev_np, _, _, nmv_np, _ = trlan_lowest(lambda v: H @ v, sec.Dim, 2, 20)
+    assert np.abs(ev - ev_np).max() < 1e-11
+    assert abs(nmv - nmv_np) <= 0.25 * nmv_np                         # same algorithm: same matvec count up to rounding-driven restarts
+    # the single-vector Lanczos agrees on the ground state
+    e0, _, _ = sec.lanczos_eigh(512, 1e-13, want_vector=False)
+    assert abs(e0 - ev[0]) < 1e-10
+
+
+def test_eigh_lowest_argument_errors(built):
+    import hxv
+    from hxv import models
+
+    sec = hxv.HxvSector.from_model(models.plaquette_2x2_nobath(), 2, 2)
+    sec.eigh_lowest(2, 100, want_vectors=False)          # Dim=36 clamps the basis to 36 vectors: fine
+    big = hxv.HxvSector.from_model(models.hm_1dchain(Nlat=2, Nbath=2), 3, 3)
+    with pytest.raises(hxv.HxvError, match="ncv > 64"):
+        big.eigh_lowest(2, 100)                          # Dim=400 does not
+    with pytest.raises(hxv.HxvError, match="neigen > Dim"):
+        sec.eigh_lowest(37, 10)
+    shard = hxv.HxvSector.from_model(models.hm_1dchain(Nlat=2, Nbath=2), 3, 3, rank=0, nranks=2)
+    with pytest.raises(hxv.HxvError, match="nranks==1"):
+        shard.eigh_lowest(1, 10)
