@@ -63,8 +63,8 @@ def cpu_baseline(model, nup, ndw, budget_s=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="C3", choices=["C2", "C3", "C4", "C5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lanczos", action="store_true", help="also time full Lanczos iterations (N=1)")

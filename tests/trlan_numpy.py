@@ -54,7 +54,7 @@ def trlan_lowest(matvec, dim: int, neigen: int, ncv: int, maxrestart: int = 512,
             T[j, j] = c[j].real
             w = w - c @ V[: j + 1]
             nrm = np.linalg.norm(w)
-            if nrm * nrm < 0.5 * (np.vdot(c, c).real + nrm * nrm):      # DGKS: one refinement pass
+            if nrm * nrm < 0.01 * (np.vdot(c, c).real + nrm * nrm):     # norm dropped 10x: one refinement pass (DGKS)
                 c2 = V[: j + 1].conj() @ w
                 T[j, j] += c2[j].real
                 w = w - c2 @ V[: j + 1]
