@@ -125,6 +125,21 @@ int finish_create(hxv_handle* h, int device, hxv_handle** out) {
 
 }  // namespace
 
+namespace hxv {
+// REAL-vector mode: available when every amplitude of H is real, the tiled kernels run, there is
+// no spH0nd block and the sector is not split.  Vectors are double[DimDw][pitch_real], pitch_real = roundup16(DimUp).
+const char* real_mode_blocker(const hxv_handle* h) {
+  if (!h->dev.real_h) return "H has complex amplitudes";
+  if (h->kernel != 1 || !h->plan.usable) return "the tiled kernels are not in use";
+  if (h->dev.nd.active) return "the spH0nd block (Jx/Jp) is active";
+  if (h->host.nranks != 1) return "the sector is split over ranks";
+  if (h->host.panel_rows > 0) return "panel handle";
+  if (h->plan.opt.passes != 3 || h->plan.opt.debug != 0) return "debug options are set";
+  return nullptr;
+}
+int pitch_real_of(const hxv_handle* h) { return (h->host.dimup + 15) & ~15; }
+}  // namespace hxv
+
 extern "C" {
 
 const char* hxv_last_error(void) { return g_err.c_str(); }
@@ -218,6 +233,23 @@ int hxv_apply_device(hxv_handle* h, const void* d_v_full, void* d_hv_local, void
     e = launch_hxv_tiled(h->dev, h->plan, (const double2*)d_v_full, h->d_wt, (double2*)d_hv_local, st);
   }
   if (e == hipSuccess && h->dev.nd.active) e = launch_hxv_nonlocal(h->dev, (const double2*)d_v_full, (double2*)d_hv_local, st);
+  if (e != hipSuccess) return fail(HXV_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+  h->n_apply++;
+  return HXV_OK;
+}
+
+int32_t hxv_pitch_real(const hxv_handle* h) { return h ? pitch_real_of(h) : -1; }
+int64_t hxv_realvec_elems(const hxv_handle* h) { return h ? (int64_t)h->host.dimdw * pitch_real_of(h) : -1; }
+int32_t hxv_real_vectors_available(const hxv_handle* h) { return h && !real_mode_blocker(h) ? 1 : 0; }
+
+int hxv_apply_device_real(hxv_handle* h, const void* d_v_real, void* d_hv_real, void* stream) {
+  if (!h || !d_v_real || !d_hv_real) return fail(HXV_ERR_ARG, "hxv_apply_device_real: NULL argument");
+  if (const char* why = real_mode_blocker(h)) return fail(HXV_ERR_UNSUPPORTED, std::string("hxv_apply_device_real: real vectors unavailable: ") + why);
+  int rcw = ensure_wt(h);
+  if (rcw) return rcw;
+  DevSector d = h->dev;
+  d.pitch = pitch_real_of(h);
+  hipError_t e = launch_hxv_tiled_real(d, h->plan, (const double*)d_v_real, (double*)h->d_wt, (double*)d_hv_real, (hipStream_t)stream);
   if (e != hipSuccess) return fail(HXV_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
   h->n_apply++;
   return HXV_OK;
@@ -337,6 +369,10 @@ int hxv_set_option(hxv_handle* h, const char* name, int64_t value) {
     h->lz_fused = value ? 1 : 0;
     return HXV_OK;
   }
+  if (!strcmp(name, "real_vectors")) {
+    h->real_vectors = value ? 1 : 0;
+    return HXV_OK;
+  }
   if (!strcmp(name, "debug")) {
     h->plan.opt.debug = (int)value;
     return HXV_OK;
@@ -375,6 +411,8 @@ int hxv_set_option(hxv_handle* h, const char* name, int64_t value) {
 
 int64_t hxv_get_option(const hxv_handle* h, const char* name) {
   if (!h || !name) return -1;
+  if (!strcmp(name, "real_vectors")) return h->real_vectors;
+  if (!strcmp(name, "lanczos_real_last")) return h->last_real;
   if (!strcmp(name, "kernel")) return h->kernel;
   if (!strcmp(name, "tile_bits_up")) return h->plan.up.lowbits;
   if (!strcmp(name, "tile_bits_dw")) return h->plan.dw.lowbits;
@@ -565,6 +603,61 @@ __global__ void __launch_bounds__(256) lz_init(int64_t n, double2* __restrict__ 
 
 int grid_for(int64_t n) { return (int)std::min<int64_t>((n + 255) / 256, RED_BLOCKS); }
 
+// ---- REAL-vector mode: layout conversions and the real start vector ----------------------------------------------
+// real [DimDw][pr] <- Re(complex [DimDw][pc]); pads zero.  partial = per-block sum of Im^2 (may be null)
+__global__ void __launch_bounds__(256) lz_to_real(int dimup, int dimdw, int pc, int pr, const double2* __restrict__ src,
+                                                  double* __restrict__ dst, double* __restrict__ partial) {
+  const int64_t n = (int64_t)dimdw * pr;
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t col = i / pr;
+    const int row = (int)(i - col * pr);
+    double x = 0.0;
+    if (row < dimup) {
+      const double2 z = src[col * pc + row];
+      x = z.x;
+      acc += z.y * z.y;
+    }
+    if (dst) dst[i] = x;
+  }
+  __shared__ double red[256];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && partial) partial[blockIdx.x] = red[0];
+}
+
+// complex [DimDw][pc] <- real [DimDw][pr]; pads zero
+__global__ void __launch_bounds__(256) lz_to_complex(int dimup, int dimdw, int pc, int pr, const double* __restrict__ src,
+                                                     double2* __restrict__ dst) {
+  const int64_t n = (int64_t)dimdw * pc;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t col = i / pc;
+    const int row = (int)(i - col * pc);
+    dst[i] = make_double2(row < dimup ? src[col * pr + row] : 0.0, 0.0);
+  }
+}
+
+// real start vector: the real part of lz_init's vector
+__global__ void __launch_bounds__(256) lz_init_real(int64_t n, double* __restrict__ q, uint64_t seed, int dimup, int pitch) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t col = i / pitch;
+    const int row = (int)(i - col * pitch);
+    if (row >= dimup) {
+      q[i] = 0.0;
+      continue;
+    }
+    uint64_t x = (uint64_t)(col * dimup + row) * 2 + seed + 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    x = x ^ (x >> 31);
+    q[i] = (double)(x >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+  }
+}
+
 // Symmetric tridiagonal eigen-solver (implicit QL with Wilkinson shifts): d[n] diagonal,
 // e[n] sub-diagonal in e[1..n-1] (e[0] unused).  On exit d = eigenvalues (unsorted) and, if z,
 // z (n x n, column-major, initialised to identity by the caller) = eigenvectors.
@@ -635,13 +728,18 @@ struct LzRunner {
   hxv_handle* h;
   LzBuf b;
   bool fused;
+  bool real;            // REAL-vector mode: the buffers hold double[DimDw][pitch_real]; every streaming kernel below is
+                        // elementwise with real scalars, so it runs unchanged on the buffer viewed as n2 double2 elements
+  int64_t n2;           // double2 elements of one vector
   bool first = true;
   double s_cur = 1.0;   // q = s_cur * b.q (fused) ; 1 (plain)
   double beta_prev = 1.0;
 
-  LzRunner(hxv_handle* hh, double2* x, double2* xm, double2* w) : h(hh), b{x, xm, w} {
+  LzRunner(hxv_handle* hh, double2* x, double2* xm, double2* w, bool real_vec = false) : h(hh), b{x, xm, w}, real(real_vec) {
     fused = hh->kernel == 1 && hh->plan.usable && !hh->dev.nd.active && hh->plan.opt.passes == 3 && hh->plan.opt.debug == 0 &&
             hh->host.nranks == 1 && hh->lz_fused;
+    n2 = real ? (int64_t)pitch_real_of(hh) * hh->host.dimdw / 2 : (int64_t)hh->host.pitch * hh->host.dimdw;
+    hh->last_real = real ? 1 : 0;
   }
 
   // b.q holds a vector of norm `nrm` (pass 1.0 if already normalised)
@@ -654,17 +752,17 @@ struct LzRunner {
   }
 
   int step(double* alpha, double* beta) {
-    const int64_t n = (int64_t)h->host.pitch * h->host.dimdw;
+    const int64_t n = n2;
     const int g = grid_for(n);
     if (!fused) {
-      int rc = hxv_apply_device(h, b.q, b.w, h->stream);
+      int rc = real ? hxv_apply_device_real(h, b.q, b.w, h->stream) : hxv_apply_device(h, b.q, b.w, h->stream);
       if (rc) return rc;
       hipLaunchKernelGGL(lz_sub_dot, dim3(g), dim3(256), 0, h->stream, n, b.w, b.qm, b.q, h->d_scalars, first ? -1 : 2, h->d_partials);
       hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_partials, g, h->d_scalars, 0, 0);
       hipLaunchKernelGGL(lz_sub_nrm, dim3(g), dim3(256), 0, h->stream, n, b.w, b.q, h->d_scalars, 0, h->d_partials + RED_BLOCKS);
       hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_partials + RED_BLOCKS, g, h->d_scalars, 1, 1);
     } else {
-      const int64_t nwg = tiled_pass_up_workgroups(h->dev, h->plan);
+      const int64_t nwg = tiled_pass_up_workgroups(h->dev, h->plan, real);
       if (nwg > h->lz_partial_n) {
         if (h->d_lz_partial) (void)hipFree(h->d_lz_partial);
         HIPCHK(hipMalloc((void**)&h->d_lz_partial, (size_t)nwg * sizeof(double)));
@@ -681,7 +779,14 @@ struct LzRunner {
       ep.i_s = 2;
       ep.i_c = 3;
       ep.partial = h->d_lz_partial;
-      hipError_t e = launch_hxv_tiled(h->dev, h->plan, b.q, h->d_wt, b.w, h->stream, &ep);
+      hipError_t e;
+      if (real) {
+        DevSector d = h->dev;
+        d.pitch = pitch_real_of(h);
+        e = launch_hxv_tiled_real(d, h->plan, (const double*)b.q, (double*)h->d_wt, (double*)b.w, h->stream, &ep);
+      } else {
+        e = launch_hxv_tiled(h->dev, h->plan, b.q, h->d_wt, b.w, h->stream, &ep);
+      }
       if (e != hipSuccess) return fail(HXV_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
       h->n_apply++;
       hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_lz_partial, (int)nwg, h->d_scalars, 0, 0);
@@ -700,7 +805,7 @@ struct LzRunner {
 
   // rotate to the next Lanczos vector (needs the beta returned by step())
   int advance() {
-    const int64_t n = (int64_t)h->host.pitch * h->host.dimdw;
+    const int64_t n = n2;
     if (!fused) {
       HIPCHK(hipMemcpyAsync(h->d_scalars + 2, h->d_scalars + 1, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
       std::swap(b.q, b.qm);
@@ -723,31 +828,76 @@ struct LzRunner {
   double scale() const { return fused ? s_cur : 1.0; }
 };
 
-int ensure_lz(hxv_handle* h) {
+// may this Lanczos run use real vectors?  (d_vin: optional complex start vector that must then be purely real)
+bool want_real(hxv_handle* h) { return h->real_vectors && !real_mode_blocker(h); }
+
+// the three work vectors of the single-vector Lanczos; `real` = layout of the coming run.  The pad rows of the two
+// layouts sit at different places and must be zero (the reductions run over the padded arrays, the products never
+// write pads), so the buffers are cleared whenever the layout changes.
+int ensure_lz(hxv_handle* h, bool real) {
   if (h->host.nranks != 1) return fail(HXV_ERR_STATE, "device Lanczos needs nranks==1 (global dots belong to the caller's communicator)");
   HIPCHK(hipSetDevice(h->device));
+  const size_t bytes = (size_t)h->host.pitch * h->host.dimdw * sizeof(double2);
   for (auto& p : h->d_lz)
     if (!p) {
-      const size_t bytes = (size_t)h->host.pitch * h->host.dimdw * sizeof(double2);
       HIPCHK(hipMalloc((void**)&p, bytes));
       HIPCHK(hipMemset(p, 0, bytes));
       h->device_bytes += (int64_t)bytes;
     }
+  if (h->lz_buf_mode != (real ? 1 : 0)) {
+    for (auto& p : h->d_lz) HIPCHK(hipMemsetAsync(p, 0, bytes, h->stream));
+    h->lz_buf_mode = real ? 1 : 0;
+  }
   return HXV_OK;
 }
 
 }  // namespace
+
+namespace hxv {
+void launch_to_real(const hxv_handle* h, const double2* src, double* dst, hipStream_t st) {
+  const int pr = pitch_real_of(h);
+  hipLaunchKernelGGL(lz_to_real, dim3(grid_for((int64_t)pr * h->host.dimdw)), dim3(256), 0, st, h->host.dimup, h->host.dimdw, h->host.pitch, pr,
+                     src, dst, (double*)nullptr);
+}
+void launch_to_complex(const hxv_handle* h, const double* src, double2* dst, hipStream_t st) {
+  hipLaunchKernelGGL(lz_to_complex, dim3(grid_for((int64_t)h->host.pitch * h->host.dimdw)), dim3(256), 0, st, h->host.dimup, h->host.dimdw,
+                     h->host.pitch, pitch_real_of(h), src, dst);
+}
+void launch_init_real(const hxv_handle* h, double* q, uint64_t seed, hipStream_t st) {
+  const int64_t n = (int64_t)pitch_real_of(h) * h->host.dimdw;
+  hipLaunchKernelGGL(lz_init_real, dim3(grid_for(n)), dim3(256), 0, st, n, q, seed, h->host.dimup, pitch_real_of(h));
+}
+}  // namespace hxv
 
 extern "C" {
 
 int hxv_lanczos_tridiag(hxv_handle* h, const void* d_vin, int32_t nlanc, double* alanc, double* blanc, double threshold,
                         int32_t* nsteps) {
   if (!h || !d_vin || nlanc < 1 || !alanc || !blanc) return fail(HXV_ERR_ARG, "hxv_lanczos_tridiag: bad argument");
-  int rc = ensure_lz(h);
-  if (rc) return rc;
+  if (h->host.nranks != 1) return fail(HXV_ERR_STATE, "device Lanczos needs nranks==1 (global dots belong to the caller's communicator)");
+  HIPCHK(hipSetDevice(h->device));
   const int64_t n = (int64_t)h->host.pitch * h->host.dimdw;
-  LzRunner lz(h, h->d_lz[0], h->d_lz[1], h->d_lz[2]);
-  HIPCHK(hipMemcpyAsync(lz.b.q, d_vin, (size_t)n * sizeof(double2), hipMemcpyDeviceToDevice, h->stream));
+  // REAL-vector mode: H real and the start vector purely real (c / c^dagger applied to a real ground state is) ->
+  // the whole recurrence stays real; alanc/blanc are the same numbers at half the bytes per pass
+  bool real = want_real(h);
+  if (real) {  // sum of Im(vin)^2 (dst = null: reduction only)
+    const int pr = pitch_real_of(h);
+    const int g = grid_for((int64_t)pr * h->host.dimdw);
+    hipLaunchKernelGGL(lz_to_real, dim3(g), dim3(256), 0, h->stream, h->host.dimup, h->host.dimdw, h->host.pitch, pr,
+                       (const double2*)d_vin, (double*)nullptr, h->d_partials);
+    hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_partials, g, h->d_scalars, 5, 0);
+    double im2 = 0.0;
+    HIPCHK(hipMemcpyAsync(&im2, h->d_scalars + 5, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    real = im2 == 0.0;
+  }
+  int rc = ensure_lz(h, real);
+  if (rc) return rc;
+  LzRunner lz(h, h->d_lz[0], h->d_lz[1], h->d_lz[2], real);
+  if (real)
+    launch_to_real(h, (const double2*)d_vin, (double*)lz.b.q, h->stream);
+  else
+    HIPCHK(hipMemcpyAsync(lz.b.q, d_vin, (size_t)n * sizeof(double2), hipMemcpyDeviceToDevice, h->stream));
   rc = lz.begin(1.0);  // vin is normalised by the caller (ED_GF_NORMAL.f90:197-199)
   if (rc) return rc;
   for (int k = 0; k < nlanc; ++k) {
@@ -777,22 +927,27 @@ int hxv_lanczos_tridiag(hxv_handle* h, const void* d_vin, int32_t nlanc, double*
 
 int hxv_lanczos_eigh(hxv_handle* h, int32_t nitermax, double threshold, double* egs, void* d_vect, int32_t* niter) {
   if (!h || nitermax < 1 || !egs) return fail(HXV_ERR_ARG, "hxv_lanczos_eigh: bad argument");
-  int rc = ensure_lz(h);
+  const bool real = want_real(h);  // the start vector is ours: real when H is (REAL-vector mode)
+  int rc = ensure_lz(h, real);
   if (rc) return rc;
-  const int64_t n = (int64_t)h->host.pitch * h->host.dimdw;
+  const int64_t nc = (int64_t)h->host.pitch * h->host.dimdw;
+  const int64_t n = real ? (int64_t)pitch_real_of(h) * h->host.dimdw / 2 : nc;  // double2 elements per vector
   const int g = grid_for(n);
   const int nmax = (int)std::min<int64_t>(nitermax, h->host.dim);
   const uint64_t seed = 0x5EED5EEDull;
   // deterministic start vector, normalised
   auto start = [&](LzRunner& lz) -> int {
-    hipLaunchKernelGGL(lz_init, dim3(g), dim3(256), 0, h->stream, n, lz.b.w, seed, h->host.dimup, h->host.pitch);
+    if (real)
+      launch_init_real(h, (double*)lz.b.w, seed, h->stream);
+    else
+      hipLaunchKernelGGL(lz_init, dim3(g), dim3(256), 0, h->stream, n, lz.b.w, seed, h->host.dimup, h->host.pitch);
     HIPCHK(hipMemsetAsync(h->d_scalars, 0, 8 * sizeof(double), h->stream));
     hipLaunchKernelGGL(lz_nrm, dim3(g), dim3(256), 0, h->stream, n, lz.b.w, h->d_partials + RED_BLOCKS);
     hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_partials + RED_BLOCKS, g, h->d_scalars, 1, 1);
     hipLaunchKernelGGL(lz_scale, dim3(g), dim3(256), 0, h->stream, n, lz.b.q, lz.b.w, h->d_scalars, 1);
     return lz.begin(1.0);
   };
-  LzRunner lz(h, h->d_lz[0], h->d_lz[1], h->d_lz[2]);
+  LzRunner lz(h, h->d_lz[0], h->d_lz[1], h->d_lz[2], real);
   rc = start(lz);
   if (rc) return rc;
   std::vector<double> al, be(1, 0.0);
@@ -844,7 +999,7 @@ int hxv_lanczos_eigh(hxv_handle* h, int32_t nitermax, double threshold, double* 
     int jmin = (int)(std::min_element(d.begin(), d.end()) - d.begin());
     const double* y = &z[(size_t)jmin * m];
     double2* out = (double2*)d_vect;
-    LzRunner lz2(h, h->d_lz[0], h->d_lz[1], h->d_lz[2]);
+    LzRunner lz2(h, h->d_lz[0], h->d_lz[1], h->d_lz[2], real);
     rc = start(lz2);
     if (rc) return rc;
     HIPCHK(hipMemsetAsync(out, 0, (size_t)n * sizeof(double2), h->stream));
@@ -861,6 +1016,11 @@ int hxv_lanczos_eigh(hxv_handle* h, int32_t nitermax, double threshold, double* 
     hipLaunchKernelGGL(lz_nrm, dim3(g), dim3(256), 0, h->stream, n, out, h->d_partials + RED_BLOCKS);
     hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_partials + RED_BLOCKS, g, h->d_scalars, 1, 1);
     hipLaunchKernelGGL(lz_scale, dim3(g), dim3(256), 0, h->stream, n, out, out, h->d_scalars, 1);
+    if (real) {
+      // the Ritz vector was accumulated as a real vector in d_vect's memory: expand it to the complex layout of the API
+      HIPCHK(hipMemcpyAsync(h->d_lz[2], out, (size_t)n * sizeof(double2), hipMemcpyDeviceToDevice, h->stream));
+      launch_to_complex(h, (const double*)h->d_lz[2], out, h->stream);
+    }
     HIPCHK(hipStreamSynchronize(h->stream));
   }
   return HXV_OK;
@@ -942,11 +1102,18 @@ int hxv_time_lanczos(hxv_handle* h, void* d_work3, int32_t nrep, float* ms_per_i
   if (!h || !d_work3 || nrep < 1 || !ms_per_iter) return fail(HXV_ERR_ARG, "hxv_time_lanczos: bad argument");
   if (h->host.nranks != 1) return fail(HXV_ERR_STATE, "hxv_time_lanczos needs nranks==1");
   HIPCHK(hipSetDevice(h->device));
-  const int64_t n = (int64_t)h->host.pitch * h->host.dimdw;
+  int64_t n = (int64_t)h->host.pitch * h->host.dimdw;
   HIPCHK(hipMemsetAsync(d_work3, 0, (size_t)3 * n * sizeof(double2), h->stream));
-  LzRunner lz(h, (double2*)d_work3, (double2*)d_work3 + n, (double2*)d_work3 + 2 * n);
+  const bool real = want_real(h);
+  LzRunner lz(h, (double2*)d_work3, (double2*)d_work3 + n, (double2*)d_work3 + 2 * n, real);
+  const int64_t nfull = n;
+  n = lz.n2;
   const int g = grid_for(n);
-  hipLaunchKernelGGL(lz_init, dim3(g), dim3(256), 0, h->stream, n, lz.b.w, 0x1234ull, h->host.dimup, h->host.pitch);
+  if (real)
+    launch_init_real(h, (double*)lz.b.w, 0x1234ull, h->stream);
+  else
+    hipLaunchKernelGGL(lz_init, dim3(g), dim3(256), 0, h->stream, n, lz.b.w, 0x1234ull, h->host.dimup, h->host.pitch);
+  (void)nfull;
   HIPCHK(hipMemsetAsync(h->d_scalars, 0, 8 * sizeof(double), h->stream));
   hipLaunchKernelGGL(lz_nrm, dim3(g), dim3(256), 0, h->stream, n, lz.b.w, h->d_partials + RED_BLOCKS);
   hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_partials + RED_BLOCKS, g, h->d_scalars, 1, 1);

@@ -62,9 +62,14 @@ __global__ void __launch_bounds__(256) tr_mdot(int64_t n, const double2* __restr
 }
 
 // out[t] = sum_b partial[b][t]  (t < nval), partial rows of `ld` values
-__global__ void __launch_bounds__(256) tr_colsum(const double* __restrict__ partial, int nblocks, int ld, int nval, double* __restrict__ out) {
+__global__ void __launch_bounds__(256) tr_colsum(const double* __restrict__ partial, int nblocks, int ld, int nval, double* __restrict__ out,
+                                                 int zero_odd) {
   __shared__ double red[256];
   for (int t = 0; t < nval; ++t) {
+    if (zero_odd && (t & 1)) {  // REAL-vector mode: the "imaginary parts" of the reinterpreted dot products are not coefficients
+      if (threadIdx.x == 0) out[t] = 0.0;
+      continue;
+    }
     double acc = 0.0;
     for (int b = threadIdx.x; b < nblocks; b += 256) acc += partial[(int64_t)b * ld + t];
     red[threadIdx.x] = acc;
@@ -264,7 +269,12 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
   const int m = (int)std::min<int64_t>(std::max(ncv, neigen + 1), dim);
   if (m > MAXCV) return fail(HXV_ERR_ARG, "hxv_eigh_lowest: ncv > 64 is not supported");
   HIPCHK(hipSetDevice(h->device));
-  const int64_t n = (int64_t)h->host.pitch * h->host.dimdw;  // padded local vector (pads are zero and stay zero)
+  // REAL-vector mode (H real, our own real start vector): the basis holds double[DimDw][pitch_real]; every kernel below
+  // is elementwise with real coefficients, so it runs unchanged on the vectors viewed as n double2 elements.
+  const bool real = h->real_vectors && !real_mode_blocker(h);
+  h->last_real = real ? 1 : 0;
+  const int64_t nc = (int64_t)h->host.pitch * h->host.dimdw;  // padded complex vector (pads are zero and stay zero)
+  const int64_t n = real ? (int64_t)pitch_real_of(h) * h->host.dimdw / 2 : nc;
   const int g = (int)std::min<int64_t>((n + 255) / 256, TR_BLOCKS);
   const double eps = 2.220446049250313e-16, eps23 = std::pow(eps, 2.0 / 3.0);
   tol = std::max(tol, eps);
@@ -293,10 +303,13 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
   auto vec = [&](int j) { return V + (int64_t)j * n; };
 
   // start vector
-  hipLaunchKernelGGL(tr_init, dim3(g), dim3(256), 0, st, n, vec(0), (uint64_t)0x5EED5EEDull, h->host.dimup, h->host.pitch);
+  if (real)
+    launch_init_real(h, (double*)vec(0), (uint64_t)0x5EED5EEDull, st);
+  else
+    hipLaunchKernelGGL(tr_init, dim3(g), dim3(256), 0, st, n, vec(0), (uint64_t)0x5EED5EEDull, h->host.dimup, h->host.pitch);
   double nrm2 = 0.0;
   hipLaunchKernelGGL(tr_scale_nrm, dim3(g), dim3(256), 0, st, n, vec(0), 1.0, d_npart);
-  hipLaunchKernelGGL(tr_colsum, dim3(1), dim3(256), 0, st, d_npart, g, 1, 1, d_nrm);
+  hipLaunchKernelGGL(tr_colsum, dim3(1), dim3(256), 0, st, d_npart, g, 1, 1, d_nrm, 0);
   HIPCHK(hipMemcpyAsync(&nrm2, d_nrm, sizeof(double), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   hipLaunchKernelGGL(tr_scale_nrm, dim3(g), dim3(256), 0, st, n, vec(0), 1.0 / std::sqrt(nrm2), (double*)nullptr);
@@ -308,10 +321,10 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
     for (int g0 = 0; g0 < nj; g0 += JB) {
       const int nb = std::min(JB, nj - g0);
       hipLaunchKernelGGL(tr_mdot, dim3(g), dim3(256), 0, st, n, vec(g0), n, nb, vec(j + 1), d_part);
-      hipLaunchKernelGGL(tr_colsum, dim3(1), dim3(256), 0, st, d_part, g, 2 * JB, 2 * nb, d_coef + 2 * g0);
+      hipLaunchKernelGGL(tr_colsum, dim3(1), dim3(256), 0, st, d_part, g, 2 * JB, 2 * nb, d_coef + 2 * g0, real ? 1 : 0);
     }
     hipLaunchKernelGGL(tr_maxpy, dim3(g), dim3(256), 0, st, n, V, n, nj, d_coef, vec(j + 1), d_npart);
-    hipLaunchKernelGGL(tr_colsum, dim3(1), dim3(256), 0, st, d_npart, g, 1, 1, d_nrm);
+    hipLaunchKernelGGL(tr_colsum, dim3(1), dim3(256), 0, st, d_npart, g, 1, 1, d_nrm, 0);
     HIPCHK(hipMemcpyAsync(c.data(), d_coef, (size_t)2 * nj * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(nrm2_after, d_nrm, sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -326,7 +339,7 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
     meff = m;
     beta_last = 0.0;
     for (int j = k; j < m; ++j) {
-      int rc = hxv_apply_device(h, vec(j), vec(j + 1), st);
+      int rc = real ? hxv_apply_device_real(h, vec(j), vec(j + 1), st) : hxv_apply_device(h, vec(j), vec(j + 1), st);
       if (rc) return rc;
       ++nmv;
       double w2 = 0.0;
@@ -388,8 +401,11 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
   if (d_evecs) {
     HIPCHK(hipMemcpyAsync(d_S, S.data(), (size_t)meff * ne * sizeof(double), hipMemcpyHostToDevice, st));
     launch_rotate(g, st, n, V, n, meff, ne, d_S);
-    HIPCHK(hipMemcpyAsync(d_evecs, V, (size_t)ne * n * sizeof(double2), hipMemcpyDeviceToDevice, st));
-    if (ne < neigen) HIPCHK(hipMemsetAsync((double2*)d_evecs + (int64_t)ne * n, 0, (size_t)(neigen - ne) * n * sizeof(double2), st));
+    if (real)
+      for (int i = 0; i < ne; ++i) launch_to_complex(h, (const double*)vec(i), (double2*)d_evecs + (int64_t)i * nc, st);
+    else
+      HIPCHK(hipMemcpyAsync(d_evecs, V, (size_t)ne * nc * sizeof(double2), hipMemcpyDeviceToDevice, st));
+    if (ne < neigen) HIPCHK(hipMemsetAsync((double2*)d_evecs + (int64_t)ne * nc, 0, (size_t)(neigen - ne) * nc * sizeof(double2), st));
   }
   HIPCHK(hipStreamSynchronize(st));
   hipError_t e = hipGetLastError();

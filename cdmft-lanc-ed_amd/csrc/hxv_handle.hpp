@@ -8,9 +8,18 @@
 #include "hxv_internal.hpp"
 #include "hxv_tiles.hpp"
 
+struct hxv_handle;
 namespace hxv {
 int fail(int code, const std::string& msg);  // records the message hxv_last_error() returns; returns code
 constexpr int RED_BLOCKS = 1024;             // workgroups of the grid-stride reduction kernels
+// REAL-vector mode helpers shared by the Lanczos drivers (defined in hxv_capi.hip)
+const char* real_mode_blocker(const hxv_handle* h);  // nullptr when real vectors can be used with this handle
+int pitch_real_of(const hxv_handle* h);
+// layout conversions between complex [DimDw][pitch] and real [DimDw][pitch_real] device vectors (pads written as zero)
+void launch_to_real(const hxv_handle* h, const double2* src, double* dst, hipStream_t st);
+void launch_to_complex(const hxv_handle* h, const double* src, double2* dst, hipStream_t st);
+// deterministic start vector, real part of the complex one (imaginary part dropped)
+void launch_init_real(const hxv_handle* h, double* q, uint64_t seed, hipStream_t st);
 }  // namespace hxv
 
 #define HIPCHK(expr)                                                                                   \
@@ -39,6 +48,9 @@ struct hxv_handle {
   double* d_lz_partial = nullptr;  // per-workgroup partial sums of the fused Lanczos epilogue
   int64_t lz_partial_n = 0;
   int lz_fused = 1;                // option "lanczos_fused"
+  int real_vectors = 1;            // option "real_vectors": device Lanczos drivers use real vectors when H and the start vector are real
+  int lz_buf_mode = 0;             // layout the d_lz work vectors were last used in (0 complex, 1 real): the pad rows differ
+  int last_real = 0;               // did the last device Lanczos run use real vectors (get_option "lanczos_real_last")
   int kernel = 1;
   int64_t n_apply = 0;
   int64_t device_bytes = 0;

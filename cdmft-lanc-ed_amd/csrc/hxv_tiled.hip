@@ -10,6 +10,7 @@
 // hit its L2.  Reference semantics: ED_HAMILTONIAN_SPARSE_HxV.f90:167-227 / :230-315.
 #include <algorithm>
 #include <numeric>
+#include <type_traits>
 
 #include "hxv_device.hpp"
 #include "hxv_tiles.hpp"
@@ -49,7 +50,24 @@ __device__ __forceinline__ void store_stream(double2* p, double2 a) {
   __builtin_nontemporal_store(x, reinterpret_cast<dbl2_t*>(p));
 }
 
+__device__ __forceinline__ void store_stream(double* p, double a) { __builtin_nontemporal_store(a, p); }
+
 constexpr uint32_t TILE_OFF_MASK = (1u << TILE_COEF_SHIFT) - 1u;
+
+// Vector element type VT: double2 (complex vectors, the reference's complex(8)) or double (REAL vectors: when H is real,
+// a real start vector keeps every Lanczos vector real -- half the bytes of every pass; device Lanczos only).
+template <typename VT>
+__device__ __forceinline__ VT vzero();
+template <>
+__device__ __forceinline__ double2 vzero<double2>() { return make_double2(0.0, 0.0); }
+template <>
+__device__ __forceinline__ double vzero<double>() { return 0.0; }
+__device__ __forceinline__ void vadd(double2& a, double2 b) { a.x += b.x; a.y += b.y; }
+__device__ __forceinline__ void vadd(double& a, double b) { a += b; }
+__device__ __forceinline__ void vscale(double2& a, double c) { a.x *= c; a.y *= c; }
+__device__ __forceinline__ void vscale(double& a, double c) { a *= c; }
+__device__ __forceinline__ double vdot(double2 a, double2 b) { return a.x * b.x + a.y * b.y; }
+__device__ __forceinline__ double vdot(double a, double b) { return a * b; }
 
 template <bool REAL>
 struct Coef;
@@ -60,6 +78,7 @@ struct Coef<true> {
     acc.x = ::fma(c, x.x, acc.x);
     acc.y = ::fma(c, x.y, acc.y);
   }
+  static __device__ __forceinline__ void fma(double& acc, double c, double x) { acc = ::fma(c, x, acc); }
   static __device__ __forceinline__ double from(double2 c) { return c.x; }
 };
 template <>
@@ -79,12 +98,13 @@ __device__ __forceinline__ double diag_value(const DevDiag& dg, double au, uint3
 // ---------------------------------------------------------------------------------------
 // pass A
 // ---------------------------------------------------------------------------------------
-template <int C, bool REAL, bool NORB1, bool LZ>
-__global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, const double2* __restrict__ v,
-                                                      const double2* __restrict__ wt, double2* __restrict__ hv, int ngroups,
+template <int C, bool REAL, bool NORB1, bool LZ, typename VT>
+__global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, const VT* __restrict__ v,
+                                                      const VT* __restrict__ wt, VT* __restrict__ hv, int ngroups,
                                                       int groups_per_xcd, int wc, LzEpilogue lz) {
   using CT = typename Coef<REAL>::type;
-  extern __shared__ double2 lds[];
+  extern __shared__ double2 lds_raw[];
+  VT* lds = reinterpret_cast<VT*>(lds_raw);
   const int b = blockIdx.x;
   const int xcd = b & 7, j = b >> 3;
   // column group: all blocks of a group share blockIdx%8 (= one XCD), and each XCD owns a contiguous range of
@@ -102,17 +122,17 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
   const int c0 = g * C;  // local column
   const int nc = min(C, s.qdw - c0);
   CT* lcoef = reinterpret_cast<CT*>(lds + C * n);
-  const double2* __restrict__ vcol0 = v + (int64_t)(s.slab0 + c0) * s.pitch;
+  const VT* __restrict__ vcol0 = v + (int64_t)(s.slab0 + c0) * s.pitch;
 #pragma unroll
   for (int cc = 0; cc < C; ++cc) {
-    const double2* __restrict__ src = vcol0 + (int64_t)min(cc, nc - 1) * s.pitch + r0;
+    const VT* __restrict__ src = vcol0 + (int64_t)min(cc, nc - 1) * s.pitch + r0;
     for (int r = threadIdx.x; r < n; r += T) lds[cc * n + r] = src[r];
   }
   for (int q = threadIdx.x; q < t.nscoef; q += T) lcoef[q] = Coef<REAL>::from(t.scoef[q]);
   // one row per thread (plan guarantees n <= blockDim.x)
   const int p = threadIdx.x;
-  double2 acc[C];
-  double2 xq[LZ ? C : 1];  // the thread's own input elements, kept for the Lanczos epilogue
+  VT acc[C];
+  VT xq[LZ ? C : 1];  // the thread's own input elements, kept for the Lanczos epilogue
   int r = 0;
   // Issued BEFORE the barrier so their latency hides behind the tile load: the dw-hop part that pass B left in the
   // column-group-blocked scratch wt[group][row][wc] (C*16 contiguous bytes per row, rows consecutive: a plain
@@ -122,16 +142,16 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
   if (p < n) {
     if (wt && wc == 0) {
       // natural layout [local column][pitch] (all-to-all exchange: the dw part arrives assembled like hv)
-      const double2* __restrict__ wcol = wt + (int64_t)c0 * s.pitch + r0 + p;
+      const VT* __restrict__ wcol = wt + (int64_t)c0 * s.pitch + r0 + p;
 #pragma unroll
       for (int cc = 0; cc < C; ++cc) acc[cc] = wcol[(int64_t)min(cc, nc - 1) * s.pitch];
     } else if (wt) {
-      const double2* __restrict__ wrow = wt + ((int64_t)(c0 / wc) * s.dimup + r0 + p) * wc + (c0 % wc);
+      const VT* __restrict__ wrow = wt + ((int64_t)(c0 / wc) * s.dimup + r0 + p) * wc + (c0 % wc);
 #pragma unroll
       for (int cc = 0; cc < C; ++cc) acc[cc] = wrow[min(cc, nc - 1)];
     } else {
 #pragma unroll
-      for (int cc = 0; cc < C; ++cc) acc[cc] = make_double2(0.0, 0.0);
+      for (int cc = 0; cc < C; ++cc) acc[cc] = vzero<VT>();
     }
     if (s.diag.mode == 0) {
       au = s.diag.a_up[r0 + p];
@@ -152,17 +172,13 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
 #pragma unroll
       for (int cc = 0; cc < C; ++cc) {
         const double d = diag_value<NORB1>(s.diag, au, mu, s.dw0 + min(c0 + cc, s.qdw - 1));
-        const double2 x = lds[cc * n + r];
-        acc[cc].x = fma(d, x.x, acc[cc].x);
-        acc[cc].y = fma(d, x.y, acc[cc].y);
+        Coef<true>::fma(acc[cc], d, lds[cc * n + r]);
       }
     } else {
 #pragma unroll
       for (int cc = 0; cc < C; ++cc) {
         const double d = s.diag.stored[(int64_t)min(c0 + cc, s.qdw - 1) * s.dimup + i];
-        const double2 x = lds[cc * n + r];
-        acc[cc].x = fma(d, x.x, acc[cc].x);
-        acc[cc].y = fma(d, x.y, acc[cc].y);
+        Coef<true>::fma(acc[cc], d, lds[cc * n + r]);
       }
     }
     // hops that leave the block, same columns, other rows: from global memory (L2 of this XCD)
@@ -170,7 +186,7 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
       // block hops: the partner block is one contiguous run, lanes read consecutive rows
       for (uint32_t h = t.bh_ptr[kb]; h < t.bh_ptr[kb + 1]; ++h) {
         const CT cf = lcoef[t.bh[2 * h + 1]];
-        const double2* __restrict__ src = vcol0 + t.bh[2 * h] + r;
+        const VT* __restrict__ src = vcol0 + t.bh[2 * h] + r;
 #pragma unroll
         for (int cc = 0; cc < C; ++cc) Coef<REAL>::fma(acc[cc], cf, src[(int64_t)min(cc, nc - 1) * s.pitch]);
       }
@@ -180,7 +196,7 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
         const uint32_t e = t.rs_tab[t.rs_off[sl] + r];
         if (__all(e == emptyz)) continue;
         const CT cf = lcoef[e >> TILE_COEF_SHIFT];
-        const double2* __restrict__ src = vcol0 + (e & TILE_OFF_MASK);
+        const VT* __restrict__ src = vcol0 + (e & TILE_OFF_MASK);
 #pragma unroll
         for (int cc = 0; cc < C; ++cc) Coef<REAL>::fma(acc[cc], cf, src[(int64_t)min(cc, nc - 1) * s.pitch]);
       }
@@ -211,17 +227,11 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
     for (int cc = 0; cc < C; ++cc) {
       if (cc < nc) {
         const int64_t o = (int64_t)(c0 + cc) * s.pitch + r0 + p;
-        double2 w = acc[cc];
+        VT w = acc[cc];
         if (LZ) {
-          w.x *= sc;
-          w.y *= sc;
-          if (lz.xm) {
-            const double2 m = lz.xm[o];
-            w.x -= cm * m.x;
-            w.y -= cm * m.y;
-          }
-          const double2 x = xq[LZ ? cc : 0];
-          asum += sc * (x.x * w.x + x.y * w.y);
+          vscale(w, sc);
+          if (lz.xm) Coef<true>::fma(w, -cm, reinterpret_cast<const VT*>(lz.xm)[o]);
+          asum += sc * vdot(xq[LZ ? cc : 0], w);
         }
         if (t.debug & 8)
           hv[o] = w;
@@ -249,13 +259,15 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
 // are done afterwards with lanes along the contiguous row direction (coalesced 16*R-byte
 // segments of other columns), after the inner sums have been parked in the tile.
 // ---------------------------------------------------------------------------------------
-template <int R, int NP, bool REAL>
-__global__ void __launch_bounds__(1024, 8) hxv_pass_dw(DevSector s, DevTiles t, const double2* __restrict__ v, double2* __restrict__ wt,
+template <int R, int NP, bool REAL, typename VT>
+__global__ void __launch_bounds__(1024, 8) hxv_pass_dw(DevSector s, DevTiles t, const VT* __restrict__ v, VT* __restrict__ wt,
                                                       int ngroups, int groups_per_xcd, int wc) {
   // NP = (row,column) pairs of the tile per thread (plan: max_block*R <= NP*blockDim.x); all their global
   // loads are issued before the first use so a workgroup keeps NP requests per lane in flight.
   using CT = typename Coef<REAL>::type;
-  extern __shared__ double2 lds[];
+  extern __shared__ double2 lds_raw[];
+  VT* lds = reinterpret_cast<VT*>(lds_raw);
+  constexpr int SLOTS = 256 / (int)sizeof(VT);  // elements in one sweep of all LDS banks
   const int b = blockIdx.x;
   const int xcd = b & 7, j = b >> 3;
   const int gl = j / t.nblocks;
@@ -268,9 +280,9 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_dw(DevSector s, DevTiles t, 
   const int T = blockDim.x;
   const int i0 = rg * R;
   const int npairs = n * R;
-  // padded row stride of the transposed tile: (stride mod 16) = 16/R spreads the R rows x (16/R) columns touched
-  // by 16 neighbouring lanes over all 16 sixteen-byte bank slots
-  const int ns = ((n + 15) & ~15) + 16 / R;
+  // padded row stride of the transposed tile: (stride mod SLOTS) = SLOTS/R spreads the R rows x (SLOTS/R) columns
+  // touched by SLOTS neighbouring lanes over all bank slots (16 sixteen-byte slots / 32 eight-byte slots)
+  const int ns = ((n + SLOTS - 1) & ~(SLOTS - 1)) + SLOTS / R;
   CT* lcoef = reinterpret_cast<CT*>(lds + R * ns);
   const uint32_t emptyz = (uint32_t)(t.nscoef - 1) << TILE_COEF_SHIFT;
   for (int q = threadIdx.x; q < t.nscoef; q += T) lcoef[q] = Coef<REAL>::from(t.scoef[q]);
@@ -283,7 +295,7 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_dw(DevSector s, DevTiles t, 
       const int c = cb0 + q / R;
       slot[it] = s.vcol_identity ? (uint32_t)c : s.vcol[c];
     }
-    double2 x[NP];
+    VT x[NP];
 #pragma unroll
     for (int it = 0; it < NP; ++it) {
       const int q = min(threadIdx.x + it * T, npairs - 1);
@@ -299,14 +311,14 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_dw(DevSector s, DevTiles t, 
   // in-block hops, one column per thread (plan guarantees n <= blockDim.x)
   const int p = threadIdx.x;
   {
-    double2 acc[R];
+    VT acc[R];
     int col1 = 0;
     if (p < n) {
       const uint32_t packed = __builtin_amdgcn_readfirstlane(t.gmax[t.gstart[kb] + (p >> 6)]);
       const int kin = (t.debug & 2) ? 0 : (int)(packed & 0xFFFFu);
       col1 = (int)t.perm[cb0 + p] - cb0;
 #pragma unroll
-      for (int r = 0; r < R; ++r) acc[r] = make_double2(0.0, 0.0);
+      for (int r = 0; r < R; ++r) acc[r] = vzero<VT>();
       for (int k0 = 0; k0 < kin; k0 += HOP_CHUNK) {
         uint32_t e[HOP_CHUNK];
 #pragma unroll
@@ -336,14 +348,14 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_dw(DevSector s, DevTiles t, 
     constexpr int HB = NP > 4 ? 4 : NP;
 #pragma unroll
     for (int base = 0; base < NP; base += HB) {
-      double2 osum[HB];
+      VT osum[HB];
 #pragma unroll
-      for (int it = 0; it < HB; ++it) osum[it] = make_double2(0.0, 0.0);
+      for (int it = 0; it < HB; ++it) osum[it] = vzero<VT>();
       // block hops: source column slot = start + column offset, one signed coefficient for the whole block
       for (uint32_t h = t.bh_ptr[kb]; h < t.bh_ptr[kb + 1]; ++h) {
         const CT cf = lcoef[t.bh[2 * h + 1]];
         const uint32_t s0 = t.bh[2 * h];
-        double2 x[HB];
+        VT x[HB];
 #pragma unroll
         for (int it = 0; it < HB; ++it) {
           const int q = min((int)threadIdx.x + (base + it) * T, npairs - 1);
@@ -363,7 +375,7 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_dw(DevSector s, DevTiles t, 
           none = none && (e[it] == emptyz);
         }
         if (__all(none)) continue;
-        double2 x[HB];
+        VT x[HB];
 #pragma unroll
         for (int it = 0; it < HB; ++it) {
           const int q = min((int)threadIdx.x + (base + it) * T, npairs - 1);
@@ -376,9 +388,8 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_dw(DevSector s, DevTiles t, 
       for (int it = 0; it < HB; ++it) {
         const int q = threadIdx.x + (base + it) * T;
         if (q < npairs) {
-          double2 a = lds[(q % R) * ns + q / R];
-          a.x += osum[it].x;
-          a.y += osum[it].y;
+          VT a = lds[(q % R) * ns + q / R];
+          vadd(a, osum[it]);
           lds[(q % R) * ns + q / R] = a;
         }
       }
@@ -603,17 +614,21 @@ void build_spin_tiles(const SpinOp& op, const std::vector<uint32_t>& map, int lo
   t.rs_per_row = rs_rows / dim;
 }
 
-template <int C, bool LZ>
-hipError_t launch_up_lz(const DevSector& s, const DevTiles& t, int lds_bytes, int threads, bool norb1, int wc, const double2* v,
-                        const double2* wt, double2* hv, const LzEpilogue& lz, hipStream_t st) {
+template <int C, bool LZ, typename VT>
+hipError_t launch_up_lz(const DevSector& s, const DevTiles& t, int lds_bytes, int threads, bool norb1, int wc, const VT* v,
+                        const VT* wt, VT* hv, const LzEpilogue& lz, hipStream_t st) {
   const int ngroups = (s.qdw + C - 1) / C;
   const int gpx = (ngroups + 7) / 8;
   const int64_t nwg = (int64_t)gpx * 8 * t.nblocks;
-  void (*kern)(DevSector, DevTiles, const double2*, const double2*, double2*, int, int, int, LzEpilogue);
-  if (s.real_h)
-    kern = norb1 ? hxv_pass_up<C, true, true, LZ> : hxv_pass_up<C, true, false, LZ>;
-  else
-    kern = norb1 ? hxv_pass_up<C, false, true, LZ> : hxv_pass_up<C, false, false, LZ>;
+  void (*kern)(DevSector, DevTiles, const VT*, const VT*, VT*, int, int, int, LzEpilogue);
+  if constexpr (std::is_same<VT, double>::value) {  // real vectors exist for real H only
+    kern = norb1 ? hxv_pass_up<C, true, true, LZ, double> : hxv_pass_up<C, true, false, LZ, double>;
+  } else {
+    if (s.real_h)
+      kern = norb1 ? hxv_pass_up<C, true, true, LZ, double2> : hxv_pass_up<C, true, false, LZ, double2>;
+    else
+      kern = norb1 ? hxv_pass_up<C, false, true, LZ, double2> : hxv_pass_up<C, false, false, LZ, double2>;
+  }
   lds_bytes = std::max(lds_bytes, threads * 8);  // the epilogue reduces through LDS
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (e != hipSuccess) return e;
@@ -621,34 +636,38 @@ hipError_t launch_up_lz(const DevSector& s, const DevTiles& t, int lds_bytes, in
   return hipGetLastError();
 }
 
-template <int C>
-hipError_t launch_up(const DevSector& s, const DevTiles& t, int lds_bytes, int threads, bool norb1, int wc, const double2* v,
-                     const double2* wt, double2* hv, const LzEpilogue* lz, hipStream_t st) {
-  if (lz) return launch_up_lz<C, true>(s, t, lds_bytes, threads, norb1, wc, v, wt, hv, *lz, st);
-  return launch_up_lz<C, false>(s, t, lds_bytes, threads, norb1, wc, v, wt, hv, LzEpilogue(), st);
+template <int C, typename VT>
+hipError_t launch_up(const DevSector& s, const DevTiles& t, int lds_bytes, int threads, bool norb1, int wc, const VT* v,
+                     const VT* wt, VT* hv, const LzEpilogue* lz, hipStream_t st) {
+  if (lz) return launch_up_lz<C, true, VT>(s, t, lds_bytes, threads, norb1, wc, v, wt, hv, *lz, st);
+  return launch_up_lz<C, false, VT>(s, t, lds_bytes, threads, norb1, wc, v, wt, hv, LzEpilogue(), st);
 }
 
-template <int R, int NP>
-hipError_t launch_dw_np(const DevSector& s, const DevTiles& t, int lds_bytes, int threads, int wc, const double2* v, double2* hv,
+template <int R, int NP, typename VT>
+hipError_t launch_dw_np(const DevSector& s, const DevTiles& t, int lds_bytes, int threads, int wc, const VT* v, VT* hv,
                         hipStream_t st) {
   const int ngroups = (s.dimup + R - 1) / R;
   const int gpx = (ngroups + 7) / 8;
   const int64_t nwg = (int64_t)gpx * 8 * t.nblocks;
-  auto kern = s.real_h ? hxv_pass_dw<R, NP, true> : hxv_pass_dw<R, NP, false>;
+  void (*kern)(DevSector, DevTiles, const VT*, VT*, int, int, int);
+  if constexpr (std::is_same<VT, double>::value)
+    kern = hxv_pass_dw<R, NP, true, double>;
+  else
+    kern = s.real_h ? hxv_pass_dw<R, NP, true, double2> : hxv_pass_dw<R, NP, false, double2>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(threads), (size_t)lds_bytes, st, s, t, v, hv, ngroups, gpx, wc);
   return hipGetLastError();
 }
 
-template <int R>
-hipError_t launch_dw(const DevSector& s, const DevTiles& t, int max_block, int lds_bytes, int threads, int wc, const double2* v,
-                     double2* hv, hipStream_t st) {
+template <int R, typename VT>
+hipError_t launch_dw(const DevSector& s, const DevTiles& t, int max_block, int lds_bytes, int threads, int wc, const VT* v,
+                     VT* hv, hipStream_t st) {
   const int np = (max_block * R + threads - 1) / threads;  // <= R because max_block <= threads
-  if (np <= 1) return launch_dw_np<R, 1>(s, t, lds_bytes, threads, wc, v, hv, st);
-  if (np <= 2) return launch_dw_np<R, 2>(s, t, lds_bytes, threads, wc, v, hv, st);
-  if (np <= 4) return launch_dw_np<R, 4>(s, t, lds_bytes, threads, wc, v, hv, st);
-  return launch_dw_np<R, 8>(s, t, lds_bytes, threads, wc, v, hv, st);
+  if (np <= 1) return launch_dw_np<R, 1, VT>(s, t, lds_bytes, threads, wc, v, hv, st);
+  if (np <= 2) return launch_dw_np<R, 2, VT>(s, t, lds_bytes, threads, wc, v, hv, st);
+  if (np <= 4) return launch_dw_np<R, 4, VT>(s, t, lds_bytes, threads, wc, v, hv, st);
+  return launch_dw_np<R, 8, VT>(s, t, lds_bytes, threads, wc, v, hv, st);
 }
 
 std::vector<double2> signed_coefs(const SpinOp& op) {
@@ -713,43 +732,66 @@ int64_t tiled_wt_elems(const DevSector& s, const TilePlan& plan) {
   return (int64_t)((s.qdw + wc - 1) / wc) * wc * s.dimup;
 }
 
-int64_t tiled_pass_up_workgroups(const DevSector& s, const TilePlan& plan) {
-  const int C = plan.opt.cols_per_tile;
+// Real-vector mode runs the same plans with twice the columns (pass A) / rows (pass B) per tile: the same tile bytes.
+static int real_cols(const TilePlan& plan) { return std::min(8, 2 * plan.opt.cols_per_tile); }
+static int real_rows(const TilePlan& plan) { return std::min(8, 2 * plan.opt.rows_per_tile); }
+static int real_wc(const TilePlan& plan) { return std::max(real_cols(plan), std::min(16, 2 * plan.opt.wt_cols)); }
+
+int64_t tiled_pass_up_workgroups(const DevSector& s, const TilePlan& plan, bool real_vec) {
+  const int C = real_vec ? real_cols(plan) : plan.opt.cols_per_tile;
   const int ngroups = (s.qdw + C - 1) / C;
   return (int64_t)((ngroups + 7) / 8) * 8 * plan.up.nblocks;
 }
 
-hipError_t launch_hxv_tiled(const DevSector& s, const TilePlan& plan, const double2* v, double2* wt, double2* hv, hipStream_t st,
-                            const LzEpilogue* lz, int only_pass, bool wt_natural) {
-  // wt: scratch of tiled_wt_elems() elements (dw-hop part, column-group-blocked), owned by the handle
-  if (s.qdw == 0) return hipSuccess;
+template <typename VT>
+static hipError_t launch_tiled_vt(const DevSector& s, const TilePlan& plan, const VT* v, VT* wt, VT* hv, hipStream_t st, const LzEpilogue* lz,
+                                  int only_pass, bool wt_natural) {
+  constexpr bool RV = std::is_same<VT, double>::value;
   DevTiles tu{plan.up.d_start, plan.up.d_perm, plan.up.d_gstart, plan.up.d_gmax, plan.up.d_ell_in, plan.up.d_ell_out,
               plan.d_scoef_up, plan.up.d_bh_ptr, plan.up.d_bh, plan.up.d_rs_ptr, plan.up.d_rs_off, plan.up.d_rs_tab,
               plan.up.nblocks, 2 * plan.ncoef_up + 1, plan.opt.debug};
   DevTiles td{plan.dw.d_start, plan.dw.d_perm, plan.dw.d_gstart, plan.dw.d_gmax, plan.dw.d_ell_in, plan.dw.d_ell_out,
               plan.d_scoef_dw, plan.dw.d_bh_ptr, plan.dw.d_bh, plan.dw.d_rs_ptr, plan.dw.d_rs_off, plan.dw.d_rs_tab,
               plan.dw.nblocks, 2 * plan.ncoef_dw + 1, plan.opt.debug};
-  const int C = plan.opt.cols_per_tile, R = plan.opt.rows_per_tile;
-  const int wc = wt_natural ? 0 : std::max(C, plan.opt.wt_cols);  // columns per group of the wt scratch; 0 = natural layout
+  const int C = RV ? real_cols(plan) : plan.opt.cols_per_tile, R = RV ? real_rows(plan) : plan.opt.rows_per_tile;
+  // columns per group of the wt scratch; 0 = natural layout
+  const int wc = wt_natural ? 0 : (RV ? real_wc(plan) : std::max(C, plan.opt.wt_cols));
   const int passes = only_pass ? only_pass : plan.opt.passes;
-  const int lds_a = std::max((plan.up.max_block * C + tu.nscoef) * 16, plan.opt.lds_min_kb_up * 1024);
-  const int lds_b = std::max(((((plan.dw.max_block + 15) & ~15) + 16 / R) * R + td.nscoef) * 16, plan.opt.lds_min_kb_dw * 1024);
+  constexpr int SLOTS = 256 / (int)sizeof(VT);
+  const int lds_a = std::max(plan.up.max_block * C * (int)sizeof(VT) + tu.nscoef * 16, plan.opt.lds_min_kb_up * 1024);
+  const int lds_b = std::max((((plan.dw.max_block + SLOTS - 1) & ~(SLOTS - 1)) + SLOTS / R) * R * (int)sizeof(VT) + td.nscoef * 16,
+                             plan.opt.lds_min_kb_dw * 1024);
   const int ta = plan.opt.threads_up, tb = plan.opt.threads_dw;
   const bool norb1 = s.diag.mode == 0 && s.diag.cross.norb == 1;
   hipError_t e = hipSuccess;
   if (passes & 2) switch (R) {
-      case 2: e = launch_dw<2>(s, td, plan.dw.max_block, lds_b, tb, wc, v, wt, st); break;
-      case 4: e = launch_dw<4>(s, td, plan.dw.max_block, lds_b, tb, wc, v, wt, st); break;
-      default: e = launch_dw<8>(s, td, plan.dw.max_block, lds_b, tb, wc, v, wt, st); break;
+      case 2: e = launch_dw<2, VT>(s, td, plan.dw.max_block, lds_b, tb, wc, v, wt, st); break;
+      case 4: e = launch_dw<4, VT>(s, td, plan.dw.max_block, lds_b, tb, wc, v, wt, st); break;
+      default: e = launch_dw<8, VT>(s, td, plan.dw.max_block, lds_b, tb, wc, v, wt, st); break;
     }
   if (e != hipSuccess) return e;
-  const double2* wta = ((passes & 2) || only_pass == 1) ? wt : nullptr;
+  const VT* wta = ((passes & 2) || only_pass == 1) ? wt : nullptr;
   if (passes & 1) switch (C) {
-      case 2: e = launch_up<2>(s, tu, lds_a, ta, norb1, wc, v, wta, hv, lz, st); break;
-      case 4: e = launch_up<4>(s, tu, lds_a, ta, norb1, wc, v, wta, hv, lz, st); break;
-      default: e = launch_up<8>(s, tu, lds_a, ta, norb1, wc, v, wta, hv, lz, st); break;
+      case 2: e = launch_up<2, VT>(s, tu, lds_a, ta, norb1, wc, v, wta, hv, lz, st); break;
+      case 4: e = launch_up<4, VT>(s, tu, lds_a, ta, norb1, wc, v, wta, hv, lz, st); break;
+      default: e = launch_up<8, VT>(s, tu, lds_a, ta, norb1, wc, v, wta, hv, lz, st); break;
     }
   return e;
+}
+
+hipError_t launch_hxv_tiled(const DevSector& s, const TilePlan& plan, const double2* v, double2* wt, double2* hv, hipStream_t st,
+                            const LzEpilogue* lz, int only_pass, bool wt_natural) {
+  // wt: scratch of tiled_wt_elems() elements (dw-hop part, column-group-blocked), owned by the handle
+  if (s.qdw == 0) return hipSuccess;
+  return launch_tiled_vt<double2>(s, plan, v, wt, hv, st, lz, only_pass, wt_natural);
+}
+
+hipError_t launch_hxv_tiled_real(const DevSector& s, const TilePlan& plan, const double* v, double* wt, double* hv, hipStream_t st,
+                                 const LzEpilogue* lz) {
+  // REAL vectors (H real; s.pitch must be the real pitch, a multiple of 16): wt needs no more bytes than in complex mode
+  if (s.qdw == 0) return hipSuccess;
+  if (!s.real_h) return hipErrorInvalidValue;
+  return launch_tiled_vt<double>(s, plan, v, wt, hv, st, lz, 0, false);
 }
 
 }  // namespace hxv

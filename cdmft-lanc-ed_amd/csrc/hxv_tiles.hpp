@@ -73,12 +73,12 @@ struct TilePlan {
 //   w = s*(H x) - c*xm   is stored instead of H x, and   sum Re(conj(s*x) * w)   is reduced per workgroup,
 // s = scal[i_s], c = scal[i_c] read from device memory.  Saves two full vector passes per iteration.
 struct LzEpilogue {
-  const double2* xm = nullptr;  // previous (unnormalised) Lanczos vector, may be null when c == 0
+  const void* xm = nullptr;     // previous (unnormalised) Lanczos vector (same element type as the product's vectors), may be null when c == 0
   const double* scal = nullptr;
   int i_s = 0, i_c = 0;
   double* partial = nullptr;    // one partial sum per workgroup of pass A
 };
-int64_t tiled_pass_up_workgroups(const DevSector& s, const TilePlan& plan);
+int64_t tiled_pass_up_workgroups(const DevSector& s, const TilePlan& plan, bool real_vec = false);
 int64_t tiled_wt_elems(const DevSector& s, const TilePlan& plan);
 
 struct PlanUploader {
@@ -88,5 +88,8 @@ struct PlanUploader {
 std::string make_tile_plan(const SectorHost& s, TilePlan& plan, const PlanUploader& up);
 hipError_t launch_hxv_tiled(const DevSector& s, const TilePlan& plan, const double2* v_full, double2* wt_scratch, double2* hv_local,
                             hipStream_t st, const LzEpilogue* lz = nullptr, int only_pass = 0, bool wt_natural = false);
+// Same product on REAL vectors (double elements; H must be real, nranks == 1): s.pitch = real pitch (multiple of 16).
+hipError_t launch_hxv_tiled_real(const DevSector& s, const TilePlan& plan, const double* v, double* wt_scratch, double* hv, hipStream_t st,
+                                 const LzEpilogue* lz = nullptr);
 
 }  // namespace hxv

@@ -41,7 +41,7 @@ class _Stats(C.Structure):
 # every symbol include/hxv.h declares (tests check that the library exports all of them)
 EXPORTS = [
     "hxv_create_from_model", "hxv_create_from_csr", "hxv_create_dw_panel", "hxv_apply_dw_panel", "hxv_apply_up_add", "hxv_destroy", "hxv_vecdim", "hxv_dims", "hxv_apply_host",
-    "hxv_apply_device", "hxv_fullvec_elems", "hxv_localvec_elems", "hxv_pitch", "hxv_time_apply", "hxv_lanczos_tridiag", "hxv_lanczos_eigh", "hxv_lanczos_tridiag_host", "hxv_lanczos_eigh_host", "hxv_eigh_lowest", "hxv_eigh_lowest_host", "hxv_time_lanczos", "hxv_apply_ladder", "hxv_get_maps",
+    "hxv_apply_device", "hxv_apply_device_real", "hxv_real_vectors_available", "hxv_pitch_real", "hxv_realvec_elems", "hxv_fullvec_elems", "hxv_localvec_elems", "hxv_pitch", "hxv_time_apply", "hxv_lanczos_tridiag", "hxv_lanczos_eigh", "hxv_lanczos_tridiag_host", "hxv_lanczos_eigh_host", "hxv_eigh_lowest", "hxv_eigh_lowest_host", "hxv_time_lanczos", "hxv_apply_ladder", "hxv_get_maps",
     "hxv_nnz", "hxv_get_csr", "hxv_get_diag", "hxv_set_option", "hxv_get_option", "hxv_get_stats", "hxv_last_error",
     "hxv_version",
 ]
@@ -81,6 +81,11 @@ def load_library():
     L.hxv_pitch.restype = i32
     L.hxv_apply_host.argtypes = [vp, i64, vp, vp]
     L.hxv_apply_device.argtypes = [vp, vp, vp, vp]
+    L.hxv_apply_device_real.argtypes = [vp, vp, vp, vp]
+    L.hxv_real_vectors_available.argtypes = [vp]
+    L.hxv_pitch_real.argtypes = [vp]
+    L.hxv_realvec_elems.argtypes = [vp]
+    L.hxv_realvec_elems.restype = i64
     L.hxv_time_apply.argtypes = [vp, vp, vp, i32, C.POINTER(C.c_float)]
     L.hxv_lanczos_tridiag.argtypes = [vp, vp, i32, pd, pd, dbl, pi32]
     L.hxv_lanczos_eigh.argtypes = [vp, i32, dbl, pd, vp, pi32]
@@ -281,6 +286,39 @@ class HxvSector:
                 return out
             return res
         return hv_local
+
+    # -- REAL-vector mode (H real; include/hxv.h) ----------------------------------------------
+    @property
+    def real_vectors_available(self) -> bool:
+        return bool(load_library().hxv_real_vectors_available(self._h))
+
+    def pad_real(self, x):
+        """contiguous real [DimDw*DimUp] -> device layout double[DimDw][pitch_real]."""
+        import torch
+
+        pr = load_library().hxv_pitch_real(self._h)
+        out = torch.zeros(self.DimDw, pr, dtype=torch.float64, device=x.device)
+        out[:, : self.DimUp] = x.view(self.DimDw, self.DimUp)
+        return out.view(-1)
+
+    def unpad_real(self, x):
+        pr = load_library().hxv_pitch_real(self._h)
+        return x.view(self.DimDw, pr)[:, : self.DimUp].reshape(-1)
+
+    def apply_device_real(self, v, hv=None, stream=None):
+        """Hv on a REAL vector (float64 CUDA tensor, contiguous Dim or padded hxv_realvec_elems)."""
+        import torch
+
+        assert v.is_cuda and v.dtype == torch.float64
+        n = load_library().hxv_realvec_elems(self._h)
+        contiguous = v.numel() != n
+        if contiguous:
+            assert v.numel() == self.Dim
+            v = self.pad_real(v)
+        out = hv if hv is not None else torch.zeros(n, dtype=torch.float64, device=v.device)
+        st = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        _chk(load_library().hxv_apply_device_real(self._h, v.data_ptr(), out.data_ptr(), st), "hxv_apply_device_real")
+        return self.unpad_real(out) if (contiguous and hv is None) else out
 
     def to_gather_layout(self, v: np.ndarray, nranks: int) -> np.ndarray:
         """Contiguous full vector (Dim) -> the padded all-gather layout hxv_apply_device expects."""

@@ -114,6 +114,19 @@ int hxv_create_dw_panel(const hxv_model *model, int32_t nup, int32_t ndw, int32_
 int hxv_apply_dw_panel(hxv_handle *panel, const void *d_x, void *d_y, void *stream);
 int hxv_apply_up_add(hxv_handle *h, const void *d_v_local, const void *d_w, void *d_hv_local, void *stream);
 
+/* ---- REAL-vector mode.  When every amplitude of H is real (cdn_hm_* models; not BHZ), H maps real vectors to real
+ * vectors, and a Lanczos run started from a real vector never leaves the reals: the same kernels then run on
+ * double instead of complex(8) elements -- half the bytes of every pass.  The reference keeps complex arrays
+ * throughout (cc_sparse_HxV, ED_VARS_GLOBAL.f90:72-78), so this mode exists only on the device side: the device
+ * Lanczos drivers below select it by themselves when it applies (option "real_vectors", default 1) and convert at
+ * their boundaries; hxv_apply_device_real is the product itself.
+ *   layout: double[DimDw columns][hxv_pitch_real(h) = roundup16(DimUp)], pad rows zero / ignored like above.
+ *   available iff H is real, the tiled kernels are in use, no spH0nd block, nranks==1 (hxv_real_vectors_available).  */
+int32_t hxv_real_vectors_available(const hxv_handle *h);
+int32_t hxv_pitch_real(const hxv_handle *h);
+int64_t hxv_realvec_elems(const hxv_handle *h);
+int hxv_apply_device_real(hxv_handle *h, const void *d_v_real, void *d_hv_real, void *stream);
+
 /* Time `nrep` back-to-back device products with HIP events recorded on the stream the
  * kernels are launched on; returns the mean milliseconds per product.                    */
 int hxv_time_apply(hxv_handle *h, const void *d_v_full, void *d_hv_local, int32_t nrep, float *ms_per_apply);

@@ -292,3 +292,90 @@ def test_eigh_lowest_argument_errors(built):
     shard = hxv.HxvSector.from_model(models.hm_1dchain(Nlat=2, Nbath=2), 3, 3, rank=0, nranks=2)
     with pytest.raises(hxv.HxvError, match="nranks==1"):
         shard.eigh_lowest(1, 10)
+
+
+def test_engine_spectra_vs_numbers_recorded_from_the_reference(built):
+    """The engine's own lowest eigenvalues against the spectra the survey recorded from the REFERENCE's dense sector
+    Hamiltonians (tests/golden/survey_known_answers.json; 8 decimals recorded): the one pin that does not pass through
+    the oracle at all.  nnz and dimensions of the engine's matrices against the recorded ones as well."""
+    import json
+    from pathlib import Path
+    import hxv
+    from hxv import models
+
+    gold = json.loads((Path(__file__).parent / "golden" / "survey_known_answers.json").read_text())
+    g = gold["C1_plaquette_2x2_U4_t1_hfF_sector_2_2"]
+    sec = hxv.HxvSector.from_model(models.plaquette_2x2_nobath(U=4.0, t=1.0, hfmode=False), 2, 2)
+    assert sec.Dim == g["Dim"] and len(sec.csr("up")[1]) == g["nnz_up"]
+    ev, _, nconv, _ = sec.eigh_lowest(4, 36, want_vectors=False)       # Dim=36: the Krylov space closes, all pairs exact
+    assert np.allclose(ev, g["lowest"], atol=5e-9)
+    assert abs(sec.lanczos_eigh(512, 1e-13, want_vector=False)[0] - g["lowest"][0]) < 5e-9
+    m = models.bhz_2d(Nbath=0)
+    g = gold["BHZ_2x2_Norb2_Nspin2_Nbath0_sector_4_4"]
+    sec = hxv.HxvSector.from_model(m, 4, 4)
+    assert sec.Dim == g["Dim"] and len(sec.csr("up")[1]) == g["nnz_up"] and len(sec.csr("dw")[1]) == g["nnz_dw"]
+    ev, _, nconv, _ = sec.eigh_lowest(2, 20, want_vectors=False)       # (the third level is degenerate: one Krylov space sees one copy)
+    assert nconv == 2 and np.allclose(ev, g["lowest"][:2], atol=5e-9)
+    g = gold["BHZ_2x2_Norb2_Nspin2_Nbath0_sector_3_5"]
+    sec = hxv.HxvSector.from_model(m, 3, 5)
+    assert sec.Dim == g["Dim"]
+    ev, _, nconv, _ = sec.eigh_lowest(3, 30, want_vectors=False)
+    assert nconv == 3 and np.allclose(ev, g["lowest"][:3], atol=5e-9)
+
+
+# ---- REAL-vector mode of the device Lanczos drivers (H real + real start vector -> double instead of complex(8)) ---
+def test_real_vector_lanczos_matches_complex_mode(built):
+    import torch
+    import hxv
+    from hxv import models
+    from oracle.oracle import OracleSector
+
+    m = models.hm_1dchain(Nlat=2, Nbath=3)              # Ns=8, sector (4,4), Dim=4900, real H
+    sec = hxv.HxvSector.from_model(m, 4, 4)
+    assert sec.real_vectors_available and sec.get_option("real_vectors") == 1
+    Hd = OracleSector(m, 4, 4).dense()
+    ref = np.linalg.eigvalsh(Hd)
+    rng = np.random.default_rng(5)
+    v = rng.standard_normal(sec.Dim)
+    v /= np.linalg.norm(v)
+    vin = torch.from_numpy(v.astype(np.complex128)).cuda()
+    res = {}
+    for mode in (1, 0):
+        sec.set_option("real_vectors", mode)
+        a, b, n = sec.lanczos_tridiag(vin, 30)
+        assert sec.get_option("lanczos_real_last") == mode
+        e0, vec, nit = sec.lanczos_eigh(512, 1e-13)
+        assert sec.get_option("lanczos_real_last") == mode
+        ev, X, nconv, nmv = sec.eigh_lowest(2, 20)
+        assert sec.get_option("lanczos_real_last") == mode and nconv == 2
+        res[mode] = (a, b, e0, vec.cpu().numpy(), ev, X.cpu().numpy())
+        assert abs(e0 - ref[0]) < 1e-10 and np.abs(ev - ref[:2]).max() < 1e-10
+        x = res[mode][3]
+        assert np.linalg.norm(Hd @ x - e0 * x) < 1e-8 and abs(np.linalg.norm(x) - 1) < 1e-12
+        Xh = res[mode][5].T
+        assert np.linalg.norm(Hd @ Xh - Xh * ev, axis=0).max() < 1e-9
+    # same start vector -> the same tridiagonal matrix in both modes
+    assert np.abs(res[1][0] - res[0][0]).max() < 1e-11 and np.abs(res[1][1] - res[0][1]).max() < 1e-11
+    assert np.abs(res[1][3].imag).max() == 0.0        # real mode returns a real eigenvector in the complex layout
+    # a start vector with an imaginary part keeps the complex path even when real vectors are enabled
+    sec.set_option("real_vectors", 1)
+    vc = models.deterministic_vector(sec.Dim)
+    vc /= np.linalg.norm(vc)
+    sec.lanczos_tridiag(torch.from_numpy(vc).cuda(), 10)
+    assert sec.get_option("lanczos_real_last") == 0
+    # both fused and plain recurrences exist in real mode
+    sec.set_option("lanczos_fused", 0)
+    a2, b2, _ = sec.lanczos_tridiag(vin, 30)
+    assert sec.get_option("lanczos_real_last") == 1
+    assert np.abs(a2 - res[1][0]).max() < 1e-11 and np.abs(b2 - res[1][1]).max() < 1e-11
+
+
+def test_real_vector_mode_not_used_for_complex_h(built):
+    import hxv
+    from hxv import models
+
+    sec = hxv.HxvSector.from_model(models.bhz_2d(Nbath=0), 4, 4)
+    sec.lanczos_eigh(512, 1e-12, want_vector=False)
+    assert sec.get_option("lanczos_real_last") == 0
+    sec.eigh_lowest(1, 10, want_vectors=False)
+    assert sec.get_option("lanczos_real_last") == 0

@@ -293,3 +293,48 @@ def test_alltoall_halves_reproduce_the_product(built, P):
             torch.cuda.synchronize()
             assert _rel(hv.cpu().numpy(), ref[sec.mpiIshift: sec.mpiIshift + sec.vecDim]) <= TOL, (m.name, P, r)
             sec.close()
+
+
+# ---- REAL-vector mode (H real): same kernels on double elements ---------------------------------------------------
+@pytest.mark.parametrize("case", ["C1", "chain", "chain_odd", "kanamori_u", "C2"])
+def test_real_vector_product_equals_complex_product(built, case):
+    import torch
+    import hxv
+    from hxv import models
+    from oracle.oracle import OracleSector
+
+    if case == "C1":
+        m, (nup, ndw) = models.plaquette_2x2_nobath(U=4.0, t=1.0, hfmode=False), (2, 2)
+    elif case == "chain":
+        m, (nup, ndw) = models.hm_1dchain(Nlat=2, Nbath=2, eps_bath=[0.3, 0.6]), (3, 3)
+    elif case == "chain_odd":
+        m, (nup, ndw) = models.hm_1dchain(Nlat=3, Nbath=2), (4, 5)          # DimUp != DimDw, odd dimensions
+    elif case == "kanamori_u":
+        m, (nup, ndw) = models.hm_2dsquare(Nbath=1), (4, 3)
+    else:
+        m, (nup, ndw) = models.hm_1dchain(), (6, 6)
+    sec = hxv.HxvSector.from_model(m, nup, ndw)
+    assert sec.real_vectors_available
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal(sec.Dim)
+    ref = OracleSector(m, nup, ndw).spMatVec_main(x.astype(np.complex128))
+    assert np.abs(ref.imag).max() == 0.0
+    xr = torch.from_numpy(x).cuda()
+    hr = sec.apply_device_real(xr).cpu().numpy()
+    hc = sec.apply_device(xr.to(torch.complex128)).cpu().numpy()
+    scale = np.abs(ref).max()
+    assert np.abs(hr - ref.real).max() <= 1e-13 * scale
+    assert np.abs(hr - hc.real).max() <= 1e-14 * scale and np.abs(hc.imag).max() == 0.0
+
+
+def test_real_vector_mode_refused_for_complex_h_and_shards(built):
+    import torch
+    import hxv
+    from hxv import models
+
+    bhz = hxv.HxvSector.from_model(models.bhz_2d(Nbath=0), 4, 4)
+    assert not bhz.real_vectors_available
+    with pytest.raises(hxv.HxvError, match="complex amplitudes"):
+        bhz.apply_device_real(torch.zeros(bhz.Dim, dtype=torch.float64, device="cuda"))
+    shard = hxv.HxvSector.from_model(models.hm_1dchain(Nlat=2, Nbath=2), 3, 3, rank=1, nranks=2)
+    assert not shard.real_vectors_available
