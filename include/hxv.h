@@ -139,7 +139,12 @@ int hxv_time_apply(hxv_handle *h, const void *d_v_full, void *d_hv_local, int32_
  *   *nsteps = iterations done (early exit when beta < threshold).
  * eigh: lowest eigenvalue *egs and eigenvector d_vect (device, Dim, written) from a
  *   deterministic start vector; stops when |dE| < threshold (and, if d_vect is wanted, the Ritz
- *   residual estimate |beta*y_last| < 1e-11*max(1,|E|)) or at nitermax (ED_DIAG.f90:176).     */
+ *   residual estimate |beta*y_last| < 1e-11*max(1,|E|)) or at nitermax (ED_DIAG.f90:176).
+ * REAL-vector mode (above): with option "real_vectors" = 1 (default) these drivers and hxv_eigh_lowest run on real
+ *   vectors whenever hxv_real_vectors_available(h) and the start vector is real (eigh / eigh_lowest: the engine's own
+ *   start vector is then real; tridiag: d_vin must have exactly zero imaginary part, else the complex path runs).
+ *   Inputs and outputs keep the complex layout; alanc/blanc/E are the same numbers.  hxv_get_option(h,"lanczos_real_last")
+ *   tells which path the last run took.                                                               */
 int hxv_lanczos_tridiag(hxv_handle *h, const void *d_vin, int32_t nlanc, double *alanc, double *blanc, double threshold,
                         int32_t *nsteps);
 int hxv_lanczos_eigh(hxv_handle *h, int32_t nitermax, double threshold, double *egs, void *d_vect, int32_t *niter);
