@@ -1,5 +1,5 @@
-// C-ABI of the engine (include/hxv.h): handle management, host/device products, device
-// Lanczos.  Everything here runs on one HIP device and one stream per handle
+// C-ABI of the engine (include/hxv.h): handle management, host/device products, options and introspection
+// (the Lanczos drivers live in hxv_lanczos.hip / hxv_eigh.hip).  Everything runs on one HIP device and one stream per handle
 // (SURVEY.md 8b "Threading / re-entrancy": one open sector at a time per rank).
 #include <algorithm>
 #include <cmath>
@@ -23,10 +23,7 @@ int fail(int code, const std::string& msg) {
 }
 }  // namespace hxv
 
-namespace {
-
-
-
+namespace hxv {
 int ensure_wt(hxv_handle* h) {
   const int64_t need = std::max<int64_t>(tiled_wt_elems(h->dev, h->plan), 1);
   if (h->d_wt && h->wt_elems >= need) return HXV_OK;
@@ -43,6 +40,9 @@ int ensure_wt(hxv_handle* h) {
   h->device_bytes += need * (int64_t)sizeof(double2);
   return HXV_OK;
 }
+}  // namespace hxv
+
+namespace {
 
 int finish_create(hxv_handle* h, int device, hxv_handle** out) {
   int ndev = 0;
@@ -475,670 +475,3 @@ extern "C" int hxv_debug_strided_read(hxv_handle* h, const void* d_v, void* d_ou
   *ms = t / nrep;
   return 0;
 }
-
-// ===========================================================================================
-// Device Lanczos
-// ===========================================================================================
-namespace {
-
-// w -= b*qm ; partial sums of Re<q,w>
-__global__ void __launch_bounds__(256) lz_sub_dot(int64_t n, double2* __restrict__ w, const double2* __restrict__ qm,
-                                                  const double2* __restrict__ q, const double* __restrict__ scal, int ib,
-                                                  double* __restrict__ partial) {
-  const double b = ib >= 0 ? scal[ib] : 0.0;
-  double acc = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    double2 x = w[i];
-    if (ib >= 0) {
-      double2 p = qm[i];
-      x.x -= b * p.x;
-      x.y -= b * p.y;
-      w[i] = x;
-    }
-    double2 y = q[i];
-    acc += y.x * x.x + y.y * x.y;
-  }
-  __shared__ double red[256];
-  red[threadIdx.x] = acc;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
-}
-
-// w -= a*q ; partial sums of |w|^2
-__global__ void __launch_bounds__(256) lz_sub_nrm(int64_t n, double2* __restrict__ w, const double2* __restrict__ q,
-                                                  const double* __restrict__ scal, int ia, double* __restrict__ partial) {
-  const double a = scal[ia];
-  double acc = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    double2 x = w[i], y = q[i];
-    x.x -= a * y.x;
-    x.y -= a * y.y;
-    w[i] = x;
-    acc += x.x * x.x + x.y * x.y;
-  }
-  __shared__ double red[256];
-  red[threadIdx.x] = acc;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
-}
-
-// partial sums of |x|^2
-__global__ void __launch_bounds__(256) lz_nrm(int64_t n, const double2* __restrict__ x, double* __restrict__ partial) {
-  double acc = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    double2 a = x[i];
-    acc += a.x * a.x + a.y * a.y;
-  }
-  __shared__ double red[256];
-  red[threadIdx.x] = acc;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
-}
-
-// scal[io] = op(sum partial[0..np))   op: 0 identity, 1 sqrt
-__global__ void __launch_bounds__(256) lz_final(const double* __restrict__ partial, int np, double* __restrict__ scal, int io, int op) {
-  __shared__ double red[256];
-  double acc = 0.0;
-  for (int i = threadIdx.x; i < np; i += 256) acc += partial[i];
-  red[threadIdx.x] = acc;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) scal[io] = op ? sqrt(red[0]) : red[0];
-}
-
-// q = w / scal[ib]
-__global__ void __launch_bounds__(256) lz_scale(int64_t n, double2* q, const double2* w,
-                                                const double* __restrict__ scal, int ib) {
-  const double r = 1.0 / scal[ib];
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    double2 x = w[i];
-    q[i] = make_double2(x.x * r, x.y * r);
-  }
-}
-
-// y += c * q   (c real, host scalar)
-__global__ void __launch_bounds__(256) lz_axpy(int64_t n, double2* __restrict__ y, const double2* __restrict__ q, double c) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    double2 x = q[i], z = y[i];
-    y[i] = make_double2(z.x + c * x.x, z.y + c * x.y);
-  }
-}
-
-// deterministic start vector: splitmix64 hash of the global index -> uniform(-0.5,0.5) re and im
-__global__ void __launch_bounds__(256) lz_init(int64_t n, double2* __restrict__ q, uint64_t seed, int dimup, int pitch) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t col = i / pitch;
-    const int row = (int)(i - col * pitch);
-    if (row >= dimup) {  // pad rows stay zero: they must not enter the dot products
-      q[i] = make_double2(0.0, 0.0);
-      continue;
-    }
-    uint64_t z = (uint64_t)(col * dimup + row) * 2 + seed;
-    double r[2];
-    for (int k = 0; k < 2; ++k) {
-      uint64_t x = z + (uint64_t)k + 0x9E3779B97F4A7C15ull;
-      x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-      x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-      x = x ^ (x >> 31);
-      r[k] = (double)(x >> 11) * (1.0 / 9007199254740992.0) - 0.5;
-    }
-    q[i] = make_double2(r[0], r[1]);
-  }
-}
-
-int grid_for(int64_t n) { return (int)std::min<int64_t>((n + 255) / 256, RED_BLOCKS); }
-
-// ---- REAL-vector mode: layout conversions and the real start vector ----------------------------------------------
-// real [DimDw][pr] <- Re(complex [DimDw][pc]); pads zero.  partial = per-block sum of Im^2 (may be null)
-__global__ void __launch_bounds__(256) lz_to_real(int dimup, int dimdw, int pc, int pr, const double2* __restrict__ src,
-                                                  double* __restrict__ dst, double* __restrict__ partial) {
-  const int64_t n = (int64_t)dimdw * pr;
-  double acc = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t col = i / pr;
-    const int row = (int)(i - col * pr);
-    double x = 0.0;
-    if (row < dimup) {
-      const double2 z = src[col * pc + row];
-      x = z.x;
-      acc += z.y * z.y;
-    }
-    if (dst) dst[i] = x;
-  }
-  __shared__ double red[256];
-  red[threadIdx.x] = acc;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0 && partial) partial[blockIdx.x] = red[0];
-}
-
-// complex [DimDw][pc] <- real [DimDw][pr]; pads zero
-__global__ void __launch_bounds__(256) lz_to_complex(int dimup, int dimdw, int pc, int pr, const double* __restrict__ src,
-                                                     double2* __restrict__ dst) {
-  const int64_t n = (int64_t)dimdw * pc;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t col = i / pc;
-    const int row = (int)(i - col * pc);
-    dst[i] = make_double2(row < dimup ? src[col * pr + row] : 0.0, 0.0);
-  }
-}
-
-// real start vector: the real part of lz_init's vector
-__global__ void __launch_bounds__(256) lz_init_real(int64_t n, double* __restrict__ q, uint64_t seed, int dimup, int pitch) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t col = i / pitch;
-    const int row = (int)(i - col * pitch);
-    if (row >= dimup) {
-      q[i] = 0.0;
-      continue;
-    }
-    uint64_t x = (uint64_t)(col * dimup + row) * 2 + seed + 0x9E3779B97F4A7C15ull;
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-    x = x ^ (x >> 31);
-    q[i] = (double)(x >> 11) * (1.0 / 9007199254740992.0) - 0.5;
-  }
-}
-
-// Symmetric tridiagonal eigen-solver (implicit QL with Wilkinson shifts): d[n] diagonal,
-// e[n] sub-diagonal in e[1..n-1] (e[0] unused).  On exit d = eigenvalues (unsorted) and, if z,
-// z (n x n, column-major, initialised to identity by the caller) = eigenvectors.
-bool tridiag_ql(int n, std::vector<double>& d, std::vector<double>& e, std::vector<double>* z) {
-  for (int i = 1; i < n; ++i) e[i - 1] = e[i];
-  e[n - 1] = 0.0;
-  for (int l = 0; l < n; ++l) {
-    int iter = 0, m;
-    do {
-      for (m = l; m < n - 1; ++m) {
-        double dd = std::fabs(d[m]) + std::fabs(d[m + 1]);
-        if (std::fabs(e[m]) <= 2.3e-16 * dd) break;
-      }
-      if (m != l) {
-        if (iter++ == 200) return false;
-        double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
-        double r = std::hypot(g, 1.0);
-        g = d[m] - d[l] + e[l] / (g + (g >= 0 ? std::fabs(r) : -std::fabs(r)));
-        double s = 1.0, c = 1.0, p = 0.0;
-        int i;
-        for (i = m - 1; i >= l; --i) {
-          double f = s * e[i], b = c * e[i];
-          r = std::hypot(f, g);
-          e[i + 1] = r;
-          if (r == 0.0) {
-            d[i + 1] -= p;
-            e[m] = 0.0;
-            break;
-          }
-          s = f / r;
-          c = g / r;
-          g = d[i + 1] - p;
-          r = (d[i] - g) * s + 2.0 * c * b;
-          p = s * r;
-          d[i + 1] = g + p;
-          g = c * r - b;
-          if (z)
-            for (int k = 0; k < n; ++k) {
-              double* zz = z->data();
-              f = zz[k + (size_t)(i + 1) * n];
-              zz[k + (size_t)(i + 1) * n] = s * zz[k + (size_t)i * n] + c * f;
-              zz[k + (size_t)i * n] = c * zz[k + (size_t)i * n] - s * f;
-            }
-        }
-        if (r == 0.0 && i >= l) continue;
-        d[l] -= p;
-        e[l] = g;
-        e[m] = 0.0;
-      }
-    } while (m != l);
-  }
-  return true;
-}
-
-struct LzBuf {
-  double2 *q, *qm, *w;
-};
-
-// scal[i] = scal[a] * scal[b]
-__global__ void lz_mul(double* scal, int i, int a, int b) { scal[i] = scal[a] * scal[b]; }
-
-// Lanczos recurrence on device.  Two implementations of one step:
-//  * plain : w = H q (any kernel), then lz_sub_dot / lz_sub_nrm / lz_scale on normalised vectors;
-//  * fused : vectors are kept UNNORMALISED (q_k = s*X, s = 1/beta_k); pass A's epilogue produces
-//            w = s*H X - c*Xm and the partial sums of alpha, one more pass subtracts alpha*q and reduces beta.
-//            144 B/state per iteration instead of 224.
-struct LzRunner {
-  hxv_handle* h;
-  LzBuf b;
-  bool fused;
-  bool real;            // REAL-vector mode: the buffers hold double[DimDw][pitch_real]; every streaming kernel below is
-                        // elementwise with real scalars, so it runs unchanged on the buffer viewed as n2 double2 elements
-  int64_t n2;           // double2 elements of one vector
-  bool first = true;
-  double s_cur = 1.0;   // q = s_cur * b.q (fused) ; 1 (plain)
-  double beta_prev = 1.0;
-
-  LzRunner(hxv_handle* hh, double2* x, double2* xm, double2* w, bool real_vec = false) : h(hh), b{x, xm, w}, real(real_vec) {
-    fused = hh->kernel == 1 && hh->plan.usable && !hh->dev.nd.active && hh->plan.opt.passes == 3 && hh->plan.opt.debug == 0 &&
-            hh->host.nranks == 1 && hh->lz_fused;
-    n2 = real ? (int64_t)pitch_real_of(hh) * hh->host.dimdw / 2 : (int64_t)hh->host.pitch * hh->host.dimdw;
-    hh->last_real = real ? 1 : 0;
-  }
-
-  // b.q holds a vector of norm `nrm` (pass 1.0 if already normalised)
-  int begin(double nrm) {
-    first = true;
-    s_cur = 1.0 / nrm;
-    beta_prev = nrm;
-    if (!fused && nrm != 1.0) return fail(HXV_ERR_STATE, "plain Lanczos expects a normalised start vector");
-    return HXV_OK;
-  }
-
-  int step(double* alpha, double* beta) {
-    const int64_t n = n2;
-    const int g = grid_for(n);
-    if (!fused) {
-      int rc = real ? hxv_apply_device_real(h, b.q, b.w, h->stream) : hxv_apply_device(h, b.q, b.w, h->stream);
-      if (rc) return rc;
-      hipLaunchKernelGGL(lz_sub_dot, dim3(g), dim3(256), 0, h->stream, n, b.w, b.qm, b.q, h->d_scalars, first ? -1 : 2, h->d_partials);
-      hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_partials, g, h->d_scalars, 0, 0);
-      hipLaunchKernelGGL(lz_sub_nrm, dim3(g), dim3(256), 0, h->stream, n, b.w, b.q, h->d_scalars, 0, h->d_partials + RED_BLOCKS);
-      hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_partials + RED_BLOCKS, g, h->d_scalars, 1, 1);
-    } else {
-      const int64_t nwg = tiled_pass_up_workgroups(h->dev, h->plan, real);
-      if (nwg > h->lz_partial_n) {
-        if (h->d_lz_partial) (void)hipFree(h->d_lz_partial);
-        HIPCHK(hipMalloc((void**)&h->d_lz_partial, (size_t)nwg * sizeof(double)));
-        h->lz_partial_n = nwg;
-      }
-      int rcw = ensure_wt(h);
-      if (rcw) return rcw;
-      // scal[2] = s, scal[3] = c = beta_k / beta_{k-1}
-      const double sc[2] = {s_cur, first ? 0.0 : 1.0 / (s_cur * beta_prev)};
-      HIPCHK(hipMemcpyAsync(h->d_scalars + 2, sc, 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-      LzEpilogue ep;
-      ep.xm = first ? nullptr : b.qm;
-      ep.scal = h->d_scalars;
-      ep.i_s = 2;
-      ep.i_c = 3;
-      ep.partial = h->d_lz_partial;
-      hipError_t e;
-      if (real) {
-        DevSector d = h->dev;
-        d.pitch = pitch_real_of(h);
-        e = launch_hxv_tiled_real(d, h->plan, (const double*)b.q, (double*)h->d_wt, (double*)b.w, h->stream, &ep);
-      } else {
-        e = launch_hxv_tiled(h->dev, h->plan, b.q, h->d_wt, b.w, h->stream, &ep);
-      }
-      if (e != hipSuccess) return fail(HXV_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
-      h->n_apply++;
-      hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_lz_partial, (int)nwg, h->d_scalars, 0, 0);
-      hipLaunchKernelGGL(lz_mul, dim3(1), dim3(1), 0, h->stream, h->d_scalars, 4, 0, 2);
-      hipLaunchKernelGGL(lz_sub_nrm, dim3(g), dim3(256), 0, h->stream, n, b.w, b.q, h->d_scalars, 4, h->d_partials + RED_BLOCKS);
-      hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_partials + RED_BLOCKS, g, h->d_scalars, 1, 1);
-    }
-    double host[2];
-    HIPCHK(hipMemcpyAsync(host, h->d_scalars, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    *alpha = host[0];
-    *beta = host[1];
-    last_beta = host[1];
-    return HXV_OK;
-  }
-
-  // rotate to the next Lanczos vector (needs the beta returned by step())
-  int advance() {
-    const int64_t n = n2;
-    if (!fused) {
-      HIPCHK(hipMemcpyAsync(h->d_scalars + 2, h->d_scalars + 1, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-      std::swap(b.q, b.qm);
-      hipLaunchKernelGGL(lz_scale, dim3(grid_for(n)), dim3(256), 0, h->stream, n, b.q, b.w, h->d_scalars, 2);
-    } else {
-      double2* old_m = b.qm;
-      b.qm = b.q;      // X_{k-1}
-      b.q = b.w;       // X_k = unnormalised residual
-      b.w = old_m;
-      beta_prev = 1.0 / s_cur;   // beta_k
-      s_cur = 1.0 / last_beta;   // 1/beta_{k+1}
-    }
-    first = false;
-    return HXV_OK;
-  }
-
-  double last_beta = 0.0;
-  // current normalised Lanczos vector = scale() * vec()
-  const double2* vec() const { return b.q; }
-  double scale() const { return fused ? s_cur : 1.0; }
-};
-
-// may this Lanczos run use real vectors?  (d_vin: optional complex start vector that must then be purely real)
-bool want_real(hxv_handle* h) { return h->real_vectors && !real_mode_blocker(h); }
-
-// the three work vectors of the single-vector Lanczos; `real` = layout of the coming run.  The pad rows of the two
-// layouts sit at different places and must be zero (the reductions run over the padded arrays, the products never
-// write pads), so the buffers are cleared whenever the layout changes.
-int ensure_lz(hxv_handle* h, bool real) {
-  if (h->host.nranks != 1) return fail(HXV_ERR_STATE, "device Lanczos needs nranks==1 (global dots belong to the caller's communicator)");
-  HIPCHK(hipSetDevice(h->device));
-  const size_t bytes = (size_t)h->host.pitch * h->host.dimdw * sizeof(double2);
-  for (auto& p : h->d_lz)
-    if (!p) {
-      HIPCHK(hipMalloc((void**)&p, bytes));
-      HIPCHK(hipMemset(p, 0, bytes));
-      h->device_bytes += (int64_t)bytes;
-    }
-  if (h->lz_buf_mode != (real ? 1 : 0)) {
-    for (auto& p : h->d_lz) HIPCHK(hipMemsetAsync(p, 0, bytes, h->stream));
-    h->lz_buf_mode = real ? 1 : 0;
-  }
-  return HXV_OK;
-}
-
-}  // namespace
-
-namespace hxv {
-void launch_to_real(const hxv_handle* h, const double2* src, double* dst, hipStream_t st) {
-  const int pr = pitch_real_of(h);
-  hipLaunchKernelGGL(lz_to_real, dim3(grid_for((int64_t)pr * h->host.dimdw)), dim3(256), 0, st, h->host.dimup, h->host.dimdw, h->host.pitch, pr,
-                     src, dst, (double*)nullptr);
-}
-void launch_to_complex(const hxv_handle* h, const double* src, double2* dst, hipStream_t st) {
-  hipLaunchKernelGGL(lz_to_complex, dim3(grid_for((int64_t)h->host.pitch * h->host.dimdw)), dim3(256), 0, st, h->host.dimup, h->host.dimdw,
-                     h->host.pitch, pitch_real_of(h), src, dst);
-}
-void launch_init_real(const hxv_handle* h, double* q, uint64_t seed, hipStream_t st) {
-  const int64_t n = (int64_t)pitch_real_of(h) * h->host.dimdw;
-  hipLaunchKernelGGL(lz_init_real, dim3(grid_for(n)), dim3(256), 0, st, n, q, seed, h->host.dimup, pitch_real_of(h));
-}
-}  // namespace hxv
-
-extern "C" {
-
-int hxv_lanczos_tridiag(hxv_handle* h, const void* d_vin, int32_t nlanc, double* alanc, double* blanc, double threshold,
-                        int32_t* nsteps) {
-  if (!h || !d_vin || nlanc < 1 || !alanc || !blanc) return fail(HXV_ERR_ARG, "hxv_lanczos_tridiag: bad argument");
-  if (h->host.nranks != 1) return fail(HXV_ERR_STATE, "device Lanczos needs nranks==1 (global dots belong to the caller's communicator)");
-  HIPCHK(hipSetDevice(h->device));
-  const int64_t n = (int64_t)h->host.pitch * h->host.dimdw;
-  // REAL-vector mode: H real and the start vector purely real (c / c^dagger applied to a real ground state is) ->
-  // the whole recurrence stays real; alanc/blanc are the same numbers at half the bytes per pass
-  bool real = want_real(h);
-  if (real) {  // sum of Im(vin)^2 (dst = null: reduction only)
-    const int pr = pitch_real_of(h);
-    const int g = grid_for((int64_t)pr * h->host.dimdw);
-    hipLaunchKernelGGL(lz_to_real, dim3(g), dim3(256), 0, h->stream, h->host.dimup, h->host.dimdw, h->host.pitch, pr,
-                       (const double2*)d_vin, (double*)nullptr, h->d_partials);
-    hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_partials, g, h->d_scalars, 5, 0);
-    double im2 = 0.0;
-    HIPCHK(hipMemcpyAsync(&im2, h->d_scalars + 5, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    real = im2 == 0.0;
-  }
-  int rc = ensure_lz(h, real);
-  if (rc) return rc;
-  LzRunner lz(h, h->d_lz[0], h->d_lz[1], h->d_lz[2], real);
-  if (real)
-    launch_to_real(h, (const double2*)d_vin, (double*)lz.b.q, h->stream);
-  else
-    HIPCHK(hipMemcpyAsync(lz.b.q, d_vin, (size_t)n * sizeof(double2), hipMemcpyDeviceToDevice, h->stream));
-  rc = lz.begin(1.0);  // vin is normalised by the caller (ED_GF_NORMAL.f90:197-199)
-  if (rc) return rc;
-  for (int k = 0; k < nlanc; ++k) {
-    alanc[k] = 0;
-    blanc[k] = 0;
-  }
-  int k = 0;
-  for (; k < nlanc; ++k) {
-    double a, bt;
-    rc = lz.step(&a, &bt);
-    if (rc) return rc;
-    alanc[k] = a;
-    if (k + 1 < nlanc) blanc[k + 1] = bt;
-    if (std::fabs(bt) < threshold) {
-      ++k;
-      break;
-    }
-    if (k + 1 < nlanc) {
-      rc = lz.advance();
-      if (rc) return rc;
-    }
-  }
-  HIPCHK(hipStreamSynchronize(h->stream));
-  if (nsteps) *nsteps = k;
-  return HXV_OK;
-}
-
-int hxv_lanczos_eigh(hxv_handle* h, int32_t nitermax, double threshold, double* egs, void* d_vect, int32_t* niter) {
-  if (!h || nitermax < 1 || !egs) return fail(HXV_ERR_ARG, "hxv_lanczos_eigh: bad argument");
-  const bool real = want_real(h);  // the start vector is ours: real when H is (REAL-vector mode)
-  int rc = ensure_lz(h, real);
-  if (rc) return rc;
-  const int64_t nc = (int64_t)h->host.pitch * h->host.dimdw;
-  const int64_t n = real ? (int64_t)pitch_real_of(h) * h->host.dimdw / 2 : nc;  // double2 elements per vector
-  const int g = grid_for(n);
-  const int nmax = (int)std::min<int64_t>(nitermax, h->host.dim);
-  const uint64_t seed = 0x5EED5EEDull;
-  // deterministic start vector, normalised
-  auto start = [&](LzRunner& lz) -> int {
-    if (real)
-      launch_init_real(h, (double*)lz.b.w, seed, h->stream);
-    else
-      hipLaunchKernelGGL(lz_init, dim3(g), dim3(256), 0, h->stream, n, lz.b.w, seed, h->host.dimup, h->host.pitch);
-    HIPCHK(hipMemsetAsync(h->d_scalars, 0, 8 * sizeof(double), h->stream));
-    hipLaunchKernelGGL(lz_nrm, dim3(g), dim3(256), 0, h->stream, n, lz.b.w, h->d_partials + RED_BLOCKS);
-    hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_partials + RED_BLOCKS, g, h->d_scalars, 1, 1);
-    hipLaunchKernelGGL(lz_scale, dim3(g), dim3(256), 0, h->stream, n, lz.b.q, lz.b.w, h->d_scalars, 1);
-    return lz.begin(1.0);
-  };
-  LzRunner lz(h, h->d_lz[0], h->d_lz[1], h->d_lz[2], real);
-  rc = start(lz);
-  if (rc) return rc;
-  std::vector<double> al, be(1, 0.0);
-  double e_old = 1e300, e_new = 0;
-  int k = 0;
-  std::vector<double> d, e;
-  for (; k < nmax; ++k) {
-    double a, bt;
-    rc = lz.step(&a, &bt);
-    if (rc) return rc;
-    al.push_back(a);
-    d = al;
-    e = be;
-    if (!tridiag_ql((int)d.size(), d, e, nullptr)) return fail(HXV_ERR_STATE, "tridiagonal QL did not converge");
-    e_new = *std::min_element(d.begin(), d.end());
-    bool conv = std::fabs(e_new - e_old) < threshold;
-    e_old = e_new;
-    if (conv && d_vect) {
-      // the energy converges quadratically faster than the vector: before accepting, require the Ritz
-      // residual estimate |beta_{k+1} * y_k| (last component of the tridiagonal eigenvector) to be small too
-      const int m = (int)al.size();
-      std::vector<double> dd = al, ee = be, zz((size_t)m * m, 0.0);
-      ee.resize(m, 0.0);
-      for (int i = 0; i < m; ++i) zz[i + (size_t)i * m] = 1.0;
-      if (!tridiag_ql(m, dd, ee, &zz)) return fail(HXV_ERR_STATE, "tridiagonal QL did not converge");
-      int jm = (int)(std::min_element(dd.begin(), dd.end()) - dd.begin());
-      const double resid = std::fabs(bt * zz[(size_t)(m - 1) + (size_t)jm * m]);
-      conv = resid < 1e-11 * std::max(1.0, std::fabs(e_new));
-    }
-    if (conv || std::fabs(bt) < 1e-14 || k + 1 == nmax) {
-      ++k;
-      break;
-    }
-    be.push_back(bt);
-    rc = lz.advance();
-    if (rc) return rc;
-  }
-  *egs = e_new;
-  if (niter) *niter = k;
-  if (d_vect) {
-    // second pass: re-run the recurrence and accumulate the Ritz vector sum_j y_j q_j
-    const int m = (int)al.size();
-    d = al;
-    e = be;
-    e.resize(m, 0.0);
-    std::vector<double> z((size_t)m * m, 0.0);
-    for (int i = 0; i < m; ++i) z[i + (size_t)i * m] = 1.0;
-    if (!tridiag_ql(m, d, e, &z)) return fail(HXV_ERR_STATE, "tridiagonal QL did not converge");
-    int jmin = (int)(std::min_element(d.begin(), d.end()) - d.begin());
-    const double* y = &z[(size_t)jmin * m];
-    double2* out = (double2*)d_vect;
-    LzRunner lz2(h, h->d_lz[0], h->d_lz[1], h->d_lz[2], real);
-    rc = start(lz2);
-    if (rc) return rc;
-    HIPCHK(hipMemsetAsync(out, 0, (size_t)n * sizeof(double2), h->stream));
-    for (int j = 0; j < m; ++j) {
-      hipLaunchKernelGGL(lz_axpy, dim3(g), dim3(256), 0, h->stream, n, out, lz2.vec(), y[j] * lz2.scale());
-      if (j + 1 == m) break;
-      double a, bt;
-      rc = lz2.step(&a, &bt);
-      if (rc) return rc;
-      rc = lz2.advance();
-      if (rc) return rc;
-    }
-    // normalise the Ritz vector
-    hipLaunchKernelGGL(lz_nrm, dim3(g), dim3(256), 0, h->stream, n, out, h->d_partials + RED_BLOCKS);
-    hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_partials + RED_BLOCKS, g, h->d_scalars, 1, 1);
-    hipLaunchKernelGGL(lz_scale, dim3(g), dim3(256), 0, h->stream, n, out, out, h->d_scalars, 1);
-    if (real) {
-      // the Ritz vector was accumulated as a real vector in d_vect's memory: expand it to the complex layout of the API
-      HIPCHK(hipMemcpyAsync(h->d_lz[2], out, (size_t)n * sizeof(double2), hipMemcpyDeviceToDevice, h->stream));
-      launch_to_complex(h, (const double*)h->d_lz[2], out, h->stream);
-    }
-    HIPCHK(hipStreamSynchronize(h->stream));
-  }
-  return HXV_OK;
-}
-
-namespace {
-int ensure_stage(hxv_handle* h) {
-  const size_t bytes = (size_t)h->host.pitch * h->host.dimdw * sizeof(double2);
-  if (!h->d_stage_v) {
-    HIPCHK(hipMalloc((void**)&h->d_stage_v, bytes));
-    HIPCHK(hipMalloc((void**)&h->d_stage_hv, bytes));
-    HIPCHK(hipMemset(h->d_stage_v, 0, bytes));
-    HIPCHK(hipMemset(h->d_stage_hv, 0, bytes));
-    h->device_bytes += 2 * (int64_t)bytes;
-  }
-  return HXV_OK;
-}
-}  // namespace
-
-int hxv_lanczos_tridiag_host(hxv_handle* h, const void* vin_host, int32_t nlanc, double* alanc, double* blanc, double threshold,
-                             int32_t* nsteps) {
-  if (!h || !vin_host) return fail(HXV_ERR_ARG, "hxv_lanczos_tridiag_host: NULL argument");
-  if (h->host.nranks != 1) return fail(HXV_ERR_STATE, "hxv_lanczos_tridiag_host needs nranks==1");
-  HIPCHK(hipSetDevice(h->device));
-  int rc = ensure_stage(h);
-  if (rc) return rc;
-  const size_t col = (size_t)h->host.dimup * sizeof(double2), pit = (size_t)h->host.pitch * sizeof(double2);
-  HIPCHK(hipMemcpy2DAsync(h->d_stage_v, pit, vin_host, col, col, (size_t)h->host.dimdw, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  return hxv_lanczos_tridiag(h, h->d_stage_v, nlanc, alanc, blanc, threshold, nsteps);
-}
-
-int hxv_lanczos_eigh_host(hxv_handle* h, int32_t nitermax, double threshold, double* egs, void* vect_host, int32_t* niter) {
-  if (!h) return fail(HXV_ERR_ARG, "hxv_lanczos_eigh_host: NULL handle");
-  if (h->host.nranks != 1) return fail(HXV_ERR_STATE, "hxv_lanczos_eigh_host needs nranks==1");
-  HIPCHK(hipSetDevice(h->device));
-  int rc = ensure_stage(h);
-  if (rc) return rc;
-  rc = hxv_lanczos_eigh(h, nitermax, threshold, egs, vect_host ? h->d_stage_hv : nullptr, niter);
-  if (rc) return rc;
-  if (vect_host) {
-    const size_t col = (size_t)h->host.dimup * sizeof(double2), pit = (size_t)h->host.pitch * sizeof(double2);
-    HIPCHK(hipMemcpy2DAsync(vect_host, col, h->d_stage_hv, pit, col, (size_t)h->host.dimdw, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-  }
-  return HXV_OK;
-}
-
-int hxv_apply_ladder(hxv_handle* from, hxv_handle* to, int32_t orbital, int32_t spin, int32_t create, const void* d_psi, void* d_out,
-                     double* norm2) {
-  if (!from || !to || !d_psi || !d_out) return fail(HXV_ERR_ARG, "hxv_apply_ladder: NULL argument");
-  const SectorHost &a = from->host, &b = to->host;
-  if (a.nranks != 1 || b.nranks != 1) return fail(HXV_ERR_STATE, "hxv_apply_ladder needs nranks==1 (the reference does this step on the master)");
-  if (a.map_up.empty() || b.map_up.empty()) return fail(HXV_ERR_STATE, "hxv_apply_ladder needs handles built from a model (basis maps)");
-  if (from->device != to->device) return fail(HXV_ERR_ARG, "hxv_apply_ladder: handles on different devices");
-  if (a.ns != b.ns || orbital < 0 || orbital >= a.ns || spin < 0 || spin > 1) return fail(HXV_ERR_ARG, "hxv_apply_ladder: bad orbital/spin");
-  const int d = create ? 1 : -1;
-  if (spin == 0 ? (b.nup != a.nup + d || b.ndw != a.ndw) : (b.ndw != a.ndw + d || b.nup != a.nup))
-    return fail(HXV_ERR_ARG, "hxv_apply_ladder: `to` is not the sector reached by this operator");
-  HIPCHK(hipSetDevice(to->device));
-  HIPCHK(hipMemsetAsync(d_out, 0, (size_t)b.pitch * b.dimdw * sizeof(double2), to->stream));  // pad rows = 0
-  const uint32_t* mf = spin == 0 ? from->dev.diag.map_up : from->dev.diag.map_dw;
-  const uint32_t* mt = spin == 0 ? to->dev.diag.map_up : to->dev.diag.map_dw;
-  hipError_t e = launch_ladder(mf, spin == 0 ? a.dimup : a.dimdw, mt, spin == 0 ? b.dimup : b.dimdw, a.pitch, b.dimup, b.pitch, b.dimdw,
-                               orbital, spin, create ? 1 : 0, (const double2*)d_psi, (double2*)d_out, to->stream);
-  if (e != hipSuccess) return fail(HXV_ERR_HIP, std::string("ladder kernel: ") + hipGetErrorString(e));
-  if (norm2) {
-    const int64_t n = (int64_t)b.pitch * b.dimdw;  // pads of d_out must be zero (hxv.h)
-    const int g = grid_for(n);
-    hipLaunchKernelGGL(lz_nrm, dim3(g), dim3(256), 0, to->stream, n, (const double2*)d_out, to->d_partials);
-    hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, to->stream, to->d_partials, g, to->d_scalars, 5, 0);
-    HIPCHK(hipMemcpyAsync(norm2, to->d_scalars + 5, sizeof(double), hipMemcpyDeviceToHost, to->stream));
-  }
-  HIPCHK(hipStreamSynchronize(to->stream));
-  return HXV_OK;
-}
-
-int hxv_time_lanczos(hxv_handle* h, void* d_work3, int32_t nrep, float* ms_per_iter) {
-  if (!h || !d_work3 || nrep < 1 || !ms_per_iter) return fail(HXV_ERR_ARG, "hxv_time_lanczos: bad argument");
-  if (h->host.nranks != 1) return fail(HXV_ERR_STATE, "hxv_time_lanczos needs nranks==1");
-  HIPCHK(hipSetDevice(h->device));
-  int64_t n = (int64_t)h->host.pitch * h->host.dimdw;
-  HIPCHK(hipMemsetAsync(d_work3, 0, (size_t)3 * n * sizeof(double2), h->stream));
-  const bool real = want_real(h);
-  LzRunner lz(h, (double2*)d_work3, (double2*)d_work3 + n, (double2*)d_work3 + 2 * n, real);
-  const int64_t nfull = n;
-  n = lz.n2;
-  const int g = grid_for(n);
-  if (real)
-    launch_init_real(h, (double*)lz.b.w, 0x1234ull, h->stream);
-  else
-    hipLaunchKernelGGL(lz_init, dim3(g), dim3(256), 0, h->stream, n, lz.b.w, 0x1234ull, h->host.dimup, h->host.pitch);
-  (void)nfull;
-  HIPCHK(hipMemsetAsync(h->d_scalars, 0, 8 * sizeof(double), h->stream));
-  hipLaunchKernelGGL(lz_nrm, dim3(g), dim3(256), 0, h->stream, n, lz.b.w, h->d_partials + RED_BLOCKS);
-  hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_partials + RED_BLOCKS, g, h->d_scalars, 1, 1);
-  hipLaunchKernelGGL(lz_scale, dim3(g), dim3(256), 0, h->stream, n, lz.b.q, lz.b.w, h->d_scalars, 1);
-  HIPCHK(hipMemsetAsync(lz.b.qm, 0, (size_t)n * sizeof(double2), h->stream));
-  int rc = lz.begin(1.0);
-  if (rc) return rc;
-  double a, bt;
-  rc = lz.step(&a, &bt);  // untimed first step (lazy allocations)
-  if (rc) return rc;
-  rc = lz.advance();
-  if (rc) return rc;
-  HIPCHK(hipEventRecord(h->ev0, h->stream));
-  for (int k = 0; k < nrep; ++k) {
-    rc = lz.step(&a, &bt);
-    if (rc) return rc;
-    rc = lz.advance();
-    if (rc) return rc;
-  }
-  HIPCHK(hipEventRecord(h->ev1, h->stream));
-  HIPCHK(hipEventSynchronize(h->ev1));
-  float ms = 0;
-  HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
-  *ms_per_iter = ms / (float)nrep;
-  return HXV_OK;
-}
-
-}  // extern "C"

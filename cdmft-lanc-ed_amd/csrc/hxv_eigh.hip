@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(256) tr_scale_nrm(int64_t n, double2* __restri
   if (threadIdx.x == 0 && partial) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-// deterministic start vector (same hash as the single-vector Lanczos in hxv_capi.hip): pad rows stay zero
+// deterministic start vector (same hash as the single-vector Lanczos in hxv_lanczos.hip): pad rows stay zero
 __global__ void __launch_bounds__(256) tr_init(int64_t n, double2* __restrict__ q, uint64_t seed, int dimup, int pitch) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const int64_t col = i / pitch;

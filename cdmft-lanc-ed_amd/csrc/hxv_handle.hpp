@@ -1,5 +1,5 @@
 // The opaque handle behind include/hxv.h and the error helpers shared by the translation units
-// that implement the C-ABI (hxv_capi.hip: products + Lanczos; hxv_eigh.hip: thick-restart eigensolver).
+// that implement the C-ABI (hxv_capi.hip: handles + products; hxv_lanczos.hip: Lanczos recurrences; hxv_eigh.hip: thick-restart eigensolver).
 #pragma once
 #include <algorithm>
 #include <string>
@@ -12,7 +12,8 @@ struct hxv_handle;
 namespace hxv {
 int fail(int code, const std::string& msg);  // records the message hxv_last_error() returns; returns code
 constexpr int RED_BLOCKS = 1024;             // workgroups of the grid-stride reduction kernels
-// REAL-vector mode helpers shared by the Lanczos drivers (defined in hxv_capi.hip)
+int ensure_wt(hxv_handle* h);                // (re)allocates the dw-hop scratch of the tiled kernels (hxv_capi.hip)
+// REAL-vector mode helpers shared by the Lanczos drivers (hxv_capi.hip / hxv_lanczos.hip)
 const char* real_mode_blocker(const hxv_handle* h);  // nullptr when real vectors can be used with this handle
 int pitch_real_of(const hxv_handle* h);
 // layout conversions between complex [DimDw][pitch] and real [DimDw][pitch_real] device vectors (pads written as zero)

@@ -69,7 +69,7 @@ struct TilePlan {
   bool usable = true;             // false: too many distinct amplitudes -> the engine uses kernel 0
 };
 
-// Optional Lanczos epilogue of pass A (device Lanczos, hxv_capi.hip): with x the input vector of the product,
+// Optional Lanczos epilogue of pass A (device Lanczos, hxv_lanczos.hip): with x the input vector of the product,
 //   w = s*(H x) - c*xm   is stored instead of H x, and   sum Re(conj(s*x) * w)   is reduced per workgroup,
 // s = scal[i_s], c = scal[i_c] read from device memory.  Saves two full vector passes per iteration.
 struct LzEpilogue {
