@@ -120,7 +120,8 @@ struct DevSector {
 struct TilePlan;  // opaque tiling data for the two-pass kernels
 hipError_t launch_hxv_naive(const DevSector& s, const double2* v_full, double2* hv_local, hipStream_t st);
 hipError_t launch_ladder(const uint32_t* map_from, int dim_from, const uint32_t* map_to, int dim_to, int pitch_from, int dimup_to,
-                         int pitch_to, int dimdw_to, int orbital, int spin, int create, const double2* psi, double2* out, hipStream_t st);
+                         int pitch_to, int dimdw_to, int orbital, int spin, int create, const double2* psi, double2* out, hipStream_t st,
+                         double2 coef = double2{1.0, 0.0}, int accumulate = 0);
 hipError_t launch_hxv_nonlocal(const DevSector& s, const double2* v_full, double2* hv_local, hipStream_t st);
 
 }  // namespace hxv

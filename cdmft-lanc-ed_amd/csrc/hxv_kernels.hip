@@ -135,7 +135,10 @@ hipError_t launch_hxv_nonlocal(const DevSector& s, const double2* v_full, double
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) ladder_kernel(const uint32_t* __restrict__ map_from, int dim_from, const uint32_t* __restrict__ map_to,
                                                     int pitch_from, int dimup_to, int pitch_to, int dimdw_to, int orbital, int spin, int create,
-                                                    const double2* __restrict__ psi, double2* __restrict__ out) {
+                                                    const double2* __restrict__ psi, double2* __restrict__ out, double2 coef,
+                                                    int accumulate) {
+  // out = (accumulate ? out : 0) + coef * c^(dagger) psi : the mixed channels of the Green's function start from
+  // (c^dagger_i + c^dagger_j)|gs> and (c^dagger_i + xi c^dagger_j)|gs> (ED_GF_NORMAL.f90:370-406, 746-780)
   const int64_t n = (int64_t)dimup_to * dimdw_to;
   const uint32_t bit = 1u << orbital;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
@@ -148,21 +151,27 @@ __global__ void __launch_bounds__(256) ladder_kernel(const uint32_t* __restrict_
       const int j = rank_in_map(map_from, dim_from, m_from);
       const double sg = par_below(m_from, orbital) ? -1.0 : 1.0;
       const double2 x = spin == 0 ? psi[(int64_t)c * pitch_from + j] : psi[(int64_t)j * pitch_from + i];
-      r = make_double2(sg * x.x, sg * x.y);
+      r = make_double2(sg * (coef.x * x.x - coef.y * x.y), sg * (coef.x * x.y + coef.y * x.x));
+    }
+    if (accumulate) {
+      const double2 o = out[(int64_t)c * pitch_to + i];
+      r.x += o.x;
+      r.y += o.y;
     }
     out[(int64_t)c * pitch_to + i] = r;
   }
 }
 
 hipError_t launch_ladder(const uint32_t* map_from, int dim_from, const uint32_t* map_to, int dim_to, int pitch_from, int dimup_to,
-                         int pitch_to, int dimdw_to, int orbital, int spin, int create, const double2* psi, double2* out, hipStream_t st) {
+                         int pitch_to, int dimdw_to, int orbital, int spin, int create, const double2* psi, double2* out, hipStream_t st,
+                         double2 coef, int accumulate) {
   (void)dim_to;
   const int64_t n = (int64_t)dimup_to * dimdw_to;
   if (n == 0) return hipSuccess;
   int64_t blocks = (n + 255) / 256;
   if (blocks > 256 * 32) blocks = 256 * 32;
   hipLaunchKernelGGL(ladder_kernel, dim3((unsigned)blocks), dim3(256), 0, st, map_from, dim_from, map_to, pitch_from, dimup_to, pitch_to,
-                     dimdw_to, orbital, spin, create, psi, out);
+                     dimdw_to, orbital, spin, create, psi, out, coef, accumulate);
   return hipGetLastError();
 }
 

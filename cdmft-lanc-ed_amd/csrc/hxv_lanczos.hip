@@ -604,6 +604,11 @@ int hxv_lanczos_eigh_host(hxv_handle* h, int32_t nitermax, double threshold, dou
 
 int hxv_apply_ladder(hxv_handle* from, hxv_handle* to, int32_t orbital, int32_t spin, int32_t create, const void* d_psi, void* d_out,
                      double* norm2) {
+  return hxv_apply_ladder_axpy(from, to, orbital, spin, create, 1.0, 0.0, 0, d_psi, d_out, norm2);
+}
+
+int hxv_apply_ladder_axpy(hxv_handle* from, hxv_handle* to, int32_t orbital, int32_t spin, int32_t create, double coef_re, double coef_im,
+                          int32_t accumulate, const void* d_psi, void* d_out, double* norm2) {
   if (!from || !to || !d_psi || !d_out) return fail(HXV_ERR_ARG, "hxv_apply_ladder: NULL argument");
   const SectorHost &a = from->host, &b = to->host;
   if (a.nranks != 1 || b.nranks != 1) return fail(HXV_ERR_STATE, "hxv_apply_ladder needs nranks==1 (the reference does this step on the master)");
@@ -614,11 +619,12 @@ int hxv_apply_ladder(hxv_handle* from, hxv_handle* to, int32_t orbital, int32_t 
   if (spin == 0 ? (b.nup != a.nup + d || b.ndw != a.ndw) : (b.ndw != a.ndw + d || b.nup != a.nup))
     return fail(HXV_ERR_ARG, "hxv_apply_ladder: `to` is not the sector reached by this operator");
   HIPCHK(hipSetDevice(to->device));
-  HIPCHK(hipMemsetAsync(d_out, 0, (size_t)b.pitch * b.dimdw * sizeof(double2), to->stream));  // pad rows = 0
+  if (!accumulate) HIPCHK(hipMemsetAsync(d_out, 0, (size_t)b.pitch * b.dimdw * sizeof(double2), to->stream));  // pad rows = 0
   const uint32_t* mf = spin == 0 ? from->dev.diag.map_up : from->dev.diag.map_dw;
   const uint32_t* mt = spin == 0 ? to->dev.diag.map_up : to->dev.diag.map_dw;
   hipError_t e = launch_ladder(mf, spin == 0 ? a.dimup : a.dimdw, mt, spin == 0 ? b.dimup : b.dimdw, a.pitch, b.dimup, b.pitch, b.dimdw,
-                               orbital, spin, create ? 1 : 0, (const double2*)d_psi, (double2*)d_out, to->stream);
+                               orbital, spin, create ? 1 : 0, (const double2*)d_psi, (double2*)d_out, to->stream,
+                               make_double2(coef_re, coef_im), accumulate ? 1 : 0);
   if (e != hipSuccess) return fail(HXV_ERR_HIP, std::string("ladder kernel: ") + hipGetErrorString(e));
   if (norm2) {
     const int64_t n = (int64_t)b.pitch * b.dimdw;  // pads of d_out must be zero (hxv.h)

@@ -41,7 +41,7 @@ class _Stats(C.Structure):
 # every symbol include/hxv.h declares (tests check that the library exports all of them)
 EXPORTS = [
     "hxv_create_from_model", "hxv_create_from_csr", "hxv_create_dw_panel", "hxv_apply_dw_panel", "hxv_apply_up_add", "hxv_destroy", "hxv_vecdim", "hxv_dims", "hxv_apply_host",
-    "hxv_apply_device", "hxv_apply_device_real", "hxv_real_vectors_available", "hxv_pitch_real", "hxv_realvec_elems", "hxv_fullvec_elems", "hxv_localvec_elems", "hxv_pitch", "hxv_time_apply", "hxv_lanczos_tridiag", "hxv_lanczos_eigh", "hxv_lanczos_tridiag_host", "hxv_lanczos_eigh_host", "hxv_eigh_lowest", "hxv_eigh_lowest_host", "hxv_time_lanczos", "hxv_apply_ladder", "hxv_get_maps",
+    "hxv_apply_device", "hxv_apply_device_real", "hxv_real_vectors_available", "hxv_pitch_real", "hxv_realvec_elems", "hxv_fullvec_elems", "hxv_localvec_elems", "hxv_pitch", "hxv_time_apply", "hxv_lanczos_tridiag", "hxv_lanczos_eigh", "hxv_lanczos_tridiag_host", "hxv_lanczos_eigh_host", "hxv_eigh_lowest", "hxv_eigh_lowest_host", "hxv_time_lanczos", "hxv_apply_ladder", "hxv_apply_ladder_axpy", "hxv_get_maps",
     "hxv_nnz", "hxv_get_csr", "hxv_get_diag", "hxv_set_option", "hxv_get_option", "hxv_get_stats", "hxv_last_error",
     "hxv_version",
 ]
@@ -95,6 +95,7 @@ def load_library():
     L.hxv_eigh_lowest_host.argtypes = [vp, i32, i32, i32, dbl, pd, vp, pi32, pi32]
     L.hxv_time_lanczos.argtypes = [vp, vp, i32, C.POINTER(C.c_float)]
     L.hxv_apply_ladder.argtypes = [vp, vp, i32, i32, i32, vp, vp, pd]
+    L.hxv_apply_ladder_axpy.argtypes = [vp, vp, i32, i32, i32, dbl, dbl, i32, vp, vp, pd]
     L.hxv_get_maps.argtypes = [vp, pi32, pi32]
     L.hxv_nnz.argtypes = [vp, i32]
     L.hxv_nnz.restype = i64
@@ -420,8 +421,10 @@ class HxvSector:
                                                  C.byref(nc), C.byref(nmv)), "hxv_eigh_lowest_host")
         return ev, basis, nc.value, nmv.value
 
-    def apply_ladder(self, to: "HxvSector", orbital: int, spin: int, create: bool, psi):
-        """c / c^dagger on (orbital, spin) from this sector into `to` (ED_GF_NORMAL.f90:180-199); returns (vector, norm2)."""
+    def apply_ladder(self, to: "HxvSector", orbital: int, spin: int, create: bool, psi, coef: complex = 1.0, out=None):
+        """c / c^dagger on (orbital, spin) from this sector into `to` (ED_GF_NORMAL.f90:180-199); returns (vector, norm2).
+        With `out` (a PADDED vector of `to`, e.g. a previous result with native layout) the term coef * c^(dagger) psi is
+        ADDED to it: the mixed channels (c^dagger_i + c^dagger_j)|gs>, (c^dagger_i + xi c^dagger_j)|gs> (:370-406, :746-780)."""
         import torch
 
         assert psi.is_cuda and psi.dtype == torch.complex128
@@ -429,12 +432,17 @@ class HxvSector:
         if contiguous:
             assert psi.numel() == self.Dim
             psi = self.pad(psi)
-        out = torch.empty(to.localElems, dtype=torch.complex128, device=psi.device)
+        accumulate = out is not None
+        if accumulate:
+            assert out.is_cuda and out.dtype == torch.complex128 and out.numel() == to.localElems and out.is_contiguous()
+        else:
+            out = torch.empty(to.localElems, dtype=torch.complex128, device=psi.device)
         torch.cuda.synchronize()
         n2 = C.c_double()
-        _chk(load_library().hxv_apply_ladder(self._h, to._h, orbital, spin, int(bool(create)), psi.data_ptr(), out.data_ptr(), C.byref(n2)),
-             "hxv_apply_ladder")
-        return (to.unpad(out) if contiguous else out), n2.value
+        cf = complex(coef)
+        _chk(load_library().hxv_apply_ladder_axpy(self._h, to._h, orbital, spin, int(bool(create)), cf.real, cf.imag, int(accumulate),
+                                                  psi.data_ptr(), out.data_ptr(), C.byref(n2)), "hxv_apply_ladder_axpy")
+        return (to.unpad(out) if (contiguous and not accumulate) else out), n2.value
 
     def time_lanczos(self, nrep: int) -> float:
         import torch

@@ -185,6 +185,11 @@ int hxv_time_lanczos(hxv_handle *h, void *d_work3 /* 3*hxv_localvec_elems() comp
  * nranks==1, same device; padded device layouts, d_out's pad rows are written as zero.                                                                               */
 int hxv_apply_ladder(hxv_handle *from, hxv_handle *to, int32_t orbital, int32_t spin, int32_t create, const void *d_psi,
                      void *d_out, double *norm2);
+/* Mixed channels (ED_GF_NORMAL.f90:370-406 (c^dagger_i + c^dagger_j)|gs>, :746-780 (c^dagger_i + xi c^dagger_j)|gs>, and the
+ * c_i + c_j / c_i - xi c_j counterparts): d_out = (accumulate ? d_out : 0) + (coef_re + i coef_im) * c^(dagger) d_psi;
+ * *norm2 = <out|out> after the update.  With accumulate != 0 the caller's d_out must have zero pad rows.     */
+int hxv_apply_ladder_axpy(hxv_handle *from, hxv_handle *to, int32_t orbital, int32_t spin, int32_t create, double coef_re,
+                          double coef_im, int32_t accumulate, const void *d_psi, void *d_out, double *norm2);
 
 /* ---- introspection (parity tests against spH0ups/spH0dws/spH0d) ------------------------ */
 int hxv_get_maps(const hxv_handle *h, int32_t *map_up, int32_t *map_dw); /* Hs(1)%map, Hs(2)%map */

@@ -379,3 +379,50 @@ def test_real_vector_mode_not_used_for_complex_h(built):
     assert sec.get_option("lanczos_real_last") == 0
     sec.eigh_lowest(1, 10, want_vectors=False)
     assert sec.get_option("lanczos_real_last") == 0
+
+
+def test_device_resident_green_function_with_mixed_channels(built):
+    """The whole buildgf step on the device: ground state (hxv_lanczos_eigh) -> start vectors c^dagger_i|gs>,
+    (c^dagger_i + c^dagger_j)|gs>, (c^dagger_i + xi c^dagger_j)|gs> and the c counterparts (hxv_apply_ladder[_axpy];
+    ED_GF_NORMAL.f90:180-199, 370-406, 746-780, 827-861) -> tridiagonal (hxv_lanczos_tridiag) -> continued fraction.
+    Each channel O is checked against the Lehmann sum  sum_n |<n|O|gs>|^2 / (i w -+ (E_n - E0))  of the dense sector."""
+    import torch
+    import hxv
+    from hxv import models
+    from oracle.oracle import OracleSector
+
+    m, N = models.hm_1dchain(Nlat=2, Nbath=2, eps_bath=[0.25, -0.4], U=2.0), 3
+    beta, Lmats = 50.0, 32
+    wm = np.pi / beta * (2 * np.arange(1, Lmats + 1) - 1)
+    gs = hxv.HxvSector.from_model(m, N, N)
+    e0, psi, _ = gs.lanczos_eigh(512, 1e-14, native=True)      # padded device vector, stays on the device
+    w0, U0 = np.linalg.eigh(OracleSector(m, N, N).dense())
+    assert abs(w0[0] - e0) < 1e-10
+    # fix the arbitrary sign of the reference eigenvector to the device one
+    psi_h = gs.unpad(psi).cpu().numpy()
+    psi_ref = U0[:, 0] * np.sign(np.vdot(U0[:, 0], psi_h).real)
+    maps0 = gs.maps()
+    i_site, j_site, spin = 0, 1, 0
+    for create, (nu, nd) in ((True, (N + 1, N)), (False, (N - 1, N))):
+        sec = hxv.HxvSector.from_model(m, nu, nd)
+        maps1 = sec.maps()
+        w1, U1 = np.linalg.eigh(OracleSector(m, nu, nd).dense())
+        sign = 1.0 if create else -1.0
+        # the reference's four operator combinations per pair (i,j): O = c_i, c_i + c_j, c_i +- xi c_j (dagger for create)
+        for cj in (0.0, 1.0, 1j if create else -1j):
+            vv, n2 = gs.apply_ladder(sec, i_site, spin, create, psi)
+            if cj != 0.0:
+                vv, n2 = gs.apply_ladder(sec, j_site, spin, create, psi, coef=cj, out=vv)
+            ref = _apply_op(psi_ref, maps0, maps1, i_site, spin, create)
+            if cj != 0.0:
+                ref = ref + cj * _apply_op(psi_ref, maps0, maps1, j_site, spin, create)
+            assert abs(n2 - np.vdot(ref, ref).real) < 1e-9
+            nl = min(sec.Dim, 150)
+            a, b, n = sec.lanczos_tridiag(vv / np.sqrt(n2), nl, threshold=1e-12)
+            assert sec.get_option("lanczos_real_last") == (0 if isinstance(cj, complex) and cj.imag != 0 else 1)
+            ev, Z = np.linalg.eigh(np.diag(a[:n]) + np.diag(b[1:n], 1) + np.diag(b[1:n], -1))
+            G = (n2 * Z[0, :] ** 2 / (1j * wm[:, None] - sign * (ev[None, :] - e0))).sum(axis=1)
+            amp = np.abs(U1.conj().T @ ref) ** 2
+            Gref = (amp[None, :] / (1j * wm[:, None] - sign * (w1[None, :] - w0[0]))).sum(axis=1)
+            assert np.abs(G - Gref).max() <= 1e-9, (create, cj, np.abs(G - Gref).max())
+        sec.close()
