@@ -181,6 +181,11 @@ def main():
                                                                  else " + 2 RCCL all-to-all transposes per product") if world > 1 else ""),
                       "matvecs_per_s": round(1e3 / ms_step, 2)},
            "roofline": roofline}
+    if world > 1:
+        # what the exchange moves into every GPU per product: the xGMI links, not HBM, bound the N>1 product
+        slab = 16 * sh.slab
+        out["config"]["exchange"] = args.exchange
+        out["config"]["exchange_ingest_bytes_per_gpu"] = (world - 1) * slab if args.exchange == "allgather" else 2 * (world - 1) * slab // world
     if not args.no_lanczos and world == 1:
         # full iterations: product + fused recurrence + 2 reductions, vectors in HBM.  Headline = complex(8) vectors, the
         # reference's data type; when H is real (C2, C3) the device drivers also run on real vectors (half the bytes).
