@@ -72,6 +72,10 @@ def main():
     ap.add_argument("--exchange", default="allgather", choices=["allgather", "alltoall"],
                     help="N>1: allgather = one RCCL all-gather per product (BASELINE's mandated exchange, default); "
                          "alltoall = the reference's own two transposes per product (lower traffic)")
+    ap.add_argument("--parallelism", default="dimdw", choices=["dimdw", "sectors"],
+                    help="N>1: dimdw = ONE sector split along DimDw with an exchange per product (BASELINE's scheme, strong scaling, default); "
+                         "sectors = every GPU runs its own whole sector, no exchange (how independent sectors / Green's-function channels "
+                         "of one ED solve spread over a node; weak scaling)")
     ap.add_argument("--check", action="store_true", help="N>1 rehearsal: verify the sharded product against the unsharded one on rank 0")
     args = ap.parse_args()
 
@@ -106,25 +110,29 @@ def main():
     else:
         model, (nup, ndw) = models.hm_ring(6, 2), (9, 9)
 
-    sec = hxv.HxvSector.from_model(model, nup, ndw, rank=rank, nranks=world, device=local_rank)
+    by_sector = world > 1 and args.parallelism == "sectors"
+    if by_sector:
+        sec = hxv.HxvSector.from_model(model, nup, ndw, device=local_rank)      # the whole sector on every GPU
+    else:
+        sec = hxv.HxvSector.from_model(model, nup, ndw, rank=rank, nranks=world, device=local_rank)
     Dim, Nloc = sec.Dim, sec.localElems   # Nloc: local vector length in the padded device layout (include/hxv.h)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     v_local = torch.randn(Nloc, dtype=torch.float64, device=dev, generator=g) + 1j * torch.randn(Nloc, dtype=torch.float64, device=dev, generator=g)
     hv_local = torch.empty(Nloc, dtype=torch.complex128, device=dev)
-    sh = hxv.ShardedHxv(sec.DimUp, sec.DimDw, rank, world, sec.apply_device, pitch=sec.pitch)
-    if world > 1 and args.exchange == "alltoall":
+    sh = hxv.ShardedHxv(sec.DimUp, sec.DimDw, 0 if by_sector else rank, 1 if by_sector else world, sec.apply_device, pitch=sec.pitch)
+    if world > 1 and args.exchange == "alltoall" and not by_sector:
         nrows = hxv.dw_split(sec.DimUp, rank, world)[0]
         panel = hxv.HxvSector.dw_panel(model, nup, ndw, nrows, device=local_rank)
         th = hxv.TransposedHxv(sec.DimUp, sec.DimDw, rank, world, panel.apply_dw_panel, sec.apply_up_add, pitch=sec.pitch,
                                pitch_panel=panel.pitch, stage_on_host=(args.backend != "nccl"))
 
     def step():
-        if world > 1 and args.exchange == "alltoall":
+        if world > 1 and args.exchange == "alltoall" and not by_sector:
             th(Nloc, v_local, hv_local)
         else:
             sh(Nloc, v_local, hv_local)
 
-    if args.check and world > 1:
+    if args.check and world > 1 and not by_sector:
         # rehearsal: every rank's slab of the sharded product == the same slab of the unsharded product
         step()
         full_sec = hxv.HxvSector.from_model(model, nup, ndw, device=local_rank)
@@ -153,7 +161,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_step = dt / args.steps * 1e3
-    value = 32.0 * Dim / (ms_step * 1e-3) / 1e9
+    value = (world if by_sector else 1) * 32.0 * Dim / (ms_step * 1e-3) / 1e9   # sectors: every rank finished a whole product
 
     # roofline of the product's kernels on this rank: HIP events on the stream they are launched on
     vfull = sh.gather(v_local)
@@ -175,13 +183,13 @@ def main():
 
     out = {"metric": "sector-HxV achieved HBM GB/s (algorithmic 32 B x Dim per product), Ns=16 half-filled sector", "value": round(value, 1),
            "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
-           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "complex128 (f64)", "data": "synthetic",
+           "higher_is_better": True, "scaling": "weak" if by_sector else "strong", "vs_baseline": None, "dtype": "complex128 (f64)", "data": "synthetic",
            "config": {"workload": f"{args.workload}: {model.name} sector ({nup},{ndw}) Dim={Dim}", "DimUp": sec.DimUp, "DimDw": sec.DimDw,
-                      "parallelism": f"DimDw split x{world}" + ((" + RCCL allgather per product" if args.exchange == "allgather"
+                      "parallelism": f"{world} independent sectors, one per GPU, no exchange" if by_sector else f"DimDw split x{world}" + ((" + RCCL allgather per product" if args.exchange == "allgather"
                                                                  else " + 2 RCCL all-to-all transposes per product") if world > 1 else ""),
-                      "matvecs_per_s": round(1e3 / ms_step, 2)},
+                      "matvecs_per_s": round((world if by_sector else 1) * 1e3 / ms_step, 2)},
            "roofline": roofline}
-    if world > 1:
+    if world > 1 and not by_sector:
         # what the exchange moves into every GPU per product: the xGMI links, not HBM, bound the N>1 product
         slab = 16 * sh.slab
         out["config"]["exchange"] = args.exchange
