@@ -168,7 +168,10 @@ int hxv_lanczos_eigh_host(hxv_handle *h, int32_t nitermax, double threshold, dou
  *   d_evecs      : device, neigen consecutive vectors of hxv_localvec_elems() elements (padded layout), or NULL
  *   evecs_host   : host, eig_basis(Dim,neigen) in the reference's contiguous layout, or NULL
  *   *nconv       : how many of the neigen pairs met the test; *nmatvec: H x V products spent.
- * Needs (ncv+1) vectors of HBM; fails with HXV_ERR_HIP and a message naming the shortfall otherwise.          */
+ * Needs (ncv+1) vectors of HBM; fails with HXV_ERR_HIP and a message naming the shortfall otherwise.
+ * Like any single-vector Krylov method (ARPACK included) it sees ONE vector of an exactly degenerate level: with
+ * neigen beyond a degenerate level the next distinct levels follow.  If Dim <= ncv the Krylov space closes and all
+ * returned pairs are exact.                                                                                      */
 int hxv_eigh_lowest(hxv_handle *h, int32_t neigen, int32_t ncv, int32_t maxrestart, double tol, double *evals, void *d_evecs,
                     int32_t *nconv, int32_t *nmatvec);
 int hxv_eigh_lowest_host(hxv_handle *h, int32_t neigen, int32_t ncv, int32_t maxrestart, double tol, double *evals,
