@@ -191,6 +191,12 @@ def test_full_size_hermiticity_and_linearity(built):
     hz = sec.apply_device(al * x + be * y)
     torch.cuda.synchronize()
     assert (hz - (al * hx + be * hy)).abs().max().item() <= 1e-12 * hz.abs().max().item()
+    # REAL-vector product at the same size: the real part of the complex product, bit for bit, and symmetric
+    xr, yr = x.real.contiguous(), y.real.contiguous()
+    hxr = sec.apply_device_real(xr)
+    assert torch.equal(hxr, sec.apply_device(xr.to(torch.complex128)).real)
+    hyr = sec.apply_device_real(yr)
+    assert abs(torch.dot(xr, hyr).item() - torch.dot(yr, hxr).item()) <= 1e-12 * (xr.norm() * hyr.norm()).item()
 
 
 @pytest.mark.parametrize("shard", [(0, 1), (2, 3)])
