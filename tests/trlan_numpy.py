@@ -52,7 +52,13 @@ def trlan_lowest(matvec, dim: int, neigen: int, ncv: int, maxrestart: int = 512,
             nmv += 1
             c = V[: j + 1].conj() @ w
             T[j, j] = c[j].real
-            w = w - c @ V[: j + 1]
+            # all projections are measured; subtracted are the two local ones, everything right after a restart, and
+            # whatever exceeds 1e-13*|w| (rounding noise is left alone) -- same rule as csrc/hxv_eigh.hip gs_pass
+            sel = np.abs(c) > 1e-13 * np.sqrt(np.vdot(c, c).real)
+            sel[max(j - 1, 0):] = True
+            if j == k:
+                sel[:] = True
+            w = w - (c * sel) @ V[: j + 1]
             nrm = np.linalg.norm(w)
             if nrm * nrm < 0.01 * (np.vdot(c, c).real + nrm * nrm):     # norm dropped 10x: one refinement pass (DGKS)
                 c2 = V[: j + 1].conj() @ w
