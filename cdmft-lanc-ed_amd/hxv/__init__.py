@@ -6,4 +6,4 @@ the reference's own host code), hxv/ (this Python mirror of the reference interf
 from .engine import HxvError, HxvSector, LIB_PATH, load_library, EXPORTS  # noqa: F401
 from .hamiltonian import EDContext  # noqa: F401
 from . import models  # noqa: F401
-from .distributed import ShardedHxv, TransposedHxv, dw_split  # noqa: F401
+from .distributed import ShardedHxv, ShardedLanczos, TransposedHxv, dw_split, start_vector_slab  # noqa: F401

@@ -155,3 +155,155 @@ class TransposedHxv:
             off += q * ns
         # 4. diagonal + up hops + dw part on the local slab
         return self.apply_up_add(v_local, w.view(-1), hv_local)
+
+
+def start_vector_slab(DimUp: int, qdw: int, dw0: int, pitch: int, device, seed: int = 0x5EED5EED):
+    """This rank's slab of the engine's deterministic Lanczos start vector (csrc/hxv_lanczos.hip lz_init): splitmix64 of
+    the GLOBAL element index -> uniform(-0.5,0.5) re and im, pad rows zero.  Every split of the sector therefore
+    starts from the same vector as the single-GPU driver."""
+    import torch
+
+    M64 = (1 << 64) - 1
+
+    def as_i64(x):  # python int (mod 2^64) -> the int64 with the same bits
+        x &= M64
+        return x - (1 << 64) if x >= (1 << 63) else x
+
+    def lsr(x, s):  # logical shift right on int64 tensors
+        return (x >> s) & ((1 << (64 - s)) - 1)
+
+    col = torch.arange(dw0, dw0 + qdw, dtype=torch.int64, device=device).view(-1, 1)
+    row = torch.arange(DimUp, dtype=torch.int64, device=device).view(1, -1)
+    z = (col * DimUp + row) * 2 + seed
+    out = torch.zeros(qdw, pitch, dtype=torch.complex128, device=device)
+    parts = []
+    for k in range(2):
+        x = z + k + as_i64(0x9E3779B97F4A7C15)
+        x = (x ^ lsr(x, 30)) * as_i64(0xBF58476D1CE4E5B9)
+        x = (x ^ lsr(x, 27)) * as_i64(0x94D049BB133111EB)
+        x = x ^ lsr(x, 31)
+        parts.append(lsr(x, 11).to(torch.float64) * (1.0 / 9007199254740992.0) - 0.5)
+    out[:, :DimUp] = torch.complex(parts[0], parts[1])
+    return out.view(-1)
+
+
+class ShardedLanczos:
+    """The Lanczos recurrences for a DimDw-split sector: what SciFortran's MPI flavours
+    sp_lanc_tridiag(MpiComm, MatVec, vin, alanc, blanc) / sp_lanc_eigh(MpiComm, MatVec, egs, vect, Nitermax, ...) do at
+    ED_GF_NORMAL.f90:215 / ED_DIAG.f90:176 when MpiStatus=T: every rank holds its slab of each Lanczos vector, the product
+    is `matvec` (ShardedHxv or TransposedHxv: one exchange per product), the two dot products per iteration are
+    all-reduced over the group (RCCL on GPUs).  Vector arithmetic is plain torch on the slabs (pad rows stay zero)."""
+
+    def __init__(self, matvec, group=None):
+        import torch.distributed as dist
+
+        self.mv, self.dist, self.group = matvec, dist, group
+        self.Nloc = matvec.Nloc
+
+    def _allsum(self, x: float, like) -> float:
+        import torch
+
+        t = torch.tensor([x], dtype=torch.float64, device=like.device)
+        if self.mv.size > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return float(t.item())
+
+    def _dot(self, a, b) -> float:
+        import torch
+
+        return self._allsum(torch.vdot(a, b).real.item(), a)
+
+    def _recurrence(self, q, nmax, threshold, on_step=None):
+        """three-term recurrence from the normalised slab q -> (alpha_1..n, [0, beta_2..n]); on_step(k, q_k) sees every
+        Lanczos vector (then the last product is not needed and is skipped)"""
+        import torch
+
+        qm = torch.zeros_like(q)
+        w = torch.zeros_like(q)      # pad rows must be zero: the product never writes them, the dots read them
+        al, be = [], [0.0]
+        for k in range(nmax):
+            if on_step is not None:
+                on_step(k, q)
+                if k + 1 == nmax:
+                    break
+            self.mv(self.Nloc, q, w)
+            if k > 0:
+                w.sub_(qm, alpha=be[-1])
+            a = self._dot(q, w)
+            w.sub_(q, alpha=a)
+            b = self._dot(w, w) ** 0.5
+            al.append(a)
+            if b < threshold or k + 1 == nmax:
+                break
+            be.append(b)
+            qm, q, w = q, w.div_(b), qm
+        return al, be
+
+    def tridiag(self, v_local, nlanc: int, threshold: float = 1e-12):
+        """-> (alanc[nlanc], blanc[nlanc] with blanc[0] unused, nsteps): vin = this rank's slab of a GLOBALLY normalised vector."""
+        import numpy as np
+
+        al, be = self._recurrence(v_local.clone(), nlanc, threshold)
+        a = np.zeros(nlanc)
+        b = np.zeros(nlanc)
+        a[: len(al)] = al
+        b[: len(be)] = be
+        return a, b, len(al)
+
+    def eigh(self, nitermax: int = 512, threshold: float = 1e-12, want_vector: bool = True, device="cpu"):
+        """-> (E0, slab of the normalised ground-state vector or None, iterations): two passes like the single-GPU driver
+        (recurrence, then re-run to accumulate the Ritz vector), same deterministic start vector, same stopping rule."""
+        import numpy as np
+        import torch
+        from scipy.linalg import eigh_tridiagonal
+
+        mv = self.mv
+        q0 = self.start_slab(device)
+        nrm = self._dot(q0, q0) ** 0.5
+        q0 = q0 / nrm
+        state = {"e_old": 1e300}
+        # pass 1: the recurrence with the driver's stopping rule evaluated after every step
+        nmax = int(min(nitermax, mv.DimUp * mv.DimDw))
+        al, be, e_new = [], [0.0], 0.0
+        qm = torch.zeros_like(q0)
+        q = q0.clone()
+        w = torch.zeros_like(q0)     # (pad rows zero, see _recurrence)
+        k = 0
+        for k in range(nmax):
+            mv(self.Nloc, q, w)
+            if k > 0:
+                w.sub_(qm, alpha=be[-1])
+            a = self._dot(q, w)
+            w.sub_(q, alpha=a)
+            b = self._dot(w, w) ** 0.5
+            al.append(a)
+            d = np.array(al)
+            e = np.array(be[1:])
+            ev, Z = eigh_tridiagonal(d, e) if len(al) > 1 else (d.copy(), np.ones((1, 1)))
+            e_new = float(ev[0])
+            conv = abs(e_new - state["e_old"]) < threshold
+            state["e_old"] = e_new
+            if conv and want_vector:
+                conv = abs(b * Z[-1, 0]) < 1e-11 * max(1.0, abs(e_new))
+            if conv or b < 1e-14 or k + 1 == nmax:
+                break
+            be.append(b)
+            qm, q, w = q, w.div_(b), qm
+        niter = len(al)
+        if not want_vector:
+            return e_new, None, niter
+        d = np.array(al)
+        ev, Z = eigh_tridiagonal(d, np.array(be[1:])) if niter > 1 else (d.copy(), np.ones((1, 1)))
+        y = Z[:, 0]
+        out = torch.zeros_like(q0)
+
+        def acc(kk, qk):
+            out.add_(qk, alpha=float(y[kk]))
+
+        self._recurrence(q0.clone(), niter, 0.0, acc)
+        out.div_(self._dot(out, out) ** 0.5)
+        return e_new, out, niter
+
+    def start_slab(self, device="cpu"):
+        mv = self.mv
+        return start_vector_slab(mv.DimUp, mv.qdw, mv.dw0, mv.pitch, device)

@@ -128,3 +128,72 @@ def test_transposed_exchange_gloo(world, sector, tmp_path):
     ref = s.spMatVec_main(models.deterministic_vector(s.Dim))
     got = np.concatenate([np.load(tmp_path / f"hv_{r}.npy") for r in range(world)])
     assert np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max()
+
+
+def _worker_lanczos(rank, world, port, nup, ndw, out):
+    import torch
+    import torch.distributed as dist
+    import scipy.sparse as sp
+    import hxv
+    from hxv import models
+    from oracle.oracle import OracleSector
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = models.hm_1dchain(Nlat=2, Nbath=2, eps_bath=[0.3, 0.6])
+    orc = OracleSector(m, nup, ndw, rank, world)
+    du, dd = orc.DimUp, orc.DimDw
+    rp, cols, vals = orc.csr("up")
+    Hup = sp.csr_matrix((vals, cols - 1, rp), shape=(du, du))
+    rp, cols, vals = orc.csr("dw")
+    Hdw = sp.csr_matrix((vals, cols - 1, rp), shape=(dd, dd))
+    sh = None
+
+    def apply_local(v_gathered, hv_local):
+        V = sh.unpad(v_gathered).numpy().reshape((du, dd), order="F")
+        c0 = orc.mpiIshift // du
+        sl = slice(c0, c0 + orc.mpiQdw)
+        res = orc.diag().reshape((du, orc.mpiQdw), order="F") * V[:, sl] + Hup @ V[:, sl] + (Hdw[sl, :] @ V.T).T
+        hv_local.copy_(torch.from_numpy(np.asarray(res).reshape(-1, order="F")))
+        return hv_local
+
+    sh = hxv.ShardedHxv(du, dd, rank, world, apply_local)
+    lz = hxv.ShardedLanczos(sh)
+    v_full = models.deterministic_vector(orc.Dim)
+    v_full /= np.linalg.norm(v_full)
+    v_local = torch.from_numpy(v_full[orc.mpiIshift: orc.mpiIshift + orc.vecDim].copy())
+    a, b, n = lz.tridiag(v_local, 25)
+    e0, vec, nit = lz.eigh(300, 1e-13)
+    np.savez(os.path.join(out, f"lz_{rank}.npz"), a=a, b=b, n=n, e0=e0, vec=vec.numpy(), nit=nit, start=lz.start_slab().numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,sector", [(2, (3, 3)), (3, (3, 2))])
+def test_sharded_lanczos_gloo(world, sector, tmp_path):
+    """sp_lanc_tridiag / sp_lanc_eigh with a communicator (MpiStatus=T): slabs of the Lanczos vectors per rank, all-reduced
+    dots, one exchange per product -- against the serial oracle recurrence and LAPACK."""
+    import torch.multiprocessing as mp
+    from hxv import models
+    from oracle.oracle import OracleSector
+    from trlan_numpy import start_vector
+
+    nup, ndw = sector
+    mp.spawn(_worker_lanczos, args=(world, _free_port(), nup, ndw, str(tmp_path)), nprocs=world, join=True)
+    m = models.hm_1dchain(Nlat=2, Nbath=2, eps_bath=[0.3, 0.6])
+    s = OracleSector(m, nup, ndw)
+    v = models.deterministic_vector(s.Dim)
+    v /= np.linalg.norm(v)
+    a_ref, b_ref = s.lanc_tridiag(v, 25)
+    res = [np.load(tmp_path / f"lz_{r}.npz") for r in range(world)]
+    for r in res:                                           # every rank holds the same scalars
+        assert int(r["n"]) == 25
+        assert np.abs(r["a"] - a_ref).max() <= 1e-10 * np.abs(a_ref).max() and np.abs(r["b"] - b_ref).max() <= 1e-10 * np.abs(b_ref).max()
+        assert r["b"][0] == 0.0
+    H = s.dense()
+    w = np.linalg.eigvalsh(H)
+    assert abs(float(res[0]["e0"]) - w[0]) <= 1e-10
+    x = np.concatenate([r["vec"] for r in res])
+    assert abs(np.linalg.norm(x) - 1) < 1e-12 and np.linalg.norm(H @ x - float(res[0]["e0"]) * x) < 1e-8
+    # the slabs of the start vector are the slabs of the single-GPU driver's deterministic start vector
+    assert np.array_equal(np.concatenate([r["start"] for r in res]), start_vector(s.Dim))

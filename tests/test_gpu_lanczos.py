@@ -426,3 +426,28 @@ def test_device_resident_green_function_with_mixed_channels(built):
             Gref = (amp[None, :] / (1j * wm[:, None] - sign * (w1[None, :] - w0[0]))).sum(axis=1)
             assert np.abs(G - Gref).max() <= 1e-9, (create, cj, np.abs(G - Gref).max())
         sec.close()
+
+
+def test_sharded_lanczos_driver_on_device_matches_native_driver(built):
+    """hxv.ShardedLanczos (the MpiStatus=T flavour of sp_lanc_tridiag / sp_lanc_eigh: torch vector ops + all-reduced dots
+    around the per-rank product) at world size 1 against the in-library drivers: same start vector, same numbers."""
+    import torch
+    import hxv
+    from hxv import models
+
+    m = models.hm_2dsquare(Nbath=1)                       # DimUp = 70 -> pitch 72: pad rows in play
+    sec = hxv.HxvSector.from_model(m, 4, 4)
+    sec.set_option("real_vectors", 0)                     # same complex start vector as the sharded driver
+    sh = hxv.ShardedHxv(sec.DimUp, sec.DimDw, 0, 1, sec.apply_device, pitch=sec.pitch)
+    lz = hxv.ShardedLanczos(sh)
+    e0, vec, nit = lz.eigh(512, 1e-13, device="cuda")
+    e0n, vecn, nitn = sec.lanczos_eigh(512, 1e-13, native=True)
+    assert abs(e0 - e0n) < 1e-11 and abs(nit - nitn) <= 2
+    ov = abs(torch.vdot(vec, vecn).item())
+    assert abs(ov - 1.0) < 1e-9
+    v = models.deterministic_vector(sec.Dim)
+    v /= np.linalg.norm(v)
+    dv = sec.pad(torch.from_numpy(v).cuda())
+    a, b, n = lz.tridiag(dv, 30)
+    an, bn, nn = sec.lanczos_tridiag(dv, 30)
+    assert n == nn == 30 and np.abs(a - an).max() < 1e-10 and np.abs(b - bn).max() < 1e-10
