@@ -36,8 +36,9 @@ struct DevTiles {
 
 constexpr int HOP_CHUNK = 8;
 
-// Non-temporal accesses (debug bit 8 only): measured SLOWER than plain loads/stores for the R*16-byte
-// column segments of pass B (they defeat L2 write combining), see scripts/strided_bench.py.
+// Non-temporal (streaming) accesses.  Measured: SLOWER than plain ones for loads (pass A's wt read: +7 %) and for short
+// strided store segments (R*16-byte column segments of a natural-layout vector: they defeat L2 write combining, see
+// scripts/strided_bench.py); FASTER for long runs that are not read again soon: pass A's hv (-3 %) and pass B's blocked wt.
 typedef double dbl2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ double2 load_stream(const double2* p) {
   dbl2_t x = __builtin_nontemporal_load(reinterpret_cast<const dbl2_t*>(p));
@@ -416,7 +417,9 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_dw(DevSector s, DevTiles t, 
     const int r = rem / wc, cc = rem % wc;
     const int lc = gq * wc + cc;  // local column
     if (lc >= cl0 && lc < cl1 && i0 + r < s.dimup)
-      wt[((int64_t)gq * s.dimup + i0 + r) * wc + cc] = lds[r * ns + (lc + s.dw0 - cb0)];
+      // streaming store: wt is read back once, by pass A, long after it has left L2; not letting it linger leaves the L2
+      // to the tile lines that the out-of-block gathers of the neighbouring workgroups hit (-3 % on pass B, measured)
+      store_stream(&wt[((int64_t)gq * s.dimup + i0 + r) * wc + cc], lds[r * ns + (lc + s.dw0 - cb0)]);
   }
 }
 
