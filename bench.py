@@ -181,7 +181,8 @@ def main():
                 "traffic": traffic, "kernel": "hxv_pass_up + hxv_pass_dw (one product)", "kernel_ms": round(k_ms, 4),
                 "algorithmic_bytes": 32 * sec.vecDim}
 
-    out = {"metric": "sector-HxV achieved HBM GB/s (algorithmic 32 B x Dim per product), Ns=16 half-filled sector", "value": round(value, 1),
+    ns = {"C2": 12, "C3": 16, "C4": 16, "C5": 18}[args.workload]
+    out = {"metric": f"sector-HxV achieved HBM GB/s (algorithmic 32 B x Dim per product), Ns={ns} half-filled sector", "value": round(value, 1),
            "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
            "higher_is_better": True, "scaling": "weak" if by_sector else "strong", "vs_baseline": None, "dtype": "complex128 (f64)", "data": "synthetic",
            "config": {"workload": f"{args.workload}: {model.name} sector ({nup},{ndw}) Dim={Dim}", "DimUp": sec.DimUp, "DimDw": sec.DimDw,
