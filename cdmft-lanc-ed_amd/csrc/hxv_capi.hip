@@ -31,11 +31,11 @@ int ensure_wt(hxv_handle* h) {
   if (h->d_wt) {
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipDeviceSynchronize());
-    (void)hipFree(h->d_wt);
+    pool_free(h->device, h->d_wt);
     h->device_bytes -= h->wt_elems * (int64_t)sizeof(double2);
     h->d_wt = nullptr;
   }
-  HIPCHK(hipMalloc((void**)&h->d_wt, (size_t)need * sizeof(double2)));
+  HIPCHK(pool_alloc(h->device, (size_t)need * sizeof(double2), (void**)&h->d_wt));
   h->wt_elems = need;
   h->device_bytes += need * (int64_t)sizeof(double2);
   return HXV_OK;
@@ -192,11 +192,10 @@ int hxv_destroy(hxv_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void* p : h->allocs) (void)hipFree(p);
-  if (h->d_stage_v) (void)hipFree(h->d_stage_v);
-  if (h->d_stage_hv) (void)hipFree(h->d_stage_hv);
-  if (h->d_wt) (void)hipFree(h->d_wt);
-  for (auto& p : h->d_lz)
-    if (p) (void)hipFree(p);
+  pool_free(h->device, h->d_stage_v);
+  pool_free(h->device, h->d_stage_hv);
+  pool_free(h->device, h->d_wt);
+  for (auto& p : h->d_lz) pool_free(h->device, p);
   if (h->d_lz_partial) (void)hipFree(h->d_lz_partial);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -289,8 +288,8 @@ int hxv_apply_host(hxv_handle* h, int64_t nloc, const void* v, void* hv) {
   const size_t col = (size_t)h->host.dimup * sizeof(double2), pit = (size_t)h->host.pitch * sizeof(double2);
   const size_t bytes = pit * (size_t)h->host.dimdw;
   if (!h->d_stage_v) {
-    HIPCHK(hipMalloc((void**)&h->d_stage_v, bytes));
-    HIPCHK(hipMalloc((void**)&h->d_stage_hv, bytes));
+    HIPCHK(pool_alloc(h->device, bytes, (void**)&h->d_stage_v));
+    HIPCHK(pool_alloc(h->device, bytes, (void**)&h->d_stage_hv));
     HIPCHK(hipMemset(h->d_stage_v, 0, bytes));
     HIPCHK(hipMemset(h->d_stage_hv, 0, bytes));
     h->device_bytes += 2 * (int64_t)bytes;

@@ -249,9 +249,12 @@ int keep_count(int m, int neigen, int nconv) {
   return std::max(1, std::min(k, m - 1));
 }
 
-struct DevFree {
-  std::vector<void*> p;
+struct DevFree {  // small buffers: hipFree; `pooled`: vector-sized ones, back to the engine's cache (hxv_pool.cpp)
+  std::vector<void*> p, pooled;
+  int device = 0;
   ~DevFree() {
+    if (!pooled.empty()) (void)hipDeviceSynchronize();  // nothing may still be using a block that the next handle gets
+    for (void* q : pooled) pool_free(device, q);
     for (void* q : p)
       if (q) (void)hipFree(q);
   }
@@ -291,8 +294,9 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
   DevFree mem;
   double2* V = nullptr;
   double *d_part = nullptr, *d_coef = nullptr, *d_S = nullptr;
-  HIPCHK(hipMalloc((void**)&V, need));
-  mem.p.push_back(V);
+  mem.device = h->device;
+  HIPCHK(pool_alloc(h->device, need, (void**)&V));
+  mem.pooled.push_back(V);
   HIPCHK(hipMemsetAsync(V, 0, need, h->stream));  // pad rows must be zero: the products never write them, the dots read them
   HIPCHK(hipMalloc((void**)&d_part, (size_t)TR_BLOCKS * (2 * JB + 1) * sizeof(double)));
   mem.p.push_back(d_part);
@@ -450,8 +454,9 @@ int hxv_eigh_lowest_host(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t max
   const int64_t n = (int64_t)h->host.pitch * h->host.dimdw;
   DevFree mem;
   double2* d = nullptr;
-  HIPCHK(hipMalloc((void**)&d, (size_t)neigen * n * sizeof(double2)));
-  mem.p.push_back(d);
+  mem.device = h->device;
+  HIPCHK(pool_alloc(h->device, (size_t)neigen * n * sizeof(double2), (void**)&d));
+  mem.pooled.push_back(d);
   int rc = hxv_eigh_lowest(h, neigen, ncv, maxrestart, tol, evals, d, nconv_out, nmatvec_out);
   if (rc) return rc;
   // eig_basis(vecDim, Neigen) in the reference's layout: columns unpadded, eigenvectors consecutive (ED_DIAG.f90:145)

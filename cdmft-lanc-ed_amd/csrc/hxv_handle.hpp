@@ -12,6 +12,9 @@ struct hxv_handle;
 namespace hxv {
 int fail(int code, const std::string& msg);  // records the message hxv_last_error() returns; returns code
 constexpr int RED_BLOCKS = 1024;             // workgroups of the grid-stride reduction kernels
+// vector-sized device buffers go through the engine's cache (hxv_pool.cpp): a fresh hipMalloc costs ~25 ms per GB here
+hipError_t pool_alloc(int device, size_t bytes, void** out);
+void pool_free(int device, void* ptr);
 int ensure_wt(hxv_handle* h);                // (re)allocates the dw-hop scratch of the tiled kernels (hxv_capi.hip)
 // REAL-vector mode helpers shared by the Lanczos drivers (hxv_capi.hip / hxv_lanczos.hip)
 const char* real_mode_blocker(const hxv_handle* h);  // nullptr when real vectors can be used with this handle

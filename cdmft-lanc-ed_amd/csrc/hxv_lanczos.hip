@@ -373,7 +373,7 @@ int ensure_lz(hxv_handle* h, bool real) {
   const size_t bytes = (size_t)h->host.pitch * h->host.dimdw * sizeof(double2);
   for (auto& p : h->d_lz)
     if (!p) {
-      HIPCHK(hipMalloc((void**)&p, bytes));
+      HIPCHK(pool_alloc(h->device, bytes, (void**)&p));
       HIPCHK(hipMemset(p, 0, bytes));
       h->device_bytes += (int64_t)bytes;
     }
@@ -563,8 +563,8 @@ namespace {
 int ensure_stage(hxv_handle* h) {
   const size_t bytes = (size_t)h->host.pitch * h->host.dimdw * sizeof(double2);
   if (!h->d_stage_v) {
-    HIPCHK(hipMalloc((void**)&h->d_stage_v, bytes));
-    HIPCHK(hipMalloc((void**)&h->d_stage_hv, bytes));
+    HIPCHK(pool_alloc(h->device, bytes, (void**)&h->d_stage_v));
+    HIPCHK(pool_alloc(h->device, bytes, (void**)&h->d_stage_hv));
     HIPCHK(hipMemset(h->d_stage_v, 0, bytes));
     HIPCHK(hipMemset(h->d_stage_hv, 0, bytes));
     h->device_bytes += 2 * (int64_t)bytes;

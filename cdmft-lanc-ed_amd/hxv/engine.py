@@ -42,7 +42,7 @@ class _Stats(C.Structure):
 EXPORTS = [
     "hxv_create_from_model", "hxv_create_from_csr", "hxv_create_dw_panel", "hxv_apply_dw_panel", "hxv_apply_up_add", "hxv_destroy", "hxv_vecdim", "hxv_dims", "hxv_apply_host",
     "hxv_apply_device", "hxv_apply_device_real", "hxv_real_vectors_available", "hxv_pitch_real", "hxv_realvec_elems", "hxv_fullvec_elems", "hxv_localvec_elems", "hxv_pitch", "hxv_time_apply", "hxv_lanczos_tridiag", "hxv_lanczos_eigh", "hxv_lanczos_tridiag_host", "hxv_lanczos_eigh_host", "hxv_eigh_lowest", "hxv_eigh_lowest_host", "hxv_time_lanczos", "hxv_apply_ladder", "hxv_apply_ladder_axpy", "hxv_get_maps",
-    "hxv_nnz", "hxv_get_csr", "hxv_get_diag", "hxv_set_option", "hxv_get_option", "hxv_get_stats", "hxv_last_error",
+    "hxv_nnz", "hxv_get_csr", "hxv_get_diag", "hxv_set_option", "hxv_get_option", "hxv_get_stats", "hxv_pool_trim", "hxv_pool_stats", "hxv_last_error",
     "hxv_version",
 ]
 
@@ -105,10 +105,23 @@ def load_library():
     L.hxv_get_option.argtypes = [vp, C.c_char_p]
     L.hxv_get_option.restype = i64
     L.hxv_get_stats.argtypes = [vp, C.POINTER(_Stats)]
+    L.hxv_pool_trim.argtypes = [i32]
+    L.hxv_pool_stats.argtypes = [i32, pi64, pi64, pi64]
     L.hxv_last_error.restype = C.c_char_p
     L.hxv_version.restype = C.c_char_p
     _lib = L
     return L
+
+
+def pool_trim(device: int = -1):
+    """Return the engine's cached device buffers to the driver (include/hxv.h, device-buffer cache)."""
+    load_library().hxv_pool_trim(device)
+
+
+def pool_stats(device: int = 0) -> dict:
+    c, h, m = C.c_int64(), C.c_int64(), C.c_int64()
+    load_library().hxv_pool_stats(device, C.byref(c), C.byref(h), C.byref(m))
+    return {"cached_bytes": c.value, "hits": h.value, "misses": m.value}
 
 
 def _chk(rc: int, what: str):

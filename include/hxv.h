@@ -194,6 +194,14 @@ int hxv_apply_ladder(hxv_handle *from, hxv_handle *to, int32_t orbital, int32_t 
 int hxv_apply_ladder_axpy(hxv_handle *from, hxv_handle *to, int32_t orbital, int32_t spin, int32_t create, double coef_re,
                           double coef_im, int32_t accumulate, const void *d_psi, void *d_out, double *norm2);
 
+/* ---- device-buffer cache.  A fresh hipMalloc costs ~25 ms per GB on this platform (0.7 s for the 28 GB Krylov basis of
+ * hxv_eigh_lowest at Ns=16), and an ED run opens sectors one after another, so the vector-sized buffers a handle frees
+ * (dw-hop scratch, Lanczos vectors, staging, Krylov basis) are kept per device and reused by the next handle.
+ * Environment: HXV_POOL=0 disables it, HXV_POOL_MAX_GB caps the cached bytes (default 40 % of the device memory).
+ * hxv_pool_trim returns everything cached on `device` (all devices if < 0) to the driver.                        */
+int hxv_pool_trim(int32_t device);
+int hxv_pool_stats(int32_t device, int64_t *cached_bytes, int64_t *hits, int64_t *misses);
+
 /* ---- introspection (parity tests against spH0ups/spH0dws/spH0d) ------------------------ */
 int hxv_get_maps(const hxv_handle *h, int32_t *map_up, int32_t *map_dw); /* Hs(1)%map, Hs(2)%map */
 int64_t hxv_nnz(const hxv_handle *h, int32_t which);                      /* 0: H_up, 1: H_dw */
