@@ -9,6 +9,8 @@
 // workgroups that share those columns/rows carry the same blockIdx%8 (one XCD) so these reads
 // hit its L2.  Reference semantics: ED_HAMILTONIAN_SPARSE_HxV.f90:167-227 / :230-315.
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <numeric>
 #include <type_traits>
 
@@ -617,6 +619,18 @@ void build_spin_tiles(const SpinOp& op, const std::vector<uint32_t>& map, int lo
   t.rs_per_row = rs_rows / dim;
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel and size, not per launch (small sectors are launch-bound)
+hipError_t allow_dynamic_lds(const void* kern, int bytes) {
+  static std::mutex mu;
+  static std::map<const void*, int> granted;
+  std::lock_guard<std::mutex> lk(mu);
+  int& g = granted[kern];
+  if (bytes <= g) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) g = bytes;
+  return e;
+}
+
 template <int C, bool LZ, typename VT>
 hipError_t launch_up_lz(const DevSector& s, const DevTiles& t, int lds_bytes, int threads, bool norb1, int wc, const VT* v,
                         const VT* wt, VT* hv, const LzEpilogue& lz, hipStream_t st) {
@@ -633,7 +647,7 @@ hipError_t launch_up_lz(const DevSector& s, const DevTiles& t, int lds_bytes, in
       kern = norb1 ? hxv_pass_up<C, false, true, LZ, double2> : hxv_pass_up<C, false, false, LZ, double2>;
   }
   lds_bytes = std::max(lds_bytes, threads * 8);  // the epilogue reduces through LDS
-  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  hipError_t e = allow_dynamic_lds((const void*)kern, lds_bytes);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(threads), (size_t)lds_bytes, st, s, t, v, wt, hv, ngroups, gpx, wc, lz);
   return hipGetLastError();
@@ -657,7 +671,7 @@ hipError_t launch_dw_np(const DevSector& s, const DevTiles& t, int lds_bytes, in
     kern = hxv_pass_dw<R, NP, true, double>;
   else
     kern = s.real_h ? hxv_pass_dw<R, NP, true, double2> : hxv_pass_dw<R, NP, false, double2>;
-  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  hipError_t e = allow_dynamic_lds((const void*)kern, lds_bytes);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(threads), (size_t)lds_bytes, st, s, t, v, hv, ngroups, gpx, wc);
   return hipGetLastError();
