@@ -40,3 +40,24 @@ def test_fortran_host_through_procedure_pointer(built):
     m2 = re.search(r"C2 device eigh E0=\s*([-\d.Ee+]+)\s*\|vec\|\^2-1=\s*([-\d.Ee+]+)", txt)
     e0_eig, dn = float(m2.group(1)), float(m2.group(2))
     assert abs(e0_tri - e0_c2) < 1e-9 and abs(e0_eig - e0_c2) < 1e-9 and abs(dn) < 1e-10
+
+
+def test_fortran_gpu_sp_eigh_wrapper(built):
+    """gpu_sp_eigh(MatVec,eval,evec,Nblock,Nitermax,tol) -- SciFortran's sp_eigh signature, ED_DIAG.f90:152-160 -- called from
+    the Fortran demo host on C2: two lowest eigenvalues vs scipy ARPACK on the oracle's matrices, residual of the 2nd pair."""
+    import scipy.sparse.linalg as sla
+    from hxv import models
+    from oracle.oracle import OracleSector
+    from helpers_matrix import oracle_full_matrix
+
+    exe = built.build_fortran()
+    if exe is None:
+        pytest.skip("flang not available")
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    m2 = re.search(r"C2 device sp_eigh E=\s*([-\d.Ee+]+)\s+([-\d.Ee+]+)\s+resid2=\s*([-\d.Ee+]+)", out.stdout)
+    assert m2, out.stdout
+    e = np.array([float(m2.group(1)), float(m2.group(2))])
+    H = oracle_full_matrix(OracleSector(models.hm_1dchain(eps_bath=[0.3, 0.6]), 6, 6))
+    ref = np.sort(sla.eigsh(H, k=2, which="SA", ncv=20, tol=1e-13)[0])
+    assert np.abs(e - ref).max() < 1e-9 and float(m2.group(3)) < 1e-8
