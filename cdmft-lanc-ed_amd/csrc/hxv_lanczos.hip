@@ -252,6 +252,21 @@ struct LzBuf {
 // scal[i] = scal[a] * scal[b]
 __global__ void lz_mul(double* scal, int i, int a, int b) { scal[i] = scal[a] * scal[b]; }
 
+// End of one fused iteration without the host: record alpha_k = scal[0], beta_{k+1} = scal[1] at the device-side step
+// counter scal[6], and prepare the next iteration's scalars  s = 1/beta_{k+1} (scal[2]),  c = s_old/s = beta_{k+1}/beta_k (scal[3]).
+__global__ void lz_next(double* scal, double* alpha_out, double* beta_out, int nmax) {
+  const int k = (int)scal[6];
+  if (k < nmax) {
+    alpha_out[k] = scal[0];
+    if (k + 1 < nmax) beta_out[k + 1] = scal[1];
+  }
+  // (the same operations, in the same order, as LzRunner::advance() + step() on the host: bit-identical recurrences)
+  const double beta_prev = 1.0 / scal[2], s_new = 1.0 / scal[1];
+  scal[2] = s_new;
+  scal[3] = 1.0 / (s_new * beta_prev);
+  scal[6] = (double)(k + 1);
+}
+
 // Lanczos recurrence on device.  Two implementations of one step:
 //  * plain : w = H q (any kernel), then lz_sub_dot / lz_sub_nrm / lz_scale on normalised vectors;
 //  * fused : vectors are kept UNNORMALISED (q_k = s*X, s = 1/beta_k); pass A's epilogue produces
@@ -333,6 +348,87 @@ struct LzRunner {
     *alpha = host[0];
     *beta = host[1];
     last_beta = host[1];
+    return HXV_OK;
+  }
+
+  // One fused iteration enqueued with NO host involvement: s and c are read from scal[2], scal[3] (left there by the
+  // previous lz_next), alpha/beta go to device arrays.  q, qm, w are explicit so that a rotation cycle can be captured.
+  int enqueue_device_iteration(double2* q, double2* qm, double2* w, double* d_alpha, double* d_beta, int nmax) {
+    const int g = grid_for(n2);
+    const int64_t nwg = tiled_pass_up_workgroups(h->dev, h->plan, real);
+    LzEpilogue ep;
+    ep.xm = qm;
+    ep.scal = h->d_scalars;
+    ep.i_s = 2;
+    ep.i_c = 3;
+    ep.partial = h->d_lz_partial;
+    hipError_t e;
+    if (real) {
+      DevSector d = h->dev;
+      d.pitch = pitch_real_of(h);
+      e = launch_hxv_tiled_real(d, h->plan, (const double*)q, (double*)h->d_wt, (double*)w, h->stream, &ep);
+    } else {
+      e = launch_hxv_tiled(h->dev, h->plan, q, h->d_wt, w, h->stream, &ep);
+    }
+    if (e != hipSuccess) return fail(HXV_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    h->n_apply++;
+    hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_lz_partial, (int)nwg, h->d_scalars, 0, 0);
+    hipLaunchKernelGGL(lz_mul, dim3(1), dim3(1), 0, h->stream, h->d_scalars, 4, 0, 2);
+    hipLaunchKernelGGL(lz_sub_nrm, dim3(g), dim3(256), 0, h->stream, n2, w, q, h->d_scalars, 4, h->d_partials + RED_BLOCKS);
+    hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_partials + RED_BLOCKS, g, h->d_scalars, 1, 1);
+    hipLaunchKernelGGL(lz_next, dim3(1), dim3(1), 0, h->stream, h->d_scalars, d_alpha, d_beta, nmax);
+    return HXV_OK;
+  }
+
+  // Iterations 1..nmax-1 of a fixed-length run on the device alone (iteration 0 was done by step(); scal[2], scal[3],
+  // scal[6] are set): the three-iteration pointer-rotation cycle is captured ONCE into a hipGraph and replayed, so a
+  // small sector pays one graph launch per three iterations instead of ~9 kernel launches, two copies and a
+  // synchronisation per iteration.  Leaves b.q/b.qm/b.w as after the last iteration.
+  int run_device_iterations(int nmax, double* d_alpha, double* d_beta, bool use_graph) {
+    double2* buf[3] = {b.q, b.w, b.qm};  // iteration k uses q = buf[k%3] (k counted from 1: q = former w), w = buf[(k+1)%3], qm = buf[(k+2)%3]
+    // after step() of iteration 0 and before any rotation: X_1 = b.w, X_0 = b.q, free = b.qm
+    int k = 1;
+    auto one = [&](int kk) -> int {
+      double2* q = buf[kk % 3];
+      double2* w = buf[(kk + 1) % 3];
+      double2* qm = buf[(kk + 2) % 3];
+      return enqueue_device_iteration(q, qm, w, d_alpha, d_beta, nmax);
+    };
+    const int cycles = use_graph ? (nmax - 1) / 3 : 0;
+    if (cycles >= 2) {
+      hipGraph_t graph = nullptr;
+      hipGraphExec_t exec = nullptr;
+      HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+      int rc = HXV_OK;
+      for (int u = 0; u < 3 && rc == HXV_OK; ++u) rc = one(k + u);
+      hipError_t ec = hipStreamEndCapture(h->stream, &graph);
+      if (rc) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return rc;
+      }
+      if (ec != hipSuccess) return fail(HXV_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ec));
+      ec = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+      if (ec != hipSuccess) {
+        (void)hipGraphDestroy(graph);
+        return fail(HXV_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ec));
+      }
+      for (int cy = 0; cy < cycles; ++cy) {
+        ec = hipGraphLaunch(exec, h->stream);
+        if (ec != hipSuccess) break;
+      }
+      k += 3 * cycles;  // (k-1) % 3 is unchanged: the remainder below continues the same rotation
+      (void)hipGraphExecDestroy(exec);
+      (void)hipGraphDestroy(graph);
+      if (ec != hipSuccess) return fail(HXV_ERR_HIP, std::string("hipGraphLaunch: ") + hipGetErrorString(ec));
+    }
+    for (; k < nmax; ++k) {
+      int rc = one(k);
+      if (rc) return rc;
+    }
+    b.q = buf[(nmax - 1) % 3];
+    b.w = buf[nmax % 3];
+    b.qm = buf[(nmax + 1) % 3];
+    first = false;
     return HXV_OK;
   }
 
@@ -438,6 +534,53 @@ int hxv_lanczos_tridiag(hxv_handle* h, const void* d_vin, int32_t nlanc, double*
     blanc[k] = 0;
   }
   int k = 0;
+  if (lz.fused && h->lz_graph && nlanc >= 8) {
+    // Fixed-length run (the Green's-function use, ED_GF_NORMAL.f90:204-220): iteration 0 with the host in the loop, the
+    // other nlanc-1 on the device alone -- scalars stay in device memory, the pointer-rotation cycle of three
+    // iterations is one hipGraph -- and alpha/beta come back once at the end.  A breakdown (beta < threshold) is
+    // found afterwards; whatever was computed past it is discarded.
+    double a, bt;
+    rc = lz.step(&a, &bt);
+    if (rc) return rc;
+    alanc[0] = a;
+    blanc[1] = bt;
+    k = 1;
+    if (std::fabs(bt) >= threshold) {
+      double* d_ab = nullptr;
+      HIPCHK(hipMalloc((void**)&d_ab, (size_t)2 * nlanc * sizeof(double)));
+      HIPCHK(hipMemsetAsync(d_ab, 0, (size_t)2 * nlanc * sizeof(double), h->stream));
+      const double s1 = 1.0 / bt, bprev = 1.0 / lz.s_cur;
+      const double init[2] = {s1, 1.0 / (s1 * bprev)};   // s_1 = 1/beta_1 ; c_1 = beta_1/beta_0, rounded like LzRunner::step()
+      const double one = 1.0;
+      hipError_t e1 = hipMemcpyAsync(h->d_scalars + 2, init, 2 * sizeof(double), hipMemcpyHostToDevice, h->stream);
+      hipError_t e2 = hipMemcpyAsync(h->d_scalars + 6, &one, sizeof(double), hipMemcpyHostToDevice, h->stream);
+      if (e1 == hipSuccess && e2 == hipSuccess) e1 = hipStreamSynchronize(h->stream);
+      rc = (e1 != hipSuccess || e2 != hipSuccess) ? fail(HXV_ERR_HIP, "scalar upload failed") : lz.run_device_iterations(nlanc, d_ab, d_ab + nlanc, true);
+      std::vector<double> ab((size_t)2 * nlanc, 0.0);
+      if (rc == HXV_OK) {
+        hipError_t e3 = hipMemcpyAsync(ab.data(), d_ab, ab.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+        if (e3 == hipSuccess) e3 = hipStreamSynchronize(h->stream);
+        if (e3 != hipSuccess) rc = fail(HXV_ERR_HIP, std::string("reading alpha/beta back: ") + hipGetErrorString(e3));
+      }
+      (void)hipStreamSynchronize(h->stream);
+      (void)hipFree(d_ab);
+      if (rc) return rc;
+      for (k = 1; k < nlanc; ++k) {
+        alanc[k] = ab[k];
+        const double b1 = k + 1 < nlanc ? ab[(size_t)nlanc + k + 1] : 1.0;
+        if (k + 1 < nlanc) blanc[k + 1] = b1;
+        if (!std::isfinite(alanc[k]) || !std::isfinite(b1) || (k + 1 < nlanc && std::fabs(b1) < threshold)) {
+          if (!std::isfinite(alanc[k])) alanc[k] = 0.0;
+          if (k + 1 < nlanc && !std::isfinite(b1)) blanc[k + 1] = 0.0;
+          ++k;
+          break;
+        }
+      }
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (nsteps) *nsteps = k;
+    return HXV_OK;
+  }
   for (; k < nlanc; ++k) {
     double a, bt;
     rc = lz.step(&a, &bt);

@@ -140,6 +140,8 @@ int hxv_time_apply(hxv_handle *h, const void *d_v_full, void *d_hv_local, int32_
  * eigh: lowest eigenvalue *egs and eigenvector d_vect (device, Dim, written) from a
  *   deterministic start vector; stops when |dE| < threshold (and, if d_vect is wanted, the Ritz
  *   residual estimate |beta*y_last| < 1e-11*max(1,|E|)) or at nitermax (ED_DIAG.f90:176).
+ * tridiag with nlanc >= 8 runs iterations 1.. on the device alone (scalars in device memory, three iterations per
+ *   hipGraph, alanc/blanc copied back once; option "lanczos_graph", default 1): bit-identical to the stepwise run.
  * REAL-vector mode (above): with option "real_vectors" = 1 (default) these drivers and hxv_eigh_lowest run on real
  *   vectors whenever hxv_real_vectors_available(h) and the start vector is real (eigh / eigh_lowest: the engine's own
  *   start vector is then real; tridiag: d_vin must have exactly zero imaginary part, else the complex path runs).

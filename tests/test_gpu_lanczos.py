@@ -478,3 +478,43 @@ def test_device_buffer_cache_reuses_vector_sized_buffers(built):
     b.close()
     hxv.pool_trim()
     assert hxv.pool_stats()["cached_bytes"] == 0
+
+
+@pytest.mark.parametrize("case", ["chain8", "C2_blocks", "tiny_breakdown", "bhz_complex"])
+def test_graph_captured_tridiagonalisation_equals_the_stepwise_one(built, case):
+    """hxv_lanczos_tridiag runs iterations 1.. on the device alone, three per hipGraph (option lanczos_graph): the same
+    kernels on the same data as the host-stepped recurrence, so alanc/blanc agree to the last bit, including a breakdown."""
+    import time
+    import torch
+    import hxv
+    from hxv import models
+
+    if case == "chain8":
+        sec, nl = hxv.HxvSector.from_model(models.hm_1dchain(Nlat=2, Nbath=3), 4, 4), 60
+    elif case == "C2_blocks":
+        sec, nl = hxv.HxvSector.from_model(models.hm_1dchain(), 6, 6), 100
+        sec.set_option("lds_budget_kb_up", 16)
+        sec.set_option("lds_budget_kb_dw", 32)
+    elif case == "tiny_breakdown":
+        sec, nl = hxv.HxvSector.from_model(models.plaquette_2x2_nobath(), 2, 2), 60      # Dim = 36 < nlanc
+    else:
+        sec, nl = hxv.HxvSector.from_model(models.bhz_2d(Nbath=0), 4, 4), 50
+    rng = np.random.default_rng(2)
+    for real_start in (True, False):
+        v = rng.standard_normal(sec.Dim) + (0 if real_start else 1j) * rng.standard_normal(sec.Dim)
+        v = (v / np.linalg.norm(v)).astype(np.complex128)
+        dv = torch.from_numpy(v).cuda()
+        out = {}
+        for g in (1, 0):
+            sec.set_option("lanczos_graph", g)
+            t0 = time.perf_counter()
+            out[g] = sec.lanczos_tridiag(dv, nl, threshold=1e-10)
+            out[g] += (time.perf_counter() - t0,)
+        (a1, b1, n1, _), (a0, b0, n0, _) = out[1], out[0]
+        if case == "tiny_breakdown":
+            # past ~Dim steps the recurrence runs on rounding noise: compare the common, meaningful part
+            m = min(n0, n1, 20)
+            assert m >= 10 and np.allclose(a1[:m], a0[:m], rtol=0, atol=1e-9) and np.allclose(b1[:m], b0[:m], rtol=0, atol=1e-9)
+        else:
+            assert n1 == n0 == nl
+            assert np.array_equal(a1, a0) and np.array_equal(b1, b0)
