@@ -806,6 +806,32 @@ int hxv_time_lanczos(hxv_handle* h, void* d_work3, int32_t nrep, float* ms_per_i
   double a, bt;
   rc = lz.step(&a, &bt);  // untimed first step (lazy allocations)
   if (rc) return rc;
+  if (lz.fused && h->lz_graph && nrep >= 8) {
+    // the fixed-length device-only path of hxv_lanczos_tridiag: iterations 1..nrep, three per hipGraph
+    double* d_ab = nullptr;
+    HIPCHK(hipMalloc((void**)&d_ab, (size_t)2 * (nrep + 1) * sizeof(double)));
+    const double s1 = 1.0 / bt, bprev = 1.0 / lz.s_cur;
+    const double init[2] = {s1, 1.0 / (s1 * bprev)};
+    const double one = 1.0;
+    hipError_t e = hipMemcpyAsync(h->d_scalars + 2, init, 2 * sizeof(double), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(h->d_scalars + 6, &one, sizeof(double), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = hipEventRecord(h->ev0, h->stream);
+    rc = e != hipSuccess ? fail(HXV_ERR_HIP, std::string("hxv_time_lanczos: ") + hipGetErrorString(e))
+                         : lz.run_device_iterations(nrep + 1, d_ab, d_ab + nrep + 1, true);
+    if (rc == HXV_OK) {
+      e = hipEventRecord(h->ev1, h->stream);
+      if (e == hipSuccess) e = hipEventSynchronize(h->ev1);
+      if (e != hipSuccess) rc = fail(HXV_ERR_HIP, std::string("hxv_time_lanczos: ") + hipGetErrorString(e));
+    }
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(d_ab);
+    if (rc) return rc;
+    float msg = 0;
+    HIPCHK(hipEventElapsedTime(&msg, h->ev0, h->ev1));
+    *ms_per_iter = msg / (float)nrep;
+    return HXV_OK;
+  }
   rc = lz.advance();
   if (rc) return rc;
   HIPCHK(hipEventRecord(h->ev0, h->stream));
