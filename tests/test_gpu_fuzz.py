@@ -108,3 +108,60 @@ def test_random_models_sectors_shards_and_tile_options(built, seed):
     if size > 1:   # the oracle's own MPI emulation agrees with its serial product (keeps the checker honest)
         chk, _ = spMatVec_mpi_main(m, nup, ndw, size, v)
         assert np.abs(chk - ref).max() <= 1e-13 * scale
+
+
+@pytest.mark.parametrize("shape,sector,seed", [((4, 1, 2, 2), (6, 6), 1), ((2, 2, 1, 2), (6, 5), 2), ((3, 1, 2, 3), (6, 7), 3), ((2, 3, 1, 1), (5, 6), 4),
+                                                ((1, 2, 2, 5), (6, 6), 5), ((2, 2, 2, 2), (7, 6), 6)])
+def test_random_ns12_models_multi_block_plans(built, shape, sector, seed):
+    """Ns = 12 with random (dense-ish, partly complex) one-body matrices and Kanamori terms: several prefix blocks per spin,
+    many distinct amplitudes (LDS coefficient tables, the > 255 amplitudes fallback), shards -- vs the oracle's product."""
+    import torch
+    import hxv
+    from hxv.models import Model
+    from oracle.oracle import OracleSector
+
+    rng = np.random.default_rng(7000 + seed)
+    Nlat, Norb, Nspin, Nbath = shape
+    n = Nlat * Norb
+
+    def blocks():
+        out = []
+        for _ in range(Nspin):
+            A = rng.standard_normal((n, n)) * (rng.random((n, n)) < 0.7)
+            if seed % 2:
+                A = A + 1j * rng.standard_normal((n, n)) * (rng.random((n, n)) < 0.5)
+            out.append((A + A.conj().T) / 2)
+        return out
+
+    def to6(bl):
+        h = np.zeros((Nlat, Nlat, Nspin, Nspin, Norb, Norb), dtype=np.complex128)
+        for s in range(Nspin):
+            for il in range(Nlat):
+                for jl in range(Nlat):
+                    for io in range(Norb):
+                        for jo in range(Norb):
+                            h[il, jl, s, s, io, jo] = bl[s][io + il * Norb, jo + jl * Norb]
+        return h
+
+    hb = np.stack([to6(blocks()) for _ in range(Nbath)], axis=-1)
+    vb = rng.standard_normal((Nlat, Nspin, Norb, Nbath))
+    U = np.zeros(5)
+    U[:Norb] = 1.0 + rng.random(Norb)
+    m = Model(Nlat, Norb, Nspin, Nbath, to6(blocks()), hb, vb, Uloc=U, Ust=0.7 if Norb > 1 else 0.0, Jh=0.2 if Norb > 1 else 0.0,
+              Jx=0.15 if Norb > 1 and seed in (2, 6) else 0.0, Jp=0.1 if Norb > 1 and seed == 6 else 0.0, xmu=0.1, hfmode=bool(seed % 2), name="fuzz12")
+    assert m.Ns == 12
+    nup, ndw = sector
+    full = OracleSector(m, nup, ndw)
+    v = rng.standard_normal(full.Dim) + 1j * rng.standard_normal(full.Dim)
+    ref = full.spMatVec_main(v)
+    scale = np.abs(ref).max()
+    for rank, size in ((0, 1), (1, 3)):
+        sec = hxv.HxvSector.from_model(m, nup, ndw, rank=rank, nranks=size)
+        dv = torch.from_numpy(sec.to_gather_layout(v, size)).cuda()
+        want = ref[sec.mpiIshift: sec.mpiIshift + sec.vecDim]
+        for o in ({}, {"lds_budget_kb": 16}, {"lds_budget_kb": 8, "cols_per_tile": 2, "rows_per_tile": 8}, {"kernel": 0}):
+            for k, val in o.items():
+                sec.set_option(k, val)
+            got = sec.unpad(sec.apply_device(dv)).cpu().numpy()
+            assert np.abs(got - want).max() <= 2e-13 * scale, (o, rank, size, sec.stats())
+        sec.close()
