@@ -165,3 +165,43 @@ def test_random_ns12_models_multi_block_plans(built, shape, sector, seed):
             got = sec.unpad(sec.apply_device(dv)).cpu().numpy()
             assert np.abs(got - want).max() <= 2e-13 * scale, (o, rank, size, sec.stats())
         sec.close()
+
+
+def test_from_csr_with_more_distinct_amplitudes_than_the_lds_table_holds(built):
+    """hxv_create_from_csr with random matrix values: > 255 distinct |amplitudes| per spin -> the tiled kernels' LDS
+    coefficient table is not used and the engine falls back to its one-thread-per-element GPU kernel (never to the CPU);
+    > 1023 is refused loudly."""
+    import scipy.sparse as sp
+    import torch
+    import hxv
+
+    rng = np.random.default_rng(77)
+    du, dd = 150, 130
+
+    def rand_herm(n, nnz_per_row):
+        A = sp.random(n, n, density=nnz_per_row / n, random_state=rng, data_rvs=rng.standard_normal).tocsr()
+        A = A + 1j * sp.random(n, n, density=nnz_per_row / n, random_state=rng, data_rvs=rng.standard_normal).tocsr()
+        H = (A + A.conj().T).tocsr()
+        H.setdiag(0)
+        H.eliminate_zeros()
+        H.sort_indices()
+        return H
+
+    Hup, Hdw = rand_herm(du, 3), rand_herm(dd, 3)
+    assert len(np.unique(np.round(np.abs(Hup.data), 12))) > 255
+    diag = rng.standard_normal(du * dd)
+    csr = lambda H: (H.indptr.astype(np.int64), (H.indices + 1).astype(np.int32), H.data.astype(np.complex128))
+    sec = hxv.HxvSector.from_csr(du, dd, csr(Hup), csr(Hdw), diag)
+    v = rng.standard_normal(du * dd) + 1j * rng.standard_normal(du * dd)
+    V = v.reshape(dd, du).T                       # V[iup, idw]
+    ref = (diag.reshape(dd, du).T * V + Hup @ V + (Hdw @ V.T).T).T.reshape(-1)
+    got = sec.apply_device(torch.from_numpy(v).cuda()).cpu().numpy()
+    assert np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max()
+    e0 = sec.lanczos_eigh(600, 1e-12, want_vector=False)[0]
+    Hfull = sp.diags(diag) + sp.kron(sp.identity(dd), Hup) + sp.kron(Hdw, sp.identity(du))
+    import scipy.sparse.linalg as sla
+    assert abs(e0 - sla.eigsh(Hfull.tocsr(), k=1, which="SA", tol=1e-12)[0][0]) < 1e-8
+    big = rand_herm(700, 4)
+    if len(np.unique(np.round(np.abs(big.data), 12))) > 1023:
+        with pytest.raises(hxv.HxvError):
+            hxv.HxvSector.from_csr(700, dd, csr(big), csr(Hdw), rng.standard_normal(700 * dd))
