@@ -6,4 +6,4 @@ the reference's own host code), hxv/ (this Python mirror of the reference interf
 from .engine import HxvError, HxvSector, LIB_PATH, load_library, EXPORTS, pool_stats, pool_trim  # noqa: F401
 from .hamiltonian import EDContext  # noqa: F401
 from . import models  # noqa: F401
-from .distributed import ShardedHxv, ShardedLanczos, TransposedHxv, dw_split, start_vector_slab  # noqa: F401
+from .distributed import ShardedHxv, ShardedLanczos, TransposedHxv, dw_split, sharded_eigh_lowest, start_vector_slab  # noqa: F401

@@ -307,3 +307,93 @@ class ShardedLanczos:
     def start_slab(self, device="cpu"):
         mv = self.mv
         return start_vector_slab(mv.DimUp, mv.qdw, mv.dw0, mv.pitch, device)
+
+
+def _keep_count(m: int, neigen: int, nconv: int) -> int:
+    """Ritz vectors kept at a thick restart (same rule as csrc/hxv_eigh.hip)."""
+    k = neigen + min(nconv, (m - neigen) // 2) + max(1, (m - neigen) // 4)
+    return max(1, min(k, m - 1))
+
+
+def sharded_eigh_lowest(matvec, neigen: int = 1, ncv: int = 0, maxrestart: int = 512, tol: float = 0.0, device="cpu", group=None):
+    """sp_eigh(MpiComm, MatVec, eval, evec, Nblock, Nitermax, tol) for a DimDw-split sector (the P-ARPACK call of
+    ED_DIAG.f90:152-156 when MpiStatus=T): the thick-restart Lanczos of csrc/hxv_eigh.hip on slabs -- every rank keeps its
+    slab of each basis vector, projections are all-reduced, the small projected problem is solved redundantly on every
+    rank.  `matvec` is a ShardedHxv / TransposedHxv.  -> (evals[neigen], slabs [neigen, Nloc], nconv, nmatvec)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    mv = matvec
+    dim = mv.DimUp * mv.DimDw
+    neigen = min(neigen, dim)
+    if ncv <= 0:
+        ncv = 10 * neigen
+    m = int(min(max(ncv, neigen + 1), dim))
+    eps = float(np.finfo(float).eps)
+    tol = max(tol, eps)
+    eps23 = eps ** (2.0 / 3.0)
+
+    def allsum(t):
+        if mv.size > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return t
+
+    def dots(Vj, w):      # <V_i, w> for the stacked slabs, all-reduced (complex via its float64 view)
+        c = Vj.conj() @ w
+        allsum(torch.view_as_real(c))
+        return c
+
+    V = torch.zeros(m + 1, mv.Nloc, dtype=torch.complex128, device=device)
+    q0 = start_vector_slab(mv.DimUp, mv.qdw, mv.dw0, mv.pitch, device)
+    V[0] = q0 / float(allsum(torch.vdot(q0, q0).real.reshape(1).clone()).item()) ** 0.5
+    T = np.zeros((m, m))
+    w = torch.zeros(mv.Nloc, dtype=torch.complex128, device=device)
+    k, nmv, nconv, meff, beta_last = 0, 0, 0, m, 0.0
+    theta = S = None
+    for it in range(maxrestart + 1):
+        meff, beta_last = m, 0.0
+        for j in range(k, m):
+            mv(mv.Nloc, V[j], w)
+            nmv += 1
+            c = dots(V[: j + 1], w)
+            ch = c.cpu().numpy()
+            T[j, j] = ch[j].real
+            sel = np.abs(ch) > 1e-13 * np.sqrt(np.vdot(ch, ch).real)      # measured Gram-Schmidt, selective update
+            sel[max(j - 1, 0):] = True
+            if j == k:
+                sel[:] = True
+            cs = torch.from_numpy(ch * sel).to(device)
+            w.sub_(cs @ V[: j + 1])
+            nrm = float(allsum(torch.vdot(w, w).real.reshape(1).clone()).item()) ** 0.5
+            if nrm * nrm < 0.01 * (np.vdot(ch, ch).real + nrm * nrm):         # norm dropped 10x: one refinement pass
+                c2 = dots(V[: j + 1], w)
+                T[j, j] += float(c2[j].real.item())
+                w.sub_(c2 @ V[: j + 1])
+                nrm2 = float(allsum(torch.vdot(w, w).real.reshape(1).clone()).item()) ** 0.5
+                nrm = 0.0 if nrm2 < 0.5 * nrm else nrm2
+            if nrm <= 1e-13 * max(1.0, np.abs(T[: j + 1, : j + 1]).max()):
+                meff, beta_last = j + 1, 0.0
+                break
+            if j + 1 < m:
+                T[j + 1, j] = T[j, j + 1] = nrm
+            beta_last = nrm
+            V[j + 1] = w / nrm
+        theta, S = np.linalg.eigh(T[:meff, :meff])
+        ne = min(neigen, meff)
+        res = np.abs(beta_last * S[meff - 1, :])
+        nconv = int((res[:ne] <= tol * np.maximum(eps23, np.abs(theta[:ne]))).sum())
+        if nconv == ne or meff < m or it == maxrestart:
+            break
+        k = _keep_count(m, neigen, nconv)
+        St = torch.from_numpy(np.ascontiguousarray(S[:, :k].T)).to(device=device, dtype=torch.complex128)
+        V[:k] = St @ V[:m]
+        V[k] = V[m]
+        T[:] = 0.0
+        for i in range(k):
+            T[i, i] = theta[i]
+            T[k, i] = T[i, k] = beta_last * S[m - 1, i]
+    ne = min(neigen, meff)
+    St = torch.from_numpy(np.ascontiguousarray(S[:, :ne].T)).to(device=device, dtype=torch.complex128)
+    X = St @ V[:meff]
+    return theta[:ne].copy(), X, nconv, nmv

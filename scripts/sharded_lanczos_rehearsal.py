@@ -19,11 +19,15 @@ panel = hxv.HxvSector.dw_panel(m, nup, ndw, nrows)
 th = hxv.TransposedHxv(sec.DimUp, sec.DimDw, rank, world, panel.apply_dw_panel, sec.apply_up_add, pitch=sec.pitch, pitch_panel=panel.pitch,
                        stage_on_host=True)
 e0t, _, nitt = hxv.ShardedLanczos(th).eigh(512, 1e-13, want_vector=False, device="cuda")
+ev, X, nconv, nmv = hxv.sharded_eigh_lowest(sh, 2, 20, device="cuda")
 if rank == 0:
     full = hxv.HxvSector.from_model(m, nup, ndw)
     full.set_option("real_vectors", 0)
     ref, _, nref = full.lanczos_eigh(512, 1e-13, want_vector=False)
     print(f"world={world}: E0 all-gather {e0:.12f} ({nit} it)  all-to-all {e0t:.12f} ({nitt} it)  single GPU {ref:.12f} ({nref} it)", flush=True)
     assert abs(e0 - ref) < 1e-10 and abs(e0t - ref) < 1e-10
+    evs, _, ncs, nmvs = full.eigh_lowest(2, 20, want_vectors=False)
+    print(f"  sp_eigh flavour: sharded {ev} ({nmv} products, nconv={nconv})  single GPU {evs} ({nmvs} products)", flush=True)
+    assert nconv == 2 and abs(ev - evs).max() < 1e-10 and abs(nmv - nmvs) <= 0.25 * nmvs
 dist.barrier()
 dist.destroy_process_group()

@@ -165,7 +165,9 @@ def _worker_lanczos(rank, world, port, nup, ndw, out):
     v_local = torch.from_numpy(v_full[orc.mpiIshift: orc.mpiIshift + orc.vecDim].copy())
     a, b, n = lz.tridiag(v_local, 25)
     e0, vec, nit = lz.eigh(300, 1e-13)
-    np.savez(os.path.join(out, f"lz_{rank}.npz"), a=a, b=b, n=n, e0=e0, vec=vec.numpy(), nit=nit, start=lz.start_slab().numpy())
+    ev, X, nconv, nmv = hxv.sharded_eigh_lowest(sh, 3, 16)
+    np.savez(os.path.join(out, f"lz_{rank}.npz"), a=a, b=b, n=n, e0=e0, vec=vec.numpy(), nit=nit, start=lz.start_slab().numpy(),
+             ev=ev, X=X.numpy(), nconv=nconv, nmv=nmv)
     dist.destroy_process_group()
 
 
@@ -195,5 +197,14 @@ def test_sharded_lanczos_gloo(world, sector, tmp_path):
     assert abs(float(res[0]["e0"]) - w[0]) <= 1e-10
     x = np.concatenate([r["vec"] for r in res])
     assert abs(np.linalg.norm(x) - 1) < 1e-12 and np.linalg.norm(H @ x - float(res[0]["e0"]) * x) < 1e-8
+    # sp_eigh with a communicator: three lowest pairs, same algorithm and start vector as the single-GPU hxv_eigh_lowest
+    from trlan_numpy import trlan_lowest
+    import scipy.sparse as sp
+    ev_np, _, _, nmv_np, _ = trlan_lowest(lambda y: H @ y, s.Dim, 3, 16)
+    for r in res:
+        assert int(r["nconv"]) == 3 and np.abs(r["ev"] - w[:3]).max() < 1e-10 and np.abs(r["ev"] - ev_np).max() < 1e-11
+        assert abs(int(r["nmv"]) - nmv_np) <= 0.25 * nmv_np
+    Xf = np.concatenate([r["X"] for r in res], axis=1).T          # (Dim, 3)
+    assert np.abs(Xf.conj().T @ Xf - np.eye(3)).max() < 1e-11 and np.linalg.norm(H @ Xf - Xf * res[0]["ev"], axis=0).max() < 1e-9
     # the slabs of the start vector are the slabs of the single-GPU driver's deterministic start vector
     assert np.array_equal(np.concatenate([r["start"] for r in res]), start_vector(s.Dim))
