@@ -212,7 +212,18 @@ int hxv_get_csr(const hxv_handle *h, int32_t which, int64_t *rowptr, int32_t *co
 /* local diagonal (vecdim doubles; the engine requires a real diagonal) */
 int hxv_get_diag(const hxv_handle *h, double *diag);
 
-/* options: "kernel" (0 naive one-pass, 1 tiled two-pass [default]), "tile_bits" ... */
+/* Options (name, value).  Behaviour:
+ *   "kernel"          1 = tiled two-pass kernels [default], 0 = one thread per element (cross-check / fallback)
+ *   "real_vectors"    1 [default] = device Lanczos drivers run on real vectors when H and the start vector are real
+ *   "lanczos_fused"   1 [default] = recurrence fused into the product's epilogue; 0 = separate vector kernels
+ *   "lanczos_graph"   1 [default] = fixed-length tridiagonalisations run device-only, three iterations per hipGraph
+ * Tile shape (changing one rebuilds the plan; invalid combinations are refused with a message):
+ *   "cols_per_tile" 2|4|8 [4], "rows_per_tile" 2|4|8 [4], "lds_budget_kb[_up|_dw]" 8..144 [64], "threads_up|_dw"
+ *   256|512|1024 [1024], "sort_mode" 0..2 [0], "sort_mode_dw" 0|1 [1], "wt_cols" 2|4|8|16 [4], "force_bits_up|_dw",
+ *   "lds_min_kb_up|_dw".
+ * Timing experiments only (results are wrong or partial when set): "passes" 1|2|3 [3], "debug" bit mask.
+ * hxv_get_option additionally reports plan statistics ("tile_bits_up", "nblocks_up", "slots_in_up_x100", ...,
+ * "lanczos_real_last").                                                                                      */
 int hxv_set_option(hxv_handle *h, const char *name, int64_t value);
 int64_t hxv_get_option(const hxv_handle *h, const char *name);
 
