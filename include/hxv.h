@@ -219,7 +219,7 @@ int hxv_get_diag(const hxv_handle *h, double *diag);
  *   "lanczos_graph"   1 [default] = fixed-length tridiagonalisations run device-only, three iterations per hipGraph
  * Tile shape (changing one rebuilds the plan; invalid combinations are refused with a message):
  *   "cols_per_tile" 2|4|8 [4], "rows_per_tile" 2|4|8 [4], "lds_budget_kb[_up|_dw]" 8..144 [64], "threads_up|_dw"
- *   256|512|1024 [1024], "sort_mode" 0..2 [0], "sort_mode_dw" 0|1 [1], "wt_cols" 2|4|8|16 [4], "force_bits_up|_dw",
+ *   256|512|1024 [1024], "sort_mode" 0..2 [0], "sort_mode_dw" 0|1 [1], "wt_cols" 2|4|8|16 [4], "tile_bits_up|_dw" (force the block bits),
  *   "lds_min_kb_up|_dw".
  * Timing experiments only (results are wrong or partial when set): "passes" 1|2|3 [3], "debug" bit mask.
  * hxv_get_option additionally reports plan statistics ("tile_bits_up", "nblocks_up", "slots_in_up_x100", ...,
