@@ -380,6 +380,10 @@ int hxv_set_option(hxv_handle* h, const char* name, int64_t value) {
     h->plan.opt.debug = (int)value;
     return HXV_OK;
   }
+  if (!strcmp(name, "job_debug")) {
+    h->plan.opt.job_debug = (int)value;
+    return HXV_OK;
+  }
   if (!strcmp(name, "passes")) {
     if (value < 1 || value > 3) return fail(HXV_ERR_ARG, "passes must be 1, 2 or 3");
     h->plan.opt.passes = (int)value;
@@ -399,6 +403,10 @@ int hxv_set_option(hxv_handle* h, const char* name, int64_t value) {
   else if (!strcmp(name, "sort_mode")) o.sort_mode = (int)value;
   else if (!strcmp(name, "wt_cols")) o.wt_cols = (int)value;
   else if (!strcmp(name, "sort_mode_dw")) o.sort_mode_dw = (int)value;
+  else if (!strcmp(name, "job_up")) o.job_up = value ? 1 : 0;
+  else if (!strcmp(name, "job_cols")) o.job_cols = (int)value;
+  else if (!strcmp(name, "job_groups")) o.job_groups = (int)value;
+  else if (!strcmp(name, "job_stages")) o.job_stages = (int)value;
   else return fail(HXV_ERR_ARG, std::string("unknown option ") + name);
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -443,6 +451,14 @@ int64_t hxv_get_option(const hxv_handle* h, const char* name) {
   if (!strcmp(name, "max_block_dw")) return h->plan.dw.max_block;
   if (!strcmp(name, "nblocks_up")) return h->plan.up.nblocks;
   if (!strcmp(name, "nblocks_dw")) return h->plan.dw.nblocks;
+  if (!strcmp(name, "job_up")) return h->plan.opt.job_up;
+  if (!strcmp(name, "job_up_active"))
+    return (h->plan.opt.job_up && h->plan.opt.sort_mode == 0 && job_up_usable(h->dev, h->plan) &&
+            job_up_fits(h->dev, h->plan, false, std::max(h->plan.opt.job_cols, h->plan.opt.wt_cols)))
+               ? 1
+               : 0;
+  if (!strcmp(name, "max_outer_up")) return h->plan.up.max_outer;
+  if (!strcmp(name, "max_outer_dw")) return h->plan.dw.max_outer;
   return -1;
 }
 

@@ -1,0 +1,87 @@
+// Device-side pieces shared by the tiled kernels (hxv_tiled.hip) and the pipelined job kernels (hxv_jobs.hip).
+#pragma once
+#include "hxv_device.hpp"
+#include "hxv_tiles.hpp"
+
+namespace hxv {
+
+struct DevTiles {
+  const uint32_t* start;   // [nblocks+1]
+  const uint32_t* perm;    // [dim]   sorted position -> index
+  const uint32_t* gstart;  // [nblocks+1] first 64-position group of each block
+  const uint32_t* gmax;    // [groups] longest in-block list of each 64-position group (low 16 bits)
+  const uint32_t* ell_in;  // [k_in][dim]
+  const uint32_t* ell_out; // unused placeholder (the out-of-block part is bh/rs below)
+  const double2* scoef;    // [nscoef] signed coefficients, last = 0
+  const uint32_t* bh_ptr;  // block hops / row slots of the out-of-block part (hxv_tiles.hpp)
+  const uint32_t* bh;
+  const uint32_t* rs_ptr;
+  const uint32_t* rs_off;
+  const uint32_t* rs_tab;
+  int nblocks, nscoef;
+  int debug;  // timing experiments only: 1 skip out-of-block hops, 2 skip in-block hops, 4 skip the hv read-modify-write (pass B)
+};
+
+constexpr int HOP_CHUNK = 8;
+
+// Non-temporal (streaming) accesses.  Measured: SLOWER than plain ones for loads (pass A's wt read: +7 %) and for short
+// strided store segments (R*16-byte column segments of a natural-layout vector: they defeat L2 write combining, see
+// scripts/strided_bench.py); FASTER for long runs that are not read again soon: pass A's hv (-3 %) and pass B's blocked wt.
+typedef double dbl2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 load_stream(const double2* p) {
+  dbl2_t x = __builtin_nontemporal_load(reinterpret_cast<const dbl2_t*>(p));
+  return make_double2(x.x, x.y);
+}
+__device__ __forceinline__ void store_stream(double2* p, double2 a) {
+  dbl2_t x;
+  x.x = a.x;
+  x.y = a.y;
+  __builtin_nontemporal_store(x, reinterpret_cast<dbl2_t*>(p));
+}
+
+__device__ __forceinline__ void store_stream(double* p, double a) { __builtin_nontemporal_store(a, p); }
+
+constexpr uint32_t TILE_OFF_MASK = (1u << TILE_COEF_SHIFT) - 1u;
+
+// Vector element type VT: double2 (complex vectors, the reference's complex(8)) or double (REAL vectors: when H is real,
+// a real start vector keeps every Lanczos vector real -- half the bytes of every pass; device Lanczos only).
+template <typename VT>
+__device__ __forceinline__ VT vzero();
+template <>
+__device__ __forceinline__ double2 vzero<double2>() { return make_double2(0.0, 0.0); }
+template <>
+__device__ __forceinline__ double vzero<double>() { return 0.0; }
+__device__ __forceinline__ void vadd(double2& a, double2 b) { a.x += b.x; a.y += b.y; }
+__device__ __forceinline__ void vadd(double& a, double b) { a += b; }
+__device__ __forceinline__ void vscale(double2& a, double c) { a.x *= c; a.y *= c; }
+__device__ __forceinline__ void vscale(double& a, double c) { a *= c; }
+__device__ __forceinline__ double vdot(double2 a, double2 b) { return a.x * b.x + a.y * b.y; }
+__device__ __forceinline__ double vdot(double a, double b) { return a * b; }
+
+template <bool REAL>
+struct Coef;
+template <>
+struct Coef<true> {
+  using type = double;
+  static __device__ __forceinline__ void fma(double2& acc, double c, double2 x) {
+    acc.x = ::fma(c, x.x, acc.x);
+    acc.y = ::fma(c, x.y, acc.y);
+  }
+  static __device__ __forceinline__ void fma(double& acc, double c, double x) { acc = ::fma(c, x, acc); }
+  static __device__ __forceinline__ double from(double2 c) { return c.x; }
+};
+template <>
+struct Coef<false> {
+  using type = double2;
+  static __device__ __forceinline__ void fma(double2& acc, double2 c, double2 x) { cfma(acc, c, x); }
+  static __device__ __forceinline__ double2 from(double2 c) { return c; }
+};
+
+template <bool NORB1>
+__device__ __forceinline__ double diag_value(const DevDiag& dg, double au, uint32_t mu, int c) {
+  const uint32_t md = dg.map_dw[c];
+  if (NORB1) return au + dg.a_dw[c] + dg.cross.uloc[0] * (double)__popc(mu & md & dg.cross.orbmask[0]);
+  return au + dg.a_dw[c] + diag_cross(dg.cross, mu, md);
+}
+
+}  // namespace hxv

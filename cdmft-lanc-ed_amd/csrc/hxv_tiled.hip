@@ -14,89 +14,9 @@
 #include <numeric>
 #include <type_traits>
 
-#include "hxv_device.hpp"
-#include "hxv_tiles.hpp"
+#include "hxv_tile_dev.hpp"
 
 namespace hxv {
-
-struct DevTiles {
-  const uint32_t* start;   // [nblocks+1]
-  const uint32_t* perm;    // [dim]   sorted position -> index
-  const uint32_t* gstart;  // [nblocks+1] first 64-position group of each block
-  const uint32_t* gmax;    // [groups] longest in-block list of each 64-position group (low 16 bits)
-  const uint32_t* ell_in;  // [k_in][dim]
-  const uint32_t* ell_out; // unused placeholder (the out-of-block part is bh/rs below)
-  const double2* scoef;    // [nscoef] signed coefficients, last = 0
-  const uint32_t* bh_ptr;  // block hops / row slots of the out-of-block part (hxv_tiles.hpp)
-  const uint32_t* bh;
-  const uint32_t* rs_ptr;
-  const uint32_t* rs_off;
-  const uint32_t* rs_tab;
-  int nblocks, nscoef;
-  int debug;  // timing experiments only: 1 skip out-of-block hops, 2 skip in-block hops, 4 skip the hv read-modify-write (pass B)
-};
-
-constexpr int HOP_CHUNK = 8;
-
-// Non-temporal (streaming) accesses.  Measured: SLOWER than plain ones for loads (pass A's wt read: +7 %) and for short
-// strided store segments (R*16-byte column segments of a natural-layout vector: they defeat L2 write combining, see
-// scripts/strided_bench.py); FASTER for long runs that are not read again soon: pass A's hv (-3 %) and pass B's blocked wt.
-typedef double dbl2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ double2 load_stream(const double2* p) {
-  dbl2_t x = __builtin_nontemporal_load(reinterpret_cast<const dbl2_t*>(p));
-  return make_double2(x.x, x.y);
-}
-__device__ __forceinline__ void store_stream(double2* p, double2 a) {
-  dbl2_t x;
-  x.x = a.x;
-  x.y = a.y;
-  __builtin_nontemporal_store(x, reinterpret_cast<dbl2_t*>(p));
-}
-
-__device__ __forceinline__ void store_stream(double* p, double a) { __builtin_nontemporal_store(a, p); }
-
-constexpr uint32_t TILE_OFF_MASK = (1u << TILE_COEF_SHIFT) - 1u;
-
-// Vector element type VT: double2 (complex vectors, the reference's complex(8)) or double (REAL vectors: when H is real,
-// a real start vector keeps every Lanczos vector real -- half the bytes of every pass; device Lanczos only).
-template <typename VT>
-__device__ __forceinline__ VT vzero();
-template <>
-__device__ __forceinline__ double2 vzero<double2>() { return make_double2(0.0, 0.0); }
-template <>
-__device__ __forceinline__ double vzero<double>() { return 0.0; }
-__device__ __forceinline__ void vadd(double2& a, double2 b) { a.x += b.x; a.y += b.y; }
-__device__ __forceinline__ void vadd(double& a, double b) { a += b; }
-__device__ __forceinline__ void vscale(double2& a, double c) { a.x *= c; a.y *= c; }
-__device__ __forceinline__ void vscale(double& a, double c) { a *= c; }
-__device__ __forceinline__ double vdot(double2 a, double2 b) { return a.x * b.x + a.y * b.y; }
-__device__ __forceinline__ double vdot(double a, double b) { return a * b; }
-
-template <bool REAL>
-struct Coef;
-template <>
-struct Coef<true> {
-  using type = double;
-  static __device__ __forceinline__ void fma(double2& acc, double c, double2 x) {
-    acc.x = ::fma(c, x.x, acc.x);
-    acc.y = ::fma(c, x.y, acc.y);
-  }
-  static __device__ __forceinline__ void fma(double& acc, double c, double x) { acc = ::fma(c, x, acc); }
-  static __device__ __forceinline__ double from(double2 c) { return c.x; }
-};
-template <>
-struct Coef<false> {
-  using type = double2;
-  static __device__ __forceinline__ void fma(double2& acc, double2 c, double2 x) { cfma(acc, c, x); }
-  static __device__ __forceinline__ double2 from(double2 c) { return c; }
-};
-
-template <bool NORB1>
-__device__ __forceinline__ double diag_value(const DevDiag& dg, double au, uint32_t mu, int c) {
-  const uint32_t md = dg.map_dw[c];
-  if (NORB1) return au + dg.a_dw[c] + dg.cross.uloc[0] * (double)__popc(mu & md & dg.cross.orbmask[0]);
-  return au + dg.a_dw[c] + diag_cross(dg.cross, mu, md);
-}
 
 // ---------------------------------------------------------------------------------------
 // pass A
@@ -450,7 +370,7 @@ int choose_lowbits(int ns, int npart, int width, int budget_bytes, int max_block
 
 struct HostTiles {
   std::vector<uint32_t> start, perm, gstart, gmax, ell_in, ell_out;
-  std::vector<uint32_t> bh_ptr, bh, rs_ptr, rs_off, rs_tab;
+  std::vector<uint32_t> bh_ptr, bh, rs_ptr, rs_off, rs_tab, order;
 };
 
 // sorted_out: outer table indexed by sorted position (pass A) or by natural index (pass B)
@@ -491,6 +411,7 @@ void build_spin_tiles(const SpinOp& op, const std::vector<uint32_t>& map, int lo
   auto pad4 = [](int k) { return std::max(HOP_CHUNK, (k + HOP_CHUNK - 1) / HOP_CHUNK * HOP_CHUNK); };
   // one extra all-empty chunk on the natural-order outer table terminates its "all lanes empty" loop
   t.k_in = pad4(kin);
+  t.k_in_real = kin;
   t.k_out = pad4(kout) + (sorted_out ? 0 : HOP_CHUNK);
   // visiting order inside each block
   h.perm.resize(dim);
@@ -617,6 +538,13 @@ void build_spin_tiles(const SpinOp& op, const std::vector<uint32_t>& map, int lo
   if (h.rs_tab.empty()) h.rs_tab.assign(1, emptyz);
   t.bh_per_row = bh_rows / dim;
   t.rs_per_row = rs_rows / dim;
+  t.max_outer = 0;
+  for (int k = 0; k < t.nblocks; ++k)
+    t.max_outer = std::max<int>(t.max_outer, (int)(h.bh_ptr[k + 1] - h.bh_ptr[k]) + (int)(h.rs_ptr[k + 1] - h.rs_ptr[k]));
+  h.order.resize(t.nblocks);
+  std::iota(h.order.begin(), h.order.end(), 0u);
+  std::stable_sort(h.order.begin(), h.order.end(),
+                   [&](uint32_t a, uint32_t b) { return h.start[a + 1] - h.start[a] > h.start[b + 1] - h.start[b]; });
 }
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel and size, not per launch (small sectors are launch-bound)
@@ -709,6 +637,9 @@ std::string make_tile_plan(const SectorHost& s, TilePlan& plan, const PlanUpload
     if (th != 256 && th != 512 && th != 1024) return "threads must be 256, 512 or 1024";
   if (o.sort_mode < 0 || o.sort_mode > 2) return "sort_mode must be 0, 1 or 2";
   if (o.wt_cols != 2 && o.wt_cols != 4 && o.wt_cols != 8 && o.wt_cols != 16) return "wt_cols must be 2, 4, 8 or 16";
+  if (o.job_cols != 1 && o.job_cols != 2) return "job_cols must be 1 or 2";
+  if (o.job_groups < 1 || o.job_groups > 65536) return "job_groups must be in [1,65536]";
+  if (o.job_stages < 2 || o.job_stages > 8) return "job_stages must be in [2,8]";
   plan.ncoef_up = (int)s.up.coef.size();
   plan.ncoef_dw = (int)s.dw.coef.size();
   plan.usable = plan.ncoef_up <= TILE_MAX_COEF && plan.ncoef_dw <= TILE_MAX_COEF;
@@ -727,7 +658,7 @@ std::string make_tile_plan(const SectorHost& s, TilePlan& plan, const PlanUpload
         up.u32(h.ell_in, &t.d_ell_in) != hipSuccess || up.u32(h.ell_out, &t.d_ell_out) != hipSuccess ||
         up.u32(h.bh_ptr, &t.d_bh_ptr) != hipSuccess || up.u32(h.bh, &t.d_bh) != hipSuccess ||
         up.u32(h.rs_ptr, &t.d_rs_ptr) != hipSuccess || up.u32(h.rs_off, &t.d_rs_off) != hipSuccess ||
-        up.u32(h.rs_tab, &t.d_rs_tab) != hipSuccess)
+        up.u32(h.rs_tab, &t.d_rs_tab) != hipSuccess || up.u32(h.order, &t.d_order) != hipSuccess)
       return "upload of tile tables failed";
     return "";
   };
@@ -754,7 +685,17 @@ static int real_cols(const TilePlan& plan) { return std::min(8, 2 * plan.opt.col
 static int real_rows(const TilePlan& plan) { return std::min(8, 2 * plan.opt.rows_per_tile); }
 static int real_wc(const TilePlan& plan) { return std::max(real_cols(plan), std::min(16, 2 * plan.opt.wt_cols)); }
 
+// Pass A runs as jobs (hxv_jobs.hip) when the plan allows it and the tile ring fits the LDS; wc_out = scratch group width.
+static bool use_job_up(const DevSector& s, const TilePlan& plan, bool real_vec, bool lz, bool wt_natural, int* wc_out = nullptr) {
+  if (real_vec || !plan.opt.job_up || plan.opt.sort_mode != 0 || plan.opt.debug != 0 || !job_up_usable(s, plan)) return false;
+  const int wc = wt_natural ? 0 : std::max(plan.opt.job_cols, plan.opt.wt_cols);
+  if (!job_up_fits(s, plan, lz, wc)) return false;
+  if (wc_out) *wc_out = wc;
+  return true;
+}
+
 int64_t tiled_pass_up_workgroups(const DevSector& s, const TilePlan& plan, bool real_vec) {
+  if (use_job_up(s, plan, real_vec, true, false)) return job_up_workgroups(s, plan);
   const int C = real_vec ? real_cols(plan) : plan.opt.cols_per_tile;
   const int ngroups = (s.qdw + C - 1) / C;
   return (int64_t)((ngroups + 7) / 8) * 8 * plan.up.nblocks;
@@ -772,8 +713,11 @@ static hipError_t launch_tiled_vt(const DevSector& s, const TilePlan& plan, cons
               plan.dw.nblocks, 2 * plan.ncoef_dw + 1, plan.opt.debug};
   const int C = RV ? real_cols(plan) : plan.opt.cols_per_tile, R = RV ? real_rows(plan) : plan.opt.rows_per_tile;
   // columns per group of the wt scratch; 0 = natural layout
-  const int wc = wt_natural ? 0 : (RV ? real_wc(plan) : std::max(C, plan.opt.wt_cols));
   const int passes = only_pass ? only_pass : plan.opt.passes;
+  // (with the job kernels pass A's tile width no longer constrains the scratch layout)
+  int wc = wt_natural ? 0 : (RV ? real_wc(plan) : std::max(C, plan.opt.wt_cols));
+  bool job_a = false;
+  if constexpr (!RV) job_a = (passes & 1) && use_job_up(s, plan, false, lz != nullptr, wt_natural, &wc);
   constexpr int SLOTS = 256 / (int)sizeof(VT);
   const int lds_a = std::max(plan.up.max_block * C * (int)sizeof(VT) + tu.nscoef * 16, plan.opt.lds_min_kb_up * 1024);
   const int lds_b = std::max((((plan.dw.max_block + SLOTS - 1) & ~(SLOTS - 1)) + SLOTS / R) * R * (int)sizeof(VT) + td.nscoef * 16,
@@ -788,6 +732,9 @@ static hipError_t launch_tiled_vt(const DevSector& s, const TilePlan& plan, cons
     }
   if (e != hipSuccess) return e;
   const VT* wta = ((passes & 2) || only_pass == 1) ? wt : nullptr;
+  if constexpr (!RV) {
+    if (job_a) return launch_up_job(s, plan, tu, wc, v, wta, hv, lz, st);
+  }
   if (passes & 1) switch (C) {
       case 2: e = launch_up<2, VT>(s, tu, lds_a, ta, norb1, wc, v, wta, hv, lz, st); break;
       case 4: e = launch_up<4, VT>(s, tu, lds_a, ta, norb1, wc, v, wta, hv, lz, st); break;

@@ -24,6 +24,7 @@ struct SpinTiles {
   int nblocks = 0;
   int max_block = 0;
   int k_in = 0, k_out = 0;
+  int k_in_real = 0;                 // longest in-block list of any row (k_in is this rounded up to the fetch chunk)
   int64_t n_in = 0, n_out = 0;       // entry counts (statistics)
   double slots_in = 0, slots_out = 0;  // processed slots per row after sorting (statistics)
   std::vector<uint32_t> start;       // [nblocks+1]
@@ -43,6 +44,8 @@ struct SpinTiles {
   uint32_t* d_rs_off = nullptr;      // [nslots] offset of each slot's table in d_rs_tab
   uint32_t* d_rs_tab = nullptr;      // flat tables, |block| words per slot
   double bh_per_row = 0, rs_per_row = 0;  // statistics: block hops / row slots visited per row
+  int max_outer = 0;                 // most (row slots + block hops) of any block (register tables of the job kernels)
+  uint32_t* d_order = nullptr;       // [nblocks] block indices, largest block first (job order inside a chunk)
 };
 
 struct TileOptions {
@@ -56,6 +59,12 @@ struct TileOptions {
   int sort_mode_dw = 1;  // pass B inner phase (LDS only): 0 natural, 1 by inner count
   int lds_min_kb_up = 0, lds_min_kb_dw = 0;  // request at least this much LDS per workgroup (limits workgroups per CU)
   int wt_cols = 4;  // columns per group of the blocked dw-hop scratch (>= cols_per_tile): R*wt_cols*16-byte write runs in pass B
+  // pipelined job kernels (hxv_jobs.hip)
+  int job_up = 1;      // pass A as jobs (block x run of column groups) with an LDS-DMA tile ring; 0 = one tile per workgroup
+  int job_cols = 1;    // columns per tile of a pass-A job (1 or 2)
+  int job_groups = 50; // column groups per job
+  int job_stages = 4;  // depth of the LDS tile ring (clamped to what fits 160 KB)
+  int job_debug = 0;   // timing experiments only (JobUp::debug); results are wrong when non-zero
   int debug = 0;   // timing experiments only (see DevTiles::debug); results are wrong when non-zero
   int passes = 3;     // bit 0: pass A (diag + up hops), bit 1: pass B (dw hops); timing experiments only
 };
@@ -78,6 +87,7 @@ struct LzEpilogue {
   int i_s = 0, i_c = 0;
   double* partial = nullptr;    // one partial sum per workgroup of pass A
 };
+// workgroups of pass A (= partial sums of the Lanczos epilogue) for the product launch_hxv_tiled would run with an epilogue
 int64_t tiled_pass_up_workgroups(const DevSector& s, const TilePlan& plan, bool real_vec = false);
 int64_t tiled_wt_elems(const DevSector& s, const TilePlan& plan);
 
@@ -86,6 +96,13 @@ struct PlanUploader {
   std::function<hipError_t(const std::vector<double2>&, double2**)> d2;
 };
 std::string make_tile_plan(const SectorHost& s, TilePlan& plan, const PlanUploader& up);
+// job kernels (hxv_jobs.hip)
+struct DevTiles;
+bool job_up_usable(const DevSector& s, const TilePlan& plan);
+int64_t job_up_workgroups(const DevSector& s, const TilePlan& plan);
+bool job_up_fits(const DevSector& s, const TilePlan& plan, bool lz, int wc);
+hipError_t launch_up_job(const DevSector& s, const TilePlan& plan, const DevTiles& tu, int wc, const double2* v, const double2* wt, double2* hv,
+                         const LzEpilogue* lz, hipStream_t st);
 hipError_t launch_hxv_tiled(const DevSector& s, const TilePlan& plan, const double2* v_full, double2* wt_scratch, double2* hv_local,
                             hipStream_t st, const LzEpilogue* lz = nullptr, int only_pass = 0, bool wt_natural = false);
 // Same product on REAL vectors (double elements; H must be real, nranks == 1): s.pitch = real pitch (multiple of 16).

@@ -1,0 +1,17 @@
+"""Target of rocprofv3 runs: apply an option set ("k=v,k=v") to the C3 sector (WORKLOAD env: C2..C5) and run nrep products."""
+import os, sys
+sys.path.insert(0, "/root/repo/cdmft-lanc-ed_amd")
+import torch, hxv
+from hxv import models
+wl = os.environ.get("WORKLOAD", "C3")
+m, (nup, ndw) = {"C2": (models.hm_1dchain(), (6, 6)), "C3": (models.hm_2dsquare(Nbath=3), (8, 8)),
+                 "C4": (models.bhz_2d(Nbath=1), (8, 8)), "C5": (models.hm_ring(6, 2), (9, 9))}[wl]
+sec = hxv.HxvSector.from_model(m, nup, ndw)
+for kv in (sys.argv[1] if len(sys.argv) > 1 else "").split(","):
+    if kv:
+        k, val = kv.split("="); sec.set_option(k, int(val))
+nrep = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+v = torch.randn(sec.fullElems, dtype=torch.float64, device="cuda") + 1j * torch.randn(sec.fullElems, dtype=torch.float64, device="cuda")
+hv = torch.empty_like(v)
+torch.cuda.synchronize()
+print("ms", sec.time_apply(v, hv, nrep))
