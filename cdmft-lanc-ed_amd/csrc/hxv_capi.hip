@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "hxv_internal.hpp"
@@ -190,7 +191,10 @@ int hxv_create_from_csr(int32_t dimup, int32_t dimdw, const int64_t* up_rowptr, 
 int hxv_destroy(hxv_handle* h) {
   if (!h) return HXV_OK;
   (void)hipSetDevice(h->device);
-  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  // kernels of this handle may still run on a CALLER's stream (hxv_apply_device & co. take one) and use the buffers
+  // below; the cache would hand them to the next handle at once (hipFree used to synchronise implicitly)
+  (void)hipDeviceSynchronize();
+  comm_release(h);
   for (void* p : h->allocs) (void)hipFree(p);
   pool_free(h->device, h->d_stage_v);
   pool_free(h->device, h->d_stage_hv);
@@ -280,13 +284,16 @@ int hxv_apply_up_add(hxv_handle* h, const void* d_v_local, const void* d_w, void
 
 int hxv_apply_host(hxv_handle* h, int64_t nloc, const void* v, void* hv) {
   if (!h || !v || !hv) return fail(HXV_ERR_ARG, "hxv_apply_host: NULL argument");
-  if (h->host.nranks != 1)
-    return fail(HXV_ERR_STATE, "hxv_apply_host needs nranks==1; a split sector exchanges slabs first (hxv_apply_device)");
-  if (nloc != h->host.dim) return fail(HXV_ERR_ARG, "hxv_apply_host: Nloc != Dim of the open sector");
+  if (h->host.panel_rows > 0) return fail(HXV_ERR_STATE, "hxv_apply_host: panel handles only do hxv_apply_dw_panel");
+  if (h->host.nranks != 1 && !comm_ready(h))
+    return fail(HXV_ERR_STATE, "hxv_apply_host on a split sector needs the slab exchange: call hxv_comm_init after opening the sector "
+                               "(or gather the vector yourself and use hxv_apply_device)");
+  // v, hv: this rank's slab, vecDim_Hv_sector = DimUp*mpiQdw elements (spMatVec_MPI_main, ED_HAMILTONIAN_SPARSE_HxV.f90:230-315)
+  if (nloc != (int64_t)h->host.qdw * h->host.dimup) return fail(HXV_ERR_ARG, "hxv_apply_host: Nloc != vecDim of the open sector");
   HIPCHK(hipSetDevice(h->device));
   // host arrays are in the reference's contiguous layout; the device layout pads every column to `pitch`
   const size_t col = (size_t)h->host.dimup * sizeof(double2), pit = (size_t)h->host.pitch * sizeof(double2);
-  const size_t bytes = pit * (size_t)h->host.dimdw;
+  const size_t bytes = pit * (size_t)std::max(h->host.qdw, 1);
   if (!h->d_stage_v) {
     HIPCHK(pool_alloc(h->device, bytes, (void**)&h->d_stage_v));
     HIPCHK(pool_alloc(h->device, bytes, (void**)&h->d_stage_hv));
@@ -294,10 +301,10 @@ int hxv_apply_host(hxv_handle* h, int64_t nloc, const void* v, void* hv) {
     HIPCHK(hipMemset(h->d_stage_hv, 0, bytes));
     h->device_bytes += 2 * (int64_t)bytes;
   }
-  HIPCHK(hipMemcpy2DAsync(h->d_stage_v, pit, v, col, col, (size_t)h->host.dimdw, hipMemcpyHostToDevice, h->stream));
-  int rc = hxv_apply_device(h, h->d_stage_v, h->d_stage_hv, h->stream);
+  if (h->host.qdw > 0) HIPCHK(hipMemcpy2DAsync(h->d_stage_v, pit, v, col, col, (size_t)h->host.qdw, hipMemcpyHostToDevice, h->stream));
+  int rc = apply_slab(h, h->d_stage_v, h->d_stage_hv, h->stream);
   if (rc) return rc;
-  HIPCHK(hipMemcpy2DAsync(hv, col, h->d_stage_hv, pit, col, (size_t)h->host.dimdw, hipMemcpyDeviceToHost, h->stream));
+  if (h->host.qdw > 0) HIPCHK(hipMemcpy2DAsync(hv, col, h->d_stage_hv, pit, col, (size_t)h->host.qdw, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return HXV_OK;
 }
@@ -354,6 +361,12 @@ int hxv_get_diag(const hxv_handle* h, double* diag) {
 
 int hxv_set_option(hxv_handle* h, const char* name, int64_t value) {
   if (!h || !name) return fail(HXV_ERR_ARG, "hxv_set_option: NULL");
+  // timing experiments (results are wrong or partial when set): only with HXV_EXPERIMENTS=1 in the environment
+  if (!strcmp(name, "debug") || !strcmp(name, "passes") || !strcmp(name, "job_debug")) {
+    const char* ex = getenv("HXV_EXPERIMENTS");
+    if (!(ex && ex[0] == '1') && value != (!strcmp(name, "passes") ? 3 : 0))
+      return fail(HXV_ERR_ARG, std::string("option ") + name + " is a timing experiment that gives wrong results; set HXV_EXPERIMENTS=1 to enable it");
+  }
   if (!strcmp(name, "kernel")) {
     if (value < 0 || value > 1) return fail(HXV_ERR_ARG, "kernel must be 0 or 1");
     h->kernel = (int)value;
@@ -478,20 +491,3 @@ int hxv_get_stats(const hxv_handle* h, hxv_stats* out) {
 
 }  // extern "C"
 
-namespace hxv {
-hipError_t launch_strided_read(const double2* v, double2* out, int dimup, int ncols, int R, int n, int mode, hipStream_t st);
-}
-extern "C" int hxv_debug_strided_read(hxv_handle* h, const void* d_v, void* d_out, int32_t R, int32_t n, int32_t mode, int32_t nrep, float* ms) {
-  // micro-benchmark helper (scripts/ only; not declared in include/hxv.h)
-  if (!h || !d_v || !d_out || !ms) return 1;
-  (void)hipSetDevice(h->device);
-  (void)hipEventRecord(h->ev0, h->stream);
-  for (int i = 0; i < nrep; ++i)
-    if (launch_strided_read((const double2*)d_v, (double2*)d_out, h->host.pitch, h->host.dimdw, R, n, mode, h->stream) != hipSuccess) return 2;
-  (void)hipEventRecord(h->ev1, h->stream);
-  (void)hipEventSynchronize(h->ev1);
-  float t = 0;
-  (void)hipEventElapsedTime(&t, h->ev0, h->ev1);
-  *ms = t / nrep;
-  return 0;
-}

@@ -128,10 +128,11 @@ __global__ void __launch_bounds__(256) tr_scale_nrm(int64_t n, double2* __restri
 }
 
 // deterministic start vector (same hash as the single-vector Lanczos in hxv_lanczos.hip): pad rows stay zero
-__global__ void __launch_bounds__(256) tr_init(int64_t n, double2* __restrict__ q, uint64_t seed, int dimup, int pitch) {
+__global__ void __launch_bounds__(256) tr_init(int64_t n, double2* __restrict__ q, uint64_t seed, int dimup, int pitch, int col0) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const int64_t col = i / pitch;
-    const int row = (int)(i - col * pitch);
+    const int64_t lcol = i / pitch;
+    const int row = (int)(i - lcol * pitch);
+    const int64_t col = lcol + col0;  // global column: a split sector starts from the same vector as the unsplit one
     if (row >= dimup) {
       q[i] = make_double2(0.0, 0.0);
       continue;
@@ -267,8 +268,8 @@ extern "C" {
 int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxrestart, double tol, double* evals, void* d_evecs,
                     int32_t* nconv_out, int32_t* nmatvec_out) {
   if (!h || !evals || neigen < 1 || maxrestart < 0) return fail(HXV_ERR_ARG, "hxv_eigh_lowest: bad argument");
-  if (h->host.nranks != 1)
-    return fail(HXV_ERR_STATE, "hxv_eigh_lowest needs nranks==1 (global dots belong to the caller's communicator)");
+  if (h->host.nranks != 1 && !comm_ready(h))
+    return fail(HXV_ERR_STATE, "hxv_eigh_lowest on a split sector needs the communicator: call hxv_comm_init after opening the sector");
   const int64_t dim = h->host.dim;
   if (neigen > dim) return fail(HXV_ERR_ARG, "hxv_eigh_lowest: neigen > Dim");
   if (ncv <= 0) ncv = 10 * neigen;  // the reference's default: lanc_ncv_factor=10, lanc_ncv_add=0 (ED_INPUT_VARS.f90:174-175)
@@ -279,7 +280,7 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
   // is elementwise with real coefficients, so it runs unchanged on the vectors viewed as n double2 elements.
   const bool real = h->real_vectors && !real_mode_blocker(h);
   h->last_real = real ? 1 : 0;
-  const int64_t nc = (int64_t)h->host.pitch * h->host.dimdw;  // padded complex vector (pads are zero and stay zero)
+  const int64_t nc = (int64_t)h->host.pitch * h->host.qdw;  // this rank's padded complex slab (pads are zero and stay zero)
   const int64_t n = real ? (int64_t)pitch_real_of(h) * h->host.dimdw / 2 : nc;
   const int g = (int)std::min<int64_t>((n + 255) / 256, TR_BLOCKS);
   const double eps = 2.220446049250313e-16, eps23 = std::pow(eps, 2.0 / 3.0);
@@ -287,6 +288,11 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
 
   size_t free_b = 0, total_b = 0;
   HIPCHK(hipMemGetInfo(&free_b, &total_b));
+  {  // blocks held by the engine's own device-buffer cache are available to pool_alloc (reused or trimmed on OOM)
+    int64_t cached = 0;
+    (void)hxv_pool_stats(h->device, &cached, nullptr, nullptr);
+    free_b += (size_t)std::max<int64_t>(cached, 0);
+  }
   const size_t need = (size_t)(m + 1) * (size_t)n * sizeof(double2);
   if (need + ((size_t)n * sizeof(double2)) > free_b)
     return fail(HXV_ERR_HIP, "hxv_eigh_lowest: the Krylov basis needs " + std::to_string(need >> 20) + " MiB of HBM for ncv=" + std::to_string(m) +
@@ -319,10 +325,11 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
   if (real)
     launch_init_real(h, (double*)vec(0), (uint64_t)0x5EED5EEDull, st);
   else
-    hipLaunchKernelGGL(tr_init, dim3(g), dim3(256), 0, st, n, vec(0), (uint64_t)0x5EED5EEDull, h->host.dimup, h->host.pitch);
+    hipLaunchKernelGGL(tr_init, dim3(g), dim3(256), 0, st, n, vec(0), (uint64_t)0x5EED5EEDull, h->host.dimup, h->host.pitch, h->host.dw0);
   double nrm2 = 0.0;
   hipLaunchKernelGGL(tr_scale_nrm, dim3(g), dim3(256), 0, st, n, vec(0), 1.0, d_npart);
   hipLaunchKernelGGL(tr_colsum, dim3(1), dim3(256), 0, st, d_npart, g, 1, 1, d_nrm, 0);
+  if (int rca = comm_allreduce_sum(h, d_nrm, 1, st)) return rca;  // split sector: projections and norms are sums over the ranks
   HIPCHK(hipMemcpyAsync(&nrm2, d_nrm, sizeof(double), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   hipLaunchKernelGGL(tr_scale_nrm, dim3(g), dim3(256), 0, st, n, vec(0), 1.0 / std::sqrt(nrm2), (double*)nullptr);
@@ -342,6 +349,7 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
       hipLaunchKernelGGL(tr_mdot, dim3(g), dim3(256), 0, st, n, vec(g0), n, nb, vec(j + 1), d_part);
       hipLaunchKernelGGL(tr_colsum, dim3(1), dim3(256), 0, st, d_part, g, 2 * JB, 2 * nb, d_coef + 2 * g0, real ? 1 : 0);
     }
+    if (int rca = comm_allreduce_sum(h, d_coef, (size_t)2 * nj, st)) return rca;
     HIPCHK(hipMemcpyAsync(c.data(), d_coef, (size_t)2 * nj * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     double ssum = 0.0;
@@ -359,6 +367,7 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
     HIPCHK(hipMemcpyAsync(d_isel, isel.data(), (size_t)nsel * sizeof(int), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(tr_maxpy, dim3(g), dim3(256), 0, st, n, V, n, nsel, d_isel, d_csel, vec(j + 1), d_npart);
     hipLaunchKernelGGL(tr_colsum, dim3(1), dim3(256), 0, st, d_npart, g, 1, 1, d_nrm, 0);
+    if (int rca = comm_allreduce_sum(h, d_nrm, 1, st)) return rca;
     HIPCHK(hipMemcpyAsync(nrm2_after, d_nrm, sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     return HXV_OK;
@@ -372,7 +381,7 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
     meff = m;
     beta_last = 0.0;
     for (int j = k; j < m; ++j) {
-      int rc = real ? hxv_apply_device_real(h, vec(j), vec(j + 1), st) : hxv_apply_device(h, vec(j), vec(j + 1), st);
+      int rc = real ? hxv_apply_device_real(h, vec(j), vec(j + 1), st) : apply_slab(h, vec(j), vec(j + 1), st);
       if (rc) return rc;
       ++nmv;
       double w2 = 0.0;
@@ -451,7 +460,8 @@ int hxv_eigh_lowest_host(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t max
   if (!h || neigen < 1) return fail(HXV_ERR_ARG, "hxv_eigh_lowest_host: bad argument");
   if (!evecs_host) return hxv_eigh_lowest(h, neigen, ncv, maxrestart, tol, evals, nullptr, nconv_out, nmatvec_out);
   HIPCHK(hipSetDevice(h->device));
-  const int64_t n = (int64_t)h->host.pitch * h->host.dimdw;
+  const int64_t n = (int64_t)h->host.pitch * h->host.qdw;
+  const int64_t vecdim = (int64_t)h->host.dimup * h->host.qdw;  // eig_basis(vecDim, Neigen): this rank's slab of every vector
   DevFree mem;
   double2* d = nullptr;
   mem.device = h->device;
@@ -462,8 +472,9 @@ int hxv_eigh_lowest_host(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t max
   // eig_basis(vecDim, Neigen) in the reference's layout: columns unpadded, eigenvectors consecutive (ED_DIAG.f90:145)
   const size_t col = (size_t)h->host.dimup * sizeof(double2), pit = (size_t)h->host.pitch * sizeof(double2);
   for (int i = 0; i < neigen; ++i)
-    HIPCHK(hipMemcpy2DAsync((char*)evecs_host + (size_t)i * h->host.dim * sizeof(double2), col, d + (int64_t)i * n, pit, col,
-                            (size_t)h->host.dimdw, hipMemcpyDeviceToHost, h->stream));
+    if (h->host.qdw > 0)
+      HIPCHK(hipMemcpy2DAsync((char*)evecs_host + (size_t)i * vecdim * sizeof(double2), col, d + (int64_t)i * n, pit, col,
+                              (size_t)h->host.qdw, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return HXV_OK;
 }

@@ -2,6 +2,7 @@
 // that implement the C-ABI (hxv_capi.hip: handles + products; hxv_lanczos.hip: Lanczos recurrences; hxv_eigh.hip: thick-restart eigensolver).
 #pragma once
 #include <algorithm>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -16,6 +17,11 @@ constexpr int RED_BLOCKS = 1024;             // workgroups of the grid-stride re
 hipError_t pool_alloc(int device, size_t bytes, void** out);
 void pool_free(int device, void* ptr);
 int ensure_wt(hxv_handle* h);                // (re)allocates the dw-hop scratch of the tiled kernels (hxv_capi.hip)
+// slab exchange of a split sector (hxv_comm.cpp)
+bool comm_ready(const hxv_handle* h);
+int comm_allreduce_sum(hxv_handle* h, double* d_buf, size_t count, hipStream_t st);  // no-op without a communicator
+int apply_slab(hxv_handle* h, const double2* d_v_local, double2* d_hv_local, hipStream_t st);
+void comm_release(hxv_handle* h);
 // REAL-vector mode helpers shared by the Lanczos drivers (hxv_capi.hip / hxv_lanczos.hip)
 const char* real_mode_blocker(const hxv_handle* h);  // nullptr when real vectors can be used with this handle
 int pitch_real_of(const hxv_handle* h);
@@ -57,6 +63,10 @@ struct hxv_handle {
   int lz_buf_mode = 0;             // layout the d_lz work vectors were last used in (0 complex, 1 real): the pad rows differ
   int last_real = 0;               // did the last device Lanczos run use real vectors (get_option "lanczos_real_last")
   int kernel = 1;
+  // split sector: RCCL communicator over the nranks handles (hxv_comm_init) and the gathered vector
+  void* comm = nullptr;          // ncclComm_t
+  double2* d_gather = nullptr;   // nranks * cmax * pitch elements (all-gather layout)
+  int64_t n_exchange = 0;
   int64_t n_apply = 0;
   int64_t device_bytes = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;

@@ -113,10 +113,12 @@ __global__ void __launch_bounds__(256) lz_axpy(int64_t n, double2* __restrict__ 
 }
 
 // deterministic start vector: splitmix64 hash of the global index -> uniform(-0.5,0.5) re and im
-__global__ void __launch_bounds__(256) lz_init(int64_t n, double2* __restrict__ q, uint64_t seed, int dimup, int pitch) {
+// (col0 = first global column of this rank's slab: a split sector starts from the same global vector as the unsplit one)
+__global__ void __launch_bounds__(256) lz_init(int64_t n, double2* __restrict__ q, uint64_t seed, int dimup, int pitch, int col0) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t col = i / pitch;
-    const int row = (int)(i - col * pitch);
+    const int64_t lcol = i / pitch;
+    const int row = (int)(i - lcol * pitch);
+    const int64_t col = lcol + col0;
     if (row >= dimup) {  // pad rows stay zero: they must not enter the dot products
       q[i] = make_double2(0.0, 0.0);
       continue;
@@ -251,6 +253,20 @@ struct LzBuf {
 
 // scal[i] = scal[a] * scal[b]
 __global__ void lz_mul(double* scal, int i, int a, int b) { scal[i] = scal[a] * scal[b]; }
+// scal[i] = sqrt(scal[i])   (split sector: the square root comes after the all-reduce of the partial sums of squares)
+__global__ void lz_sqrt(double* scal, int i) { scal[i] = sqrt(scal[i]); }
+
+// sum (op 0) or 2-norm (op 1) of the per-workgroup partials into scal[io]; on a split sector the sums of all ranks are added
+int reduce_scalar(hxv_handle* h, const double* partial, int np, int io, int op) {
+  const bool dist = comm_ready(h);
+  hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, partial, np, h->d_scalars, io, dist ? 0 : op);
+  if (dist) {
+    int rc = comm_allreduce_sum(h, h->d_scalars + io, 1, h->stream);
+    if (rc) return rc;
+    if (op) hipLaunchKernelGGL(lz_sqrt, dim3(1), dim3(1), 0, h->stream, h->d_scalars, io);
+  }
+  return HXV_OK;
+}
 
 // End of one fused iteration without the host: record alpha_k = scal[0], beta_{k+1} = scal[1] at the device-side step
 // counter scal[6], and prepare the next iteration's scalars  s = 1/beta_{k+1} (scal[2]),  c = s_old/s = beta_{k+1}/beta_k (scal[3]).
@@ -285,8 +301,9 @@ struct LzRunner {
 
   LzRunner(hxv_handle* hh, double2* x, double2* xm, double2* w, bool real_vec = false) : h(hh), b{x, xm, w}, real(real_vec) {
     fused = hh->kernel == 1 && hh->plan.usable && !hh->dev.nd.active && hh->plan.opt.passes == 3 && hh->plan.opt.debug == 0 &&
-            hh->host.nranks == 1 && hh->lz_fused;
-    n2 = real ? (int64_t)pitch_real_of(hh) * hh->host.dimdw / 2 : (int64_t)hh->host.pitch * hh->host.dimdw;
+            hh->host.nranks == 1 && !comm_ready(hh) && hh->lz_fused;
+    // (local slab: qdw == DimDw on an unsplit sector)
+    n2 = real ? (int64_t)pitch_real_of(hh) * hh->host.dimdw / 2 : (int64_t)hh->host.pitch * hh->host.qdw;
     hh->last_real = real ? 1 : 0;
   }
 
@@ -303,12 +320,15 @@ struct LzRunner {
     const int64_t n = n2;
     const int g = grid_for(n);
     if (!fused) {
-      int rc = real ? hxv_apply_device_real(h, b.q, b.w, h->stream) : hxv_apply_device(h, b.q, b.w, h->stream);
+      // (apply_slab = exchange + product on a split sector, the plain product otherwise)
+      int rc = real ? hxv_apply_device_real(h, b.q, b.w, h->stream) : apply_slab(h, b.q, b.w, h->stream);
       if (rc) return rc;
       hipLaunchKernelGGL(lz_sub_dot, dim3(g), dim3(256), 0, h->stream, n, b.w, b.qm, b.q, h->d_scalars, first ? -1 : 2, h->d_partials);
-      hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_partials, g, h->d_scalars, 0, 0);
+      rc = reduce_scalar(h, h->d_partials, g, 0, 0);
+      if (rc) return rc;
       hipLaunchKernelGGL(lz_sub_nrm, dim3(g), dim3(256), 0, h->stream, n, b.w, b.q, h->d_scalars, 0, h->d_partials + RED_BLOCKS);
-      hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_partials + RED_BLOCKS, g, h->d_scalars, 1, 1);
+      rc = reduce_scalar(h, h->d_partials + RED_BLOCKS, g, 1, 1);
+      if (rc) return rc;
     } else {
       const int64_t nwg = tiled_pass_up_workgroups(h->dev, h->plan, real);
       if (nwg > h->lz_partial_n) {
@@ -464,9 +484,10 @@ bool want_real(hxv_handle* h) { return h->real_vectors && !real_mode_blocker(h);
 // layouts sit at different places and must be zero (the reductions run over the padded arrays, the products never
 // write pads), so the buffers are cleared whenever the layout changes.
 int ensure_lz(hxv_handle* h, bool real) {
-  if (h->host.nranks != 1) return fail(HXV_ERR_STATE, "device Lanczos needs nranks==1 (global dots belong to the caller's communicator)");
+  if (h->host.nranks != 1 && !comm_ready(h))
+    return fail(HXV_ERR_STATE, "device Lanczos on a split sector needs the communicator: call hxv_comm_init after opening the sector");
   HIPCHK(hipSetDevice(h->device));
-  const size_t bytes = (size_t)h->host.pitch * h->host.dimdw * sizeof(double2);
+  const size_t bytes = (size_t)h->host.pitch * std::max(h->host.qdw, 1) * sizeof(double2);
   for (auto& p : h->d_lz)
     if (!p) {
       HIPCHK(pool_alloc(h->device, bytes, (void**)&p));
@@ -503,9 +524,8 @@ extern "C" {
 int hxv_lanczos_tridiag(hxv_handle* h, const void* d_vin, int32_t nlanc, double* alanc, double* blanc, double threshold,
                         int32_t* nsteps) {
   if (!h || !d_vin || nlanc < 1 || !alanc || !blanc) return fail(HXV_ERR_ARG, "hxv_lanczos_tridiag: bad argument");
-  if (h->host.nranks != 1) return fail(HXV_ERR_STATE, "device Lanczos needs nranks==1 (global dots belong to the caller's communicator)");
   HIPCHK(hipSetDevice(h->device));
-  const int64_t n = (int64_t)h->host.pitch * h->host.dimdw;
+  const int64_t n = (int64_t)h->host.pitch * h->host.qdw;  // this rank's slab
   // REAL-vector mode: H real and the start vector purely real (c / c^dagger applied to a real ground state is) ->
   // the whole recurrence stays real; alanc/blanc are the same numbers at half the bytes per pass
   bool real = want_real(h);
@@ -527,7 +547,26 @@ int hxv_lanczos_tridiag(hxv_handle* h, const void* d_vin, int32_t nlanc, double*
     launch_to_real(h, (const double2*)d_vin, (double*)lz.b.q, h->stream);
   else
     HIPCHK(hipMemcpyAsync(lz.b.q, d_vin, (size_t)n * sizeof(double2), hipMemcpyDeviceToDevice, h->stream));
-  rc = lz.begin(1.0);  // vin is normalised by the caller (ED_GF_NORMAL.f90:197-199)
+  // SciFortran's sp_lanc_tridiag normalises vin on its first iteration; the reference's call sites pass a normalised
+  // vector already (ED_GF_NORMAL.f90:197-199).  Measure the (global) norm and normalise only when it is not 1.
+  {
+    const int gq = grid_for(lz.n2);
+    hipLaunchKernelGGL(lz_nrm, dim3(gq), dim3(256), 0, h->stream, lz.n2, lz.b.q, h->d_partials + RED_BLOCKS);
+    rc = reduce_scalar(h, h->d_partials + RED_BLOCKS, gq, 5, 1);
+    if (rc) return rc;
+    double nrm = 0.0;
+    HIPCHK(hipMemcpyAsync(&nrm, h->d_scalars + 5, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (!(nrm > 0.0) || !std::isfinite(nrm)) return fail(HXV_ERR_ARG, "hxv_lanczos_tridiag: the start vector is zero or not finite");
+    if (std::fabs(nrm - 1.0) <= 1e-14) {
+      rc = lz.begin(1.0);
+    } else if (lz.fused) {
+      rc = lz.begin(nrm);  // the fused recurrence carries the scale factor
+    } else {
+      hipLaunchKernelGGL(lz_scale, dim3(gq), dim3(256), 0, h->stream, lz.n2, lz.b.q, lz.b.q, h->d_scalars, 5);
+      rc = lz.begin(1.0);
+    }
+  }
   if (rc) return rc;
   for (int k = 0; k < nlanc; ++k) {
     alanc[k] = 0;
@@ -606,7 +645,7 @@ int hxv_lanczos_eigh(hxv_handle* h, int32_t nitermax, double threshold, double* 
   const bool real = want_real(h);  // the start vector is ours: real when H is (REAL-vector mode)
   int rc = ensure_lz(h, real);
   if (rc) return rc;
-  const int64_t nc = (int64_t)h->host.pitch * h->host.dimdw;
+  const int64_t nc = (int64_t)h->host.pitch * h->host.qdw;                        // this rank's slab
   const int64_t n = real ? (int64_t)pitch_real_of(h) * h->host.dimdw / 2 : nc;  // double2 elements per vector
   const int g = grid_for(n);
   const int nmax = (int)std::min<int64_t>(nitermax, h->host.dim);
@@ -616,10 +655,11 @@ int hxv_lanczos_eigh(hxv_handle* h, int32_t nitermax, double threshold, double* 
     if (real)
       launch_init_real(h, (double*)lz.b.w, seed, h->stream);
     else
-      hipLaunchKernelGGL(lz_init, dim3(g), dim3(256), 0, h->stream, n, lz.b.w, seed, h->host.dimup, h->host.pitch);
+      hipLaunchKernelGGL(lz_init, dim3(g), dim3(256), 0, h->stream, n, lz.b.w, seed, h->host.dimup, h->host.pitch, h->host.dw0);
     HIPCHK(hipMemsetAsync(h->d_scalars, 0, 8 * sizeof(double), h->stream));
     hipLaunchKernelGGL(lz_nrm, dim3(g), dim3(256), 0, h->stream, n, lz.b.w, h->d_partials + RED_BLOCKS);
-    hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_partials + RED_BLOCKS, g, h->d_scalars, 1, 1);
+    int rcn = reduce_scalar(h, h->d_partials + RED_BLOCKS, g, 1, 1);
+    if (rcn) return rcn;
     hipLaunchKernelGGL(lz_scale, dim3(g), dim3(256), 0, h->stream, n, lz.b.q, lz.b.w, h->d_scalars, 1);
     return lz.begin(1.0);
   };
@@ -690,7 +730,8 @@ int hxv_lanczos_eigh(hxv_handle* h, int32_t nitermax, double threshold, double* 
     }
     // normalise the Ritz vector
     hipLaunchKernelGGL(lz_nrm, dim3(g), dim3(256), 0, h->stream, n, out, h->d_partials + RED_BLOCKS);
-    hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_partials + RED_BLOCKS, g, h->d_scalars, 1, 1);
+    rc = reduce_scalar(h, h->d_partials + RED_BLOCKS, g, 1, 1);
+    if (rc) return rc;
     hipLaunchKernelGGL(lz_scale, dim3(g), dim3(256), 0, h->stream, n, out, out, h->d_scalars, 1);
     if (real) {
       // the Ritz vector was accumulated as a real vector in d_vect's memory: expand it to the complex layout of the API
@@ -704,7 +745,7 @@ int hxv_lanczos_eigh(hxv_handle* h, int32_t nitermax, double threshold, double* 
 
 namespace {
 int ensure_stage(hxv_handle* h) {
-  const size_t bytes = (size_t)h->host.pitch * h->host.dimdw * sizeof(double2);
+  const size_t bytes = (size_t)h->host.pitch * std::max(h->host.qdw, 1) * sizeof(double2);
   if (!h->d_stage_v) {
     HIPCHK(pool_alloc(h->device, bytes, (void**)&h->d_stage_v));
     HIPCHK(pool_alloc(h->device, bytes, (void**)&h->d_stage_hv));
@@ -719,19 +760,18 @@ int ensure_stage(hxv_handle* h) {
 int hxv_lanczos_tridiag_host(hxv_handle* h, const void* vin_host, int32_t nlanc, double* alanc, double* blanc, double threshold,
                              int32_t* nsteps) {
   if (!h || !vin_host) return fail(HXV_ERR_ARG, "hxv_lanczos_tridiag_host: NULL argument");
-  if (h->host.nranks != 1) return fail(HXV_ERR_STATE, "hxv_lanczos_tridiag_host needs nranks==1");
   HIPCHK(hipSetDevice(h->device));
   int rc = ensure_stage(h);
   if (rc) return rc;
   const size_t col = (size_t)h->host.dimup * sizeof(double2), pit = (size_t)h->host.pitch * sizeof(double2);
-  HIPCHK(hipMemcpy2DAsync(h->d_stage_v, pit, vin_host, col, col, (size_t)h->host.dimdw, hipMemcpyHostToDevice, h->stream));
+  if (h->host.qdw > 0)
+    HIPCHK(hipMemcpy2DAsync(h->d_stage_v, pit, vin_host, col, col, (size_t)h->host.qdw, hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return hxv_lanczos_tridiag(h, h->d_stage_v, nlanc, alanc, blanc, threshold, nsteps);
 }
 
 int hxv_lanczos_eigh_host(hxv_handle* h, int32_t nitermax, double threshold, double* egs, void* vect_host, int32_t* niter) {
   if (!h) return fail(HXV_ERR_ARG, "hxv_lanczos_eigh_host: NULL handle");
-  if (h->host.nranks != 1) return fail(HXV_ERR_STATE, "hxv_lanczos_eigh_host needs nranks==1");
   HIPCHK(hipSetDevice(h->device));
   int rc = ensure_stage(h);
   if (rc) return rc;
@@ -739,7 +779,8 @@ int hxv_lanczos_eigh_host(hxv_handle* h, int32_t nitermax, double threshold, dou
   if (rc) return rc;
   if (vect_host) {
     const size_t col = (size_t)h->host.dimup * sizeof(double2), pit = (size_t)h->host.pitch * sizeof(double2);
-    HIPCHK(hipMemcpy2DAsync(vect_host, col, h->d_stage_hv, pit, col, (size_t)h->host.dimdw, hipMemcpyDeviceToHost, h->stream));
+    if (h->host.qdw > 0)
+      HIPCHK(hipMemcpy2DAsync(vect_host, col, h->d_stage_hv, pit, col, (size_t)h->host.qdw, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
   }
   return HXV_OK;
@@ -794,7 +835,7 @@ int hxv_time_lanczos(hxv_handle* h, void* d_work3, int32_t nrep, float* ms_per_i
   if (real)
     launch_init_real(h, (double*)lz.b.w, 0x1234ull, h->stream);
   else
-    hipLaunchKernelGGL(lz_init, dim3(g), dim3(256), 0, h->stream, n, lz.b.w, 0x1234ull, h->host.dimup, h->host.pitch);
+    hipLaunchKernelGGL(lz_init, dim3(g), dim3(256), 0, h->stream, n, lz.b.w, 0x1234ull, h->host.dimup, h->host.pitch, 0);
   (void)nfull;
   HIPCHK(hipMemsetAsync(h->d_scalars, 0, 8 * sizeof(double), h->stream));
   hipLaunchKernelGGL(lz_nrm, dim3(g), dim3(256), 0, h->stream, n, lz.b.w, h->d_partials + RED_BLOCKS);

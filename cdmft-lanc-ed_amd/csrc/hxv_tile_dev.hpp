@@ -11,7 +11,6 @@ struct DevTiles {
   const uint32_t* gstart;  // [nblocks+1] first 64-position group of each block
   const uint32_t* gmax;    // [groups] longest in-block list of each 64-position group (low 16 bits)
   const uint32_t* ell_in;  // [k_in][dim]
-  const uint32_t* ell_out; // unused placeholder (the out-of-block part is bh/rs below)
   const double2* scoef;    // [nscoef] signed coefficients, last = 0
   const uint32_t* bh_ptr;  // block hops / row slots of the out-of-block part (hxv_tiles.hpp)
   const uint32_t* bh;

@@ -369,7 +369,7 @@ int choose_lowbits(int ns, int npart, int width, int budget_bytes, int max_block
 }
 
 struct HostTiles {
-  std::vector<uint32_t> start, perm, gstart, gmax, ell_in, ell_out;
+  std::vector<uint32_t> start, perm, gstart, gmax, ell_in;
   std::vector<uint32_t> bh_ptr, bh, rs_ptr, rs_off, rs_tab, order;
 };
 
@@ -447,7 +447,6 @@ void build_spin_tiles(const SpinOp& op, const std::vector<uint32_t>& map, int lo
   // tables
   const uint32_t emptyz = (uint32_t)(2 * op.coef.size()) << TILE_COEF_SHIFT;
   h.ell_in.assign((size_t)t.k_in * dim, emptyz);
-  h.ell_out.assign(1, emptyz);  // the flat outer table is superseded by block hops + row slots (below)
   std::vector<uint32_t> pos_of(dim);
   for (int q = 0; q < dim; ++q) pos_of[h.perm[q]] = (uint32_t)q;
   for (int i = 0; i < dim; ++i) {
@@ -655,7 +654,7 @@ std::string make_tile_plan(const SectorHost& s, TilePlan& plan, const PlanUpload
     if (t.max_block > max_block) return "block larger than the workgroup (one thread per block row/column)";
     if (up.u32(h.start, &t.d_start) != hipSuccess || up.u32(h.perm, &t.d_perm) != hipSuccess ||
         up.u32(h.gstart, &t.d_gstart) != hipSuccess || up.u32(h.gmax, &t.d_gmax) != hipSuccess ||
-        up.u32(h.ell_in, &t.d_ell_in) != hipSuccess || up.u32(h.ell_out, &t.d_ell_out) != hipSuccess ||
+        up.u32(h.ell_in, &t.d_ell_in) != hipSuccess ||
         up.u32(h.bh_ptr, &t.d_bh_ptr) != hipSuccess || up.u32(h.bh, &t.d_bh) != hipSuccess ||
         up.u32(h.rs_ptr, &t.d_rs_ptr) != hipSuccess || up.u32(h.rs_off, &t.d_rs_off) != hipSuccess ||
         up.u32(h.rs_tab, &t.d_rs_tab) != hipSuccess || up.u32(h.order, &t.d_order) != hipSuccess)
@@ -705,10 +704,10 @@ template <typename VT>
 static hipError_t launch_tiled_vt(const DevSector& s, const TilePlan& plan, const VT* v, VT* wt, VT* hv, hipStream_t st, const LzEpilogue* lz,
                                   int only_pass, bool wt_natural) {
   constexpr bool RV = std::is_same<VT, double>::value;
-  DevTiles tu{plan.up.d_start, plan.up.d_perm, plan.up.d_gstart, plan.up.d_gmax, plan.up.d_ell_in, plan.up.d_ell_out,
+  DevTiles tu{plan.up.d_start, plan.up.d_perm, plan.up.d_gstart, plan.up.d_gmax, plan.up.d_ell_in,
               plan.d_scoef_up, plan.up.d_bh_ptr, plan.up.d_bh, plan.up.d_rs_ptr, plan.up.d_rs_off, plan.up.d_rs_tab,
               plan.up.nblocks, 2 * plan.ncoef_up + 1, plan.opt.debug};
-  DevTiles td{plan.dw.d_start, plan.dw.d_perm, plan.dw.d_gstart, plan.dw.d_gmax, plan.dw.d_ell_in, plan.dw.d_ell_out,
+  DevTiles td{plan.dw.d_start, plan.dw.d_perm, plan.dw.d_gstart, plan.dw.d_gmax, plan.dw.d_ell_in,
               plan.d_scoef_dw, plan.dw.d_bh_ptr, plan.dw.d_bh, plan.dw.d_rs_ptr, plan.dw.d_rs_off, plan.dw.d_rs_tab,
               plan.dw.nblocks, 2 * plan.ncoef_dw + 1, plan.opt.debug};
   const int C = RV ? real_cols(plan) : plan.opt.cols_per_tile, R = RV ? real_rows(plan) : plan.opt.rows_per_tile;
@@ -758,76 +757,4 @@ hipError_t launch_hxv_tiled_real(const DevSector& s, const TilePlan& plan, const
   return launch_tiled_vt<double>(s, plan, v, wt, hv, st, lz, 0, false);
 }
 
-}  // namespace hxv
-// ---------------------------------------------------------------------------------------
-// Micro-benchmark (not part of the product path): read every element of a DimUp x ncols matrix once,
-// in pass-B tile order: workgroup = [R consecutive rows] x [n consecutive columns].  Tells what HBM gives
-// for R*16-byte segments at a column stride of DimUp*16 bytes.
-// ---------------------------------------------------------------------------------------
-namespace hxv {
-template <int R>
-__global__ void __launch_bounds__(1024) strided_read_kernel(const double2* __restrict__ v, double2* __restrict__ out, int dimup, int ncols,
-                                                           int n, int ngroups, int groups_per_xcd, int nblocks, int mode) {
-  extern __shared__ double2 lds[];
-  const int b = blockIdx.x;
-  const int xcd = b & 7, j = b >> 3;
-  const int gl = j / nblocks, kb = j - gl * nblocks;
-  const int rg = xcd * groups_per_xcd + gl;
-  if (gl >= groups_per_xcd || rg >= ngroups) return;
-  const int cb0 = kb * n, nn = min(n, ncols - cb0), i0 = rg * R;
-  double2 acc = make_double2(0.0, 0.0);
-  if (mode == 0) {  // read only
-    for (int q = threadIdx.x; q < nn * R; q += blockDim.x) {
-      const double2 x = v[(int64_t)(cb0 + q / R) * dimup + min(i0 + q % R, dimup - 1)];
-      acc.x += x.x;
-      acc.y += x.y;
-    }
-    if (acc.x == 1.2345e300) out[b] = acc;  // keep the loads alive
-    return;
-  }
-  // mode >= 1: stage through LDS transposed (lds[r*nn + col]) like pass B
-  for (int q = threadIdx.x; q < nn * R; q += blockDim.x)
-    lds[(q % R) * nn + q / R] = v[(int64_t)(cb0 + q / R) * dimup + min(i0 + q % R, dimup - 1)];
-  __syncthreads();
-  if (mode == 1) {
-    for (int q = threadIdx.x; q < nn * R; q += blockDim.x) {
-      const double2 x = lds[(q % R) * nn + q / R];
-      acc.x += x.x;
-      acc.y += x.y;
-    }
-    if (acc.x == 1.2345e300) out[b] = acc;
-    return;
-  }
-  for (int q = threadIdx.x; q < nn * R; q += blockDim.x) {
-    if (i0 + q % R >= dimup) continue;
-    const int64_t o = (int64_t)(cb0 + q / R) * dimup + i0 + q % R;
-    double2 x = lds[(q % R) * nn + q / R];
-    if (mode == 4 || mode == 5) {  // read-modify-write
-      const double2 h = (mode == 5) ? load_stream(&out[o]) : out[o];
-      x.x += h.x;
-      x.y += h.y;
-    }
-    if (mode == 3 || mode == 5)
-      store_stream(&out[o], x);
-    else
-      out[o] = x;
-  }
-}
-
-hipError_t launch_strided_read(const double2* v, double2* out, int dimup, int ncols, int R, int n, int mode, hipStream_t st) {
-  const int ngroups = (dimup + R - 1) / R, gpx = (ngroups + 7) / 8, nblocks = (ncols + n - 1) / n;
-  const int64_t nwg = (int64_t)gpx * 8 * nblocks;
-  const size_t lds = mode ? (size_t)n * R * 16 : 0;
-#define SR(RR)                                                                                                         \
-  case RR: {                                                                                                           \
-    (void)hipFuncSetAttribute((const void*)strided_read_kernel<RR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    hipLaunchKernelGGL(strided_read_kernel<RR>, dim3((unsigned)nwg), dim3(1024), lds, st, v, out, dimup, ncols, n, ngroups, gpx, nblocks, mode); \
-  } break;
-  switch (R) {
-    SR(4) SR(8) SR(16) SR(32) SR(64)
-    default: return hipErrorInvalidValue;
-  }
-#undef SR
-  return hipGetLastError();
-}
 }  // namespace hxv

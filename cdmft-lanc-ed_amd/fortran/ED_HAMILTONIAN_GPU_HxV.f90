@@ -16,10 +16,27 @@ module ED_HAMILTONIAN_GPU_HXV
   public :: gpu_delete_Hv_sector
   public :: gpu_vecDim_Hv_sector
   public :: gpuMatVec_main
+  public :: gpuMatVec_MPI_main
+  public :: gpu_comm_unique_id
+  public :: gpu_comm_init
   public :: gpu_lanc_tridiag_host
   public :: gpu_sp_lanc_tridiag
   public :: gpu_sp_lanc_eigh
   public :: gpu_sp_eigh
+
+  !> SciFortran's drivers are generic in exactly this way: the serial form takes the product first, the MPI form the
+  !! communicator first (call sites ED_DIAG.f90:152-156,161-165,176-184; ED_GF_NORMAL.f90:215,217).  Both forms end in
+  !! the same device driver: on a split sector the engine's own communicator (gpu_comm_init) does the all-reduces, so
+  !! MpiComm is accepted for call compatibility only.
+  interface gpu_sp_eigh
+     module procedure gpu_sp_eigh_serial, gpu_sp_eigh_mpi
+  end interface gpu_sp_eigh
+  interface gpu_sp_lanc_eigh
+     module procedure gpu_sp_lanc_eigh_serial, gpu_sp_lanc_eigh_mpi
+  end interface gpu_sp_lanc_eigh
+  interface gpu_sp_lanc_tridiag
+     module procedure gpu_sp_lanc_tridiag_serial, gpu_sp_lanc_tridiag_mpi
+  end interface gpu_sp_lanc_tridiag
 
   !> mirrors struct hxv_model of include/hxv.h
   type, bind(C) :: hxv_model
@@ -79,6 +96,15 @@ module ED_HAMILTONIAN_GPU_HXV
        complex(c_double_complex)            :: evecs(*)
        integer(c_int32_t)                   :: nconv,nmatvec
      end function hxv_eigh_lowest_host
+     integer(c_int) function hxv_comm_unique_id(id) bind(C,name="hxv_comm_unique_id")
+       import :: c_int, c_int8_t
+       integer(c_int8_t) :: id(128)
+     end function hxv_comm_unique_id
+     integer(c_int) function hxv_comm_init(h,id) bind(C,name="hxv_comm_init")
+       import :: c_int, c_int8_t, c_ptr
+       type(c_ptr),value            :: h
+       integer(c_int8_t),intent(in) :: id(128)
+     end function hxv_comm_init
      type(c_ptr) function hxv_last_error() bind(C,name="hxv_last_error")
        import :: c_ptr
      end function hxv_last_error
@@ -158,6 +184,32 @@ contains
     call check(hxv_apply_host(handle,int(Nloc,c_int64_t),v,Hv),"gpuMatVec_main")
   end subroutine gpuMatVec_main
 
+  !> Target of the pointer when MpiStatus=T (the reference binds spMatVec_MPI_main there, ED_HAMILTONIAN.f90:131-134):
+  !! v, Hv are this rank's slab of vecDim_Hv_sector elements; the engine all-gathers the slabs itself (hxv_apply_host).
+  subroutine gpuMatVec_MPI_main(Nloc,v,Hv)
+    integer                    :: Nloc
+    complex(8),dimension(Nloc) :: v
+    complex(8),dimension(Nloc) :: Hv
+    if(.not.c_associated(handle))stop "gpuMatVec_MPI_main ERROR: Hsector NOT set"
+    call check(hxv_apply_host(handle,int(Nloc,c_int64_t),v,Hv),"gpuMatVec_MPI_main")
+  end subroutine gpuMatVec_MPI_main
+
+  !> Communicator of the open (split) sector.  Host side, after gpu_build_Hv_sector on every rank of MpiComm:
+  !!     if(MpiRank==0)call gpu_comm_unique_id(id)
+  !!     call MPI_Bcast(id,128,MPI_BYTE,0,MpiComm,ierr)
+  !!     call gpu_comm_init(id)
+  !! (gpu_delete_Hv_sector releases it with the sector.)
+  subroutine gpu_comm_unique_id(id)
+    integer(c_int8_t),intent(out) :: id(128)
+    call check(hxv_comm_unique_id(id),"gpu_comm_unique_id")
+  end subroutine gpu_comm_unique_id
+
+  subroutine gpu_comm_init(id)
+    integer(c_int8_t),intent(in) :: id(128)
+    if(.not.c_associated(handle))stop "gpu_comm_init ERROR: Hsector NOT set"
+    call check(hxv_comm_init(handle,id),"gpu_comm_init")
+  end subroutine gpu_comm_init
+
   !> Plain Lanczos tridiagonalisation driven through a cc_sparse_HxV procedure on HOST vectors:
   !! the call shape of SciFortran's sp_lanc_tridiag(MatVec,vin,alanc,blanc) as consumed at
   !! ED_GF_NORMAL.f90:215-220,949-951 (alanc(k)=<q_k|H|q_k>, blanc(k+1)=beta_{k+1}, blanc(1) unused).
@@ -200,7 +252,7 @@ contains
   !!                        sp_lanc_eigh(MatVec,egs,vect,Nitermax,iverbose,threshold)   ED_DIAG.f90:176-184
   !! MatVec is accepted for signature compatibility and not called: the product of the OPEN sector runs on the
   !! device; vin/vect cross PCIe once per run instead of twice per iteration.
-  subroutine gpu_sp_lanc_tridiag(MatVec,vin,alanc,blanc,threshold)
+  subroutine gpu_sp_lanc_tridiag_serial(MatVec,vin,alanc,blanc,threshold)
     interface
        subroutine MatVec(Nloc,v,Hv)
          integer                    :: Nloc
@@ -214,10 +266,12 @@ contains
     integer(c_int32_t)          :: nsteps
     if(.not.c_associated(handle))stop "gpu_sp_lanc_tridiag ERROR: Hsector NOT set"
     thr=1d-12; if(present(threshold))thr=threshold
+    !(the engine normalises the start vector itself, as SciFortran's sp_lanc_tridiag does on its first iteration; on a
+    ! split sector the norm is the global one)
     call check(hxv_lanczos_tridiag_host(handle,vin,int(size(alanc),c_int32_t),alanc,blanc,thr,nsteps),"gpu_sp_lanc_tridiag")
-  end subroutine gpu_sp_lanc_tridiag
+  end subroutine gpu_sp_lanc_tridiag_serial
 
-  subroutine gpu_sp_lanc_eigh(MatVec,egs,vect,Nitermax,iverbose,threshold)
+  subroutine gpu_sp_lanc_eigh_serial(MatVec,egs,vect,Nitermax,iverbose,threshold)
     interface
        subroutine MatVec(Nloc,v,Hv)
          integer                    :: Nloc
@@ -237,11 +291,11 @@ contains
     if(present(iverbose))then
        if(iverbose)write(*,"(A,I6,A,F20.12)")"gpu_sp_lanc_eigh: iterations=",niter," E0=",egs
     endif
-  end subroutine gpu_sp_lanc_eigh
+  end subroutine gpu_sp_lanc_eigh_serial
 
   !> sp_eigh(MatVec,eval,evec,Nblock,Nitermax,tol,iverbose) -- the default (lanc_method="arpack") spectrum call at
   !! ED_DIAG.f90:152-160 -- on the device: size(eval) lowest eigenpairs, Krylov basis of Nblock vectors in HBM.
-  subroutine gpu_sp_eigh(MatVec,eval,evec,Nblock,Nitermax,tol,iverbose)
+  subroutine gpu_sp_eigh_serial(MatVec,eval,evec,Nblock,Nitermax,tol,iverbose)
     interface
        subroutine MatVec(Nloc,v,Hv)
          integer                    :: Nloc
@@ -258,12 +312,70 @@ contains
     if(.not.c_associated(handle))stop "gpu_sp_eigh ERROR: Hsector NOT set"
     if(size(evec,2)<size(eval))stop "gpu_sp_eigh ERROR: size(evec,2) < size(eval)"
     ncv=0;   if(present(Nblock))ncv=int(Nblock,c_int32_t)
+    !Nblock = min(dim,lanc_ncv_factor*max(Neigen,lanc_nstates_sector)+lanc_ncv_add) (ED_DIAG.f90:96) exceeds the engine's
+    !largest Krylov basis (64 vectors) once lanc_nstates_sector >= 7: clamp instead of stopping the run
+    if(ncv>64)then
+       write(*,"(A,I6,A)")"gpu_sp_eigh WARNING: Nblock=",ncv," > 64: using a Krylov basis of 64 vectors"
+       ncv=max(64_c_int32_t,int(size(eval)+1,c_int32_t))
+    endif
+    !Nitermax bounds the RESTARTS here (each restart is up to ncv products; ARPACK's bound counts restarts too)
     nit=512; if(present(Nitermax))nit=int(Nitermax,c_int32_t)
     tl=0d0;  if(present(tol))tl=tol
     call check(hxv_eigh_lowest_host(handle,int(size(eval),c_int32_t),ncv,nit,tl,eval,evec,nconv,nmv),"gpu_sp_eigh")
     if(present(iverbose))then
        if(iverbose)write(*,"(A,I4,A,I6,A,F20.12)")"gpu_sp_eigh: converged=",nconv," matvecs=",nmv," E0=",eval(1)
     endif
-  end subroutine gpu_sp_eigh
+  end subroutine gpu_sp_eigh_serial
+
+  !> MpiComm-first forms: the call text of the reference's MpiStatus=T branches compiles against these unchanged,
+  !!   call sp_eigh(MpiComm,spHtimesV_p,eig_values,eig_basis,Nblock,Nitermax,tol=lanc_tolerance,iverbose=(ed_verbose>3))   ED_DIAG.f90:152-156
+  !!   call sp_lanc_eigh(MpiComm,spHtimesV_p,eig_values(1),eig_basis(:,1),Nitermax,iverbose=...,threshold=lanc_tolerance)    ED_DIAG.f90:176-177
+  !!   call sp_lanc_tridiag(MpiComm,spHtimesV_p,vvloc,alfa_,beta_)                                                            ED_GF_NORMAL.f90:215
+  !! with vectors = this rank's slab (vecDim_Hv_sector elements).  MpiComm is the reference's integer communicator.
+  subroutine gpu_sp_eigh_mpi(MpiComm,MatVec,eval,evec,Nblock,Nitermax,tol,iverbose)
+    integer,intent(in)          :: MpiComm
+    interface
+       subroutine MatVec(Nloc,v,Hv)
+         integer                    :: Nloc
+         complex(8),dimension(Nloc) :: v,Hv
+       end subroutine MatVec
+    end interface
+    real(8),intent(inout)       :: eval(:)
+    complex(8),intent(inout)    :: evec(:,:)
+    integer,intent(in),optional :: Nblock,Nitermax
+    real(8),intent(in),optional :: tol
+    logical,intent(in),optional :: iverbose
+    call gpu_sp_eigh_serial(MatVec,eval,evec,Nblock,Nitermax,tol,iverbose)
+  end subroutine gpu_sp_eigh_mpi
+
+  subroutine gpu_sp_lanc_eigh_mpi(MpiComm,MatVec,egs,vect,Nitermax,iverbose,threshold)
+    integer,intent(in)          :: MpiComm
+    interface
+       subroutine MatVec(Nloc,v,Hv)
+         integer                    :: Nloc
+         complex(8),dimension(Nloc) :: v,Hv
+       end subroutine MatVec
+    end interface
+    real(8),intent(inout)       :: egs
+    complex(8),intent(inout)    :: vect(:)
+    integer,intent(in)          :: Nitermax
+    logical,intent(in),optional :: iverbose
+    real(8),intent(in),optional :: threshold
+    call gpu_sp_lanc_eigh_serial(MatVec,egs,vect,Nitermax,iverbose,threshold)
+  end subroutine gpu_sp_lanc_eigh_mpi
+
+  subroutine gpu_sp_lanc_tridiag_mpi(MpiComm,MatVec,vin,alanc,blanc,threshold)
+    integer,intent(in)          :: MpiComm
+    interface
+       subroutine MatVec(Nloc,v,Hv)
+         integer                    :: Nloc
+         complex(8),dimension(Nloc) :: v,Hv
+       end subroutine MatVec
+    end interface
+    complex(8),intent(inout)    :: vin(:)
+    real(8),intent(inout)       :: alanc(:),blanc(:)
+    real(8),intent(in),optional :: threshold
+    call gpu_sp_lanc_tridiag_serial(MatVec,vin,alanc,blanc,threshold)
+  end subroutine gpu_sp_lanc_tridiag_mpi
 
 end module ED_HAMILTONIAN_GPU_HXV

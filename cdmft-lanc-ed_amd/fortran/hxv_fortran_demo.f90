@@ -98,7 +98,52 @@ contains
     deallocate(eig_values,eig_basis)
     spHtimesV_p => null()
     call gpu_delete_Hv_sector()
+    !
+    !MpiStatus=T side: the same sector with the slab exchange behind the C-ABI (one-rank communicator here: the RCCL
+    !all-gather / all-reduce path runs; with more ranks every rank does exactly this on its slab).  The three call
+    !texts are those of ED_DIAG.f90:152-156,176-177 and ED_GF_NORMAL.f90:215.
+    call mpi_branch(impHloc,Hbath,Vbath,Uloc)
   end subroutine chain_ns12
+
+  subroutine mpi_branch(impHloc,Hbath,Vbath,Uloc)
+    use, intrinsic :: iso_c_binding, only: c_int8_t
+    integer,parameter :: Nlat=4,Norb=1,Nspin=1,Nbath=2
+    complex(8) :: impHloc(Nlat,Nlat,Nspin,Nspin,Norb,Norb),Hbath(Nlat,Nlat,Nspin,Nspin,Norb,Norb,Nbath)
+    real(8)    :: Vbath(Nlat,Nspin,Norb,Nbath),Uloc(5)
+    integer    :: MpiComm,MpiRank,MpiSize,vecDim,Neigen,Nblock,Nitermax,ed_verbose,i
+    real(8)    :: lanc_tolerance
+    integer(c_int8_t)      :: id(128)
+    complex(8),allocatable :: eig_basis(:,:),vvloc(:)
+    real(8),allocatable    :: eig_values(:),alfa_(:),beta_(:)
+    MpiComm=0; MpiRank=0; MpiSize=1       !(no MPI library in this build: the communicator value is not used by the engine)
+    Neigen=2; Nblock=20; Nitermax=512; lanc_tolerance=1d-18; ed_verbose=0
+    call gpu_build_Hv_sector(Nlat,Norb,Nspin,Nbath,6,6,impHloc,Hbath,Vbath,Uloc,0d0,0d0,0d0,0d0,0d0,.true.,MpiRank,MpiSize)
+    if(MpiRank==0)call gpu_comm_unique_id(id)
+    !call MPI_Bcast(id,128,MPI_BYTE,0,MpiComm,ierr)
+    call gpu_comm_init(id)
+    spHtimesV_p => gpuMatVec_MPI_main
+    vecDim=gpu_vecDim_Hv_sector()
+    allocate(eig_values(Neigen),eig_basis(vecDim,Neigen))
+    call gpu_sp_eigh(MpiComm,spHtimesV_p,eig_values,eig_basis,&
+         Nblock,&
+         Nitermax,&
+         tol=lanc_tolerance,&
+         iverbose=(ed_verbose>3))
+    write(*,"(A,2F16.10)")"C2 MPI-branch sp_eigh E=",eig_values
+    call gpu_sp_lanc_eigh(MpiComm,spHtimesV_p,eig_values(1),eig_basis(:,1),Nitermax,&
+         iverbose=(ed_verbose>3),threshold=lanc_tolerance)
+    write(*,"(A,F16.10)")"C2 MPI-branch sp_lanc_eigh E0=",eig_values(1)
+    allocate(vvloc(vecDim),alfa_(100),beta_(100))
+    do i=1,vecDim
+       vvloc(i)=cmplx(sin(0.37d0*(i-1)+0.11d0),cos(0.23d0*(i-1)+0.05d0),8)
+    enddo
+    vvloc=vvloc/sqrt(dble(dot_product(vvloc,vvloc)))
+    call gpu_sp_lanc_tridiag(MpiComm,spHtimesV_p,vvloc,alfa_,beta_)
+    write(*,"(A,F16.10)")"C2 MPI-branch sp_lanc_tridiag E0=",lowest_tridiag(alfa_,beta_)
+    deallocate(eig_values,eig_basis,vvloc,alfa_,beta_)
+    spHtimesV_p => null()
+    call gpu_delete_Hv_sector()
+  end subroutine mpi_branch
 
   !> lowest eigenvalue of the Lanczos tridiagonal by bisection (Sturm count); blanc(1) unused
   function lowest_tridiag(a,b) result(e)

@@ -43,7 +43,7 @@ EXPORTS = [
     "hxv_create_from_model", "hxv_create_from_csr", "hxv_create_dw_panel", "hxv_apply_dw_panel", "hxv_apply_up_add", "hxv_destroy", "hxv_vecdim", "hxv_dims", "hxv_apply_host",
     "hxv_apply_device", "hxv_apply_device_real", "hxv_real_vectors_available", "hxv_pitch_real", "hxv_realvec_elems", "hxv_fullvec_elems", "hxv_localvec_elems", "hxv_pitch", "hxv_time_apply", "hxv_lanczos_tridiag", "hxv_lanczos_eigh", "hxv_lanczos_tridiag_host", "hxv_lanczos_eigh_host", "hxv_eigh_lowest", "hxv_eigh_lowest_host", "hxv_time_lanczos", "hxv_apply_ladder", "hxv_apply_ladder_axpy", "hxv_get_maps",
     "hxv_nnz", "hxv_get_csr", "hxv_get_diag", "hxv_set_option", "hxv_get_option", "hxv_get_stats", "hxv_pool_trim", "hxv_pool_stats", "hxv_last_error",
-    "hxv_version",
+    "hxv_version", "hxv_comm_unique_id", "hxv_comm_init", "hxv_comm_free", "hxv_apply_device_slab", "hxv_exchange_count",
 ]
 
 _lib = None
@@ -109,6 +109,12 @@ def load_library():
     L.hxv_pool_stats.argtypes = [i32, pi64, pi64, pi64]
     L.hxv_last_error.restype = C.c_char_p
     L.hxv_version.restype = C.c_char_p
+    L.hxv_comm_unique_id.argtypes = [vp]
+    L.hxv_comm_init.argtypes = [vp, vp]
+    L.hxv_comm_free.argtypes = [vp]
+    L.hxv_apply_device_slab.argtypes = [vp, vp, vp, vp]
+    L.hxv_exchange_count.argtypes = [vp]
+    L.hxv_exchange_count.restype = i64
     _lib = L
     return L
 
@@ -138,7 +144,7 @@ class HxvSector:
     """An open sector on one GPU: the device-side replacement of the state that
     build_Hv_sector leaves in ED_HAMILTONIAN_COMMON.f90:11-20 + spH0d/spH0ups/spH0dws."""
 
-    def __init__(self, handle, keep=None):
+    def __init__(self, handle, keep=None, device_index: int = 0):
         self._h = handle
         self._keep = keep
         L = load_library()
@@ -152,6 +158,7 @@ class HxvSector:
         self.fullElems = L.hxv_fullvec_elems(self._h)   # length of the (padded) all-gather layout handed to apply_device
         self.localElems = L.hxv_localvec_elems(self._h)  # length of the (padded) local result / of a Lanczos vector
         self.ncolsFull = self.fullElems // self.pitch
+        self.device_index = int(device_index)
 
     # -- constructors ---------------------------------------------------------------------
     @staticmethod
@@ -177,7 +184,7 @@ class HxvSector:
         m, keep = cls._model_struct(model)
         out = C.c_void_p()
         _chk(L.hxv_create_dw_panel(C.byref(m), nup, ndw, nrows, device, C.byref(out)), "hxv_create_dw_panel")
-        return cls(out, keep=keep)
+        return cls(out, keep=keep, device_index=device)
 
     def apply_dw_panel(self, x, y=None):
         """y = x H_dw^T on a panel handle; x, y: [DimDw columns][pitch] torch complex128 CUDA tensors."""
@@ -218,7 +225,7 @@ class HxvSector:
         m.vbath = vb.ctypes.data if model.Nbath > 0 else None
         out = C.c_void_p()
         _chk(L.hxv_create_from_model(C.byref(m), nup, ndw, rank, nranks, device, C.byref(out)), "hxv_create_from_model")
-        return cls(out, keep=(h, hb, vb))
+        return cls(out, keep=(h, hb, vb), device_index=device)
 
     @classmethod
     def from_csr(cls, DimUp, DimDw, up, dw, diag, rank: int = 0, nranks: int = 1, device: int = 0) -> "HxvSector":
@@ -234,7 +241,12 @@ class HxvSector:
         _chk(L.hxv_create_from_csr(DimUp, DimDw, _p(arrs[0], C.c_int64), _p(arrs[1], C.c_int32), _p(arrs[2], C.c_double),
                                    _p(arrs[3], C.c_int64), _p(arrs[4], C.c_int32), _p(arrs[5], C.c_double), _p(dg, C.c_double),
                                    rank, nranks, device, C.byref(out)), "hxv_create_from_csr")
-        return cls(out)
+        return cls(out, device_index=device)
+
+    def _dev(self):
+        import torch
+
+        return torch.device("cuda", self.device_index)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -301,6 +313,37 @@ class HxvSector:
             return res
         return hv_local
 
+    # -- slab exchange behind the C-ABI (split sector, MpiStatus=T; include/hxv.h) ------------------------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """128-byte id of a new communicator (rank 0); broadcast it with the host program's own means."""
+        buf = C.create_string_buffer(128)
+        _chk(load_library().hxv_comm_unique_id(buf), "hxv_comm_unique_id")
+        return buf.raw
+
+    def comm_init(self, id128: bytes):
+        """Collective over the nranks handles of this sector (one process per GPU)."""
+        assert len(id128) == 128
+        _chk(load_library().hxv_comm_init(self._h, C.create_string_buffer(id128, 128)), "hxv_comm_init")
+
+    def comm_free(self):
+        _chk(load_library().hxv_comm_free(self._h), "hxv_comm_free")
+
+    def apply_device_slab(self, v_local, hv_local=None, stream=None):
+        """(H v)|slab from this rank's slab: exchange (ncclAllGather on the stream) + product.  Padded layout, localElems each."""
+        import torch
+
+        assert v_local.is_cuda and v_local.dtype == torch.complex128 and v_local.is_contiguous() and v_local.numel() == self.localElems
+        if hv_local is None:
+            hv_local = torch.zeros(self.localElems, dtype=torch.complex128, device=v_local.device)
+        st = torch.cuda.current_stream(v_local.device).cuda_stream if stream is None else stream
+        _chk(load_library().hxv_apply_device_slab(self._h, v_local.data_ptr(), hv_local.data_ptr(), st), "hxv_apply_device_slab")
+        return hv_local
+
+    @property
+    def exchange_count(self) -> int:
+        return load_library().hxv_exchange_count(self._h)
+
     # -- REAL-vector mode (H real; include/hxv.h) ----------------------------------------------
     @property
     def real_vectors_available(self) -> bool:
@@ -362,8 +405,8 @@ class HxvSector:
 
         assert vin.is_cuda and vin.dtype == torch.complex128
         if vin.numel() != self.localElems:
-            assert vin.numel() == self.Dim
-            vin = self.pad(vin)
+            assert vin.numel() == self.vecDim
+            vin = self.pad(vin, self.mpiQdw)
         torch.cuda.synchronize()
         a = np.zeros(nlanc)
         b = np.zeros(nlanc)
@@ -380,7 +423,7 @@ class HxvSector:
         torch.cuda.synchronize()
         e = C.c_double()
         n = C.c_int32()
-        vec = torch.zeros(self.localElems, dtype=torch.complex128, device="cuda") if want_vector else None
+        vec = torch.zeros(self.localElems, dtype=torch.complex128, device=self._dev()) if want_vector else None
         _chk(load_library().hxv_lanczos_eigh(self._h, nitermax, threshold, C.byref(e), vec.data_ptr() if want_vector else None,
                                              C.byref(n)), "hxv_lanczos_eigh")
         if want_vector and not native:
@@ -390,7 +433,7 @@ class HxvSector:
     def lanczos_tridiag_host(self, vin: np.ndarray, nlanc: int, threshold: float = 1e-12):
         """sp_lanc_tridiag on a HOST start vector (reference layout): one PCIe copy per run."""
         vin = np.ascontiguousarray(vin, dtype=np.complex128)
-        assert vin.size == self.Dim
+        assert vin.size == self.vecDim          # this rank's slab (the whole vector on an unsplit sector)
         a = np.zeros(nlanc)
         b = np.zeros(nlanc)
         n = C.c_int32()
@@ -402,7 +445,7 @@ class HxvSector:
         """sp_lanc_eigh with the eigenvector returned in a HOST array (reference layout)."""
         e = C.c_double()
         n = C.c_int32()
-        vec = np.zeros(self.Dim, dtype=np.complex128)
+        vec = np.zeros(self.vecDim, dtype=np.complex128)
         _chk(load_library().hxv_lanczos_eigh_host(self._h, nitermax, threshold, C.byref(e), vec.ctypes.data, C.byref(n)),
              "hxv_lanczos_eigh_host")
         return e.value, vec, n.value
@@ -416,7 +459,7 @@ class HxvSector:
         torch.cuda.synchronize()
         ev = np.zeros(neigen)
         nc, nmv = C.c_int32(), C.c_int32()
-        vecs = torch.zeros(neigen * self.localElems, dtype=torch.complex128, device="cuda") if want_vectors else None
+        vecs = torch.zeros(neigen * self.localElems, dtype=torch.complex128, device=self._dev()) if want_vectors else None
         _chk(load_library().hxv_eigh_lowest(self._h, neigen, ncv, maxrestart, tol, _p(ev, C.c_double),
                                             vecs.data_ptr() if want_vectors else None, C.byref(nc), C.byref(nmv)), "hxv_eigh_lowest")
         if want_vectors:
@@ -429,7 +472,7 @@ class HxvSector:
         """Same with eig_basis returned in a HOST array, Fortran shape (Dim, neigen)."""
         ev = np.zeros(neigen)
         nc, nmv = C.c_int32(), C.c_int32()
-        basis = np.zeros((self.Dim, neigen), dtype=np.complex128, order="F")
+        basis = np.zeros((self.vecDim, neigen), dtype=np.complex128, order="F")
         _chk(load_library().hxv_eigh_lowest_host(self._h, neigen, ncv, maxrestart, tol, _p(ev, C.c_double), basis.ctypes.data,
                                                  C.byref(nc), C.byref(nmv)), "hxv_eigh_lowest_host")
         return ev, basis, nc.value, nmv.value
@@ -460,7 +503,7 @@ class HxvSector:
     def time_lanczos(self, nrep: int) -> float:
         import torch
 
-        work = torch.empty(3 * self.localElems, dtype=torch.complex128, device="cuda")
+        work = torch.empty(3 * self.localElems, dtype=torch.complex128, device=self._dev())
         torch.cuda.synchronize()
         ms = C.c_float()
         _chk(load_library().hxv_time_lanczos(self._h, work.data_ptr(), nrep, C.byref(ms)), "hxv_time_lanczos")

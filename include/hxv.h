@@ -75,11 +75,29 @@ int64_t hxv_vecdim(const hxv_handle *h);
 int hxv_dims(const hxv_handle *h, int32_t *dimup, int32_t *dimdw, int64_t *dim, int32_t *qdw, int64_t *ishift);
 
 /* ---- the product -----------------------------------------------------------------------
- * spHtimesV_p(Nloc,v,Hv) with HOST arrays (cc_sparse_HxV, ED_VARS_GLOBAL.f90:72-78):
- * Hv is overwritten (ED_HAMILTONIAN_SPARSE_HxV.f90:175,250); synchronous.  nranks==1 only
- * (the MPI form needs the exchange, which lives with the caller's communicator: see
- * hxv_apply_device and INTEGRATION.md).  Pays two PCIe copies per call.                 */
+ * spHtimesV_p(Nloc,v,Hv) with HOST arrays (cc_sparse_HxV, ED_VARS_GLOBAL.f90:72-78): v, Hv = this rank's slab of
+ * vecDim_Hv_sector elements; Hv is overwritten (ED_HAMILTONIAN_SPARSE_HxV.f90:175,250); synchronous.  Serial sector
+ * (nranks==1) = spMatVec_main; split sector (nranks>1) = spMatVec_MPI_main: the re-assembly the reference does with two
+ * MPI transposes inside the product (ED_HAMILTONIAN_SPARSE_HxV.f90:272-296) is done here by the engine itself -- one
+ * ncclAllGather of the slabs over xGMI -- once the handles share a communicator (hxv_comm_init below).
+ * Pays two PCIe copies of the slab per call.                                                            */
 int hxv_apply_host(hxv_handle *h, int64_t nloc, const void *v, void *hv);
+
+/* ---- slab exchange of a split sector (MpiStatus=T side of the boundary) -------------------------------------------
+ * One RCCL communicator over the nranks handles of a sector (one process per GPU).  Rank 0 draws an id, the host program
+ * broadcasts its HXV_COMM_ID_BYTES bytes by its own means (the reference: MPI_Bcast over MpiComm), every rank calls
+ * hxv_comm_init (collective).  Afterwards hxv_apply_host, hxv_apply_device_slab and the device Lanczos drivers work on
+ * split sectors: the product all-gathers the slabs (equal counts, all-gather layout of hxv_apply_device) on the stream it
+ * runs on, the drivers' dot products are ncclAllReduce sums.  hxv_destroy releases the communicator.
+ * RCCL is loaded at the first of these calls (dlopen), not at link time.                                            */
+#define HXV_COMM_ID_BYTES 128
+int hxv_comm_unique_id(void *id128);
+int hxv_comm_init(hxv_handle *h, const void *id128);
+int hxv_comm_free(hxv_handle *h);
+/* d_hv_local = (H v)|slab from this rank's slab d_v_local (hxv_localvec_elems() elements each, padded device layout):
+ * exchange + product, asynchronous on `stream`.  nranks==1 without a communicator: the plain product.              */
+int hxv_apply_device_slab(hxv_handle *h, const void *d_v_local, void *d_hv_local, void *stream);
+int64_t hxv_exchange_count(const hxv_handle *h); /* all-gathers since creation */
 
 /* Device-resident product.  d_v_full: the FULL vector in the ALL-GATHER LAYOUT: nranks slabs of
  * cmax*pitch elements each, cmax = ceil(DimDw/nranks), slab r holding rank r's columns (ranks

@@ -1,6 +1,7 @@
 """In-process A/B of the pipelined job kernels against the one-tile-per-workgroup kernels (C3 unless WORKLOAD is set).
 usage: ab_jobs.py "k=v,k=v" ...   each set is applied on top of the defaults; prints full product, pass B alone, difference."""
 import os, sys
+os.environ.setdefault("HXV_EXPERIMENTS", "1")  # the passes / job_debug timing options
 sys.path.insert(0, "cdmft-lanc-ed_amd")
 import torch, hxv
 from hxv import models

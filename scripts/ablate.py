@@ -1,4 +1,5 @@
 import sys, os
+os.environ.setdefault("HXV_EXPERIMENTS", "1")
 sys.path.insert(0, "cdmft-lanc-ed_amd")
 import torch, hxv
 from hxv import models

@@ -1,0 +1,121 @@
+"""The slab exchange behind the C-ABI (hxv_comm_*, include/hxv.h): RCCL communicator per open sector, products and device
+Lanczos drivers through it.  One GPU here, so the communicator has ONE rank: ncclAllGather / ncclAllReduce run, the numbers must
+equal the serial path exactly.  (N>1 on hardware is the driver's scaling run; the N>1 arithmetic of the exchange -- unequal
+slabs, all-gather layout -- is covered by tests/test_gpu_parity.py and the gloo tests.)"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-13
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def test_world_size_one_rccl_product_and_drivers(built):
+    import torch
+    import hxv
+    from hxv import models
+    from oracle.oracle import OracleSector
+
+    m = models.hm_1dchain(eps_bath=[0.3, 0.6])
+    ser = hxv.HxvSector.from_model(m, 6, 6)
+    sec = hxv.HxvSector.from_model(m, 6, 6)
+    sec.comm_init(hxv.HxvSector.comm_unique_id())
+    orc = OracleSector(m, 6, 6)
+    v = models.deterministic_vector(sec.Dim)
+    v /= np.linalg.norm(v)
+    ref = orc.spMatVec_main(v)
+    # host-array product = spMatVec_MPI_main on the (one) slab
+    assert _rel(sec.apply_host(v), ref) <= TOL
+    n0 = sec.exchange_count
+    assert n0 >= 1
+    dv = sec.pad(torch.from_numpy(v).cuda())
+    hv = sec.unpad(sec.apply_device_slab(dv))
+    torch.cuda.synchronize()
+    assert _rel(hv.cpu().numpy(), ref) <= TOL and sec.exchange_count == n0 + 1
+    # Lanczos drivers: all-reduced dots, plain recurrence -> same numbers as the serial handle to rounding
+    a1, b1, n1 = sec.lanczos_tridiag(torch.from_numpy(v).cuda(), 60)
+    ser.set_option("lanczos_fused", 0)
+    ser.set_option("real_vectors", 0)
+    a0, b0, n0s = ser.lanczos_tridiag(torch.from_numpy(v).cuda(), 60)
+    assert n1 == n0s and np.abs(a1 - a0).max() < 1e-11 and np.abs(b1 - b0).max() < 1e-11
+    e1, vec1, _ = sec.lanczos_eigh(400, 1e-14)
+    e0, vec0, _ = ser.lanczos_eigh(400, 1e-14)
+    assert abs(e1 - e0) < 1e-11
+    hvec = orc.spMatVec_main(vec1.cpu().numpy())
+    assert np.linalg.norm(hvec - e1 * vec1.cpu().numpy()) < 1e-8
+    ev1, vecs1, nc1, _ = sec.eigh_lowest(2, 20, 200, 0.0)
+    ev0, _, nc0, _ = ser.eigh_lowest(2, 20, 200, 0.0)
+    assert nc1 == 2 and nc0 == 2 and np.abs(ev1 - ev0).max() < 1e-10
+    # an unnormalised start vector is normalised by the driver (SciFortran's sp_lanc_tridiag does so on its first iteration)
+    a2, b2, _ = sec.lanczos_tridiag(torch.from_numpy(3.7 * v).cuda(), 60)
+    assert np.abs(a2 - a1).max() < 1e-10 and np.abs(b2 - b1).max() < 1e-10
+    for fused in (1, 0):
+        ser.set_option("lanczos_fused", fused)
+        a3, b3, _ = ser.lanczos_tridiag(torch.from_numpy(3.7 * v).cuda(), 60)
+        assert np.abs(a3 - a0).max() < 1e-10 and np.abs(b3 - b0).max() < 1e-10, fused
+    sec.close()
+    ser.close()
+
+
+def test_split_sector_without_communicator_fails_loudly(built):
+    import hxv
+    from hxv import models
+
+    sec = hxv.HxvSector.from_model(models.hm_1dchain(), 6, 6, rank=1, nranks=3)
+    v = np.zeros(sec.vecDim, dtype=np.complex128)
+    with pytest.raises(hxv.engine.HxvError, match="hxv_comm_init"):
+        sec.apply_host(v)
+    with pytest.raises(hxv.engine.HxvError, match="hxv_comm_init"):
+        sec.lanczos_eigh(10)
+    sec.close()
+
+
+def test_side_stream_then_close_then_reopen(built):
+    """buffers of a closed handle go to the device-buffer cache; kernels launched on a CALLER's stream must have
+    finished by then (hxv_destroy synchronises the device).  Apply on a side stream, close at once, reopen, apply_host."""
+    import torch
+    import hxv
+    from hxv import models
+    from oracle.oracle import OracleSector
+
+    m = models.hm_1dchain(eps_bath=[0.3, 0.6])
+    orc = OracleSector(m, 6, 6)
+    v = models.deterministic_vector(orc.Dim)
+    ref = orc.spMatVec_main(v)
+    side = torch.cuda.Stream()
+    for _ in range(3):
+        sec = hxv.HxvSector.from_model(m, 6, 6)
+        dv = sec.pad(torch.from_numpy(v).cuda())
+        out = torch.zeros(sec.localElems, dtype=torch.complex128, device="cuda")
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            for _ in range(20):
+                sec.apply_device(dv, out, stream=side.cuda_stream)
+        sec.close()                      # no synchronisation by the caller
+        sec2 = hxv.HxvSector.from_model(m, 6, 6)
+        assert _rel(sec2.apply_host(v), ref) <= TOL
+        sec2.close()
+        assert _rel(sec.unpad(out).cpu().numpy(), ref) <= TOL
+
+
+def test_experiment_options_are_gated(built):
+    import hxv
+    from hxv import models
+
+    sec = hxv.HxvSector.from_model(models.hm_1dchain(), 6, 6)
+    old = os.environ.pop("HXV_EXPERIMENTS", None)
+    try:
+        for name, val in (("debug", 1), ("passes", 1), ("job_debug", 4)):
+            with pytest.raises(hxv.engine.HxvError, match="HXV_EXPERIMENTS"):
+                sec.set_option(name, val)
+        sec.set_option("passes", 3)      # the neutral values stay settable
+        sec.set_option("debug", 0)
+    finally:
+        if old is not None:
+            os.environ["HXV_EXPERIMENTS"] = old
+    sec.close()

@@ -61,3 +61,22 @@ def test_fortran_gpu_sp_eigh_wrapper(built):
     H = oracle_full_matrix(OracleSector(models.hm_1dchain(eps_bath=[0.3, 0.6]), 6, 6))
     ref = np.sort(sla.eigsh(H, k=2, which="SA", ncv=20, tol=1e-13)[0])
     assert np.abs(e - ref).max() < 1e-9 and float(m2.group(3)) < 1e-8
+
+
+def test_fortran_mpi_branch_call_text(built):
+    """The reference's MpiStatus=T call lines (ED_DIAG.f90:152-156,176-177; ED_GF_NORMAL.f90:215: communicator first) compile
+    against the glue's generic interfaces and run through the engine's own communicator (one rank: RCCL all-gather /
+    all-reduce execute); the numbers equal the serial branch."""
+    exe = built.build_fortran()
+    if exe is None:
+        pytest.skip("flang not available")
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    txt = out.stdout
+    ser = re.search(r"C2 device sp_eigh E=\s*([-\d.Ee+]+)\s+([-\d.Ee+]+)", txt)
+    mpi = re.search(r"C2 MPI-branch sp_eigh E=\s*([-\d.Ee+]+)\s+([-\d.Ee+]+)", txt)
+    assert ser and mpi, txt
+    assert abs(float(ser.group(1)) - float(mpi.group(1))) < 1e-9 and abs(float(ser.group(2)) - float(mpi.group(2))) < 1e-9
+    e_l = float(re.search(r"C2 MPI-branch sp_lanc_eigh E0=\s*([-\d.Ee+]+)", txt).group(1))
+    e_t = float(re.search(r"C2 MPI-branch sp_lanc_tridiag E0=\s*([-\d.Ee+]+)", txt).group(1))
+    assert abs(e_l - float(ser.group(1))) < 1e-9 and abs(e_t - float(ser.group(1))) < 1e-8

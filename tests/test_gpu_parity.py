@@ -349,3 +349,158 @@ def test_real_vector_mode_refused_for_complex_h_and_shards(built):
         bhz.apply_device_real(torch.zeros(bhz.Dim, dtype=torch.float64, device="cuda"))
     shard = hxv.HxvSector.from_model(models.hm_1dchain(Nlat=2, Nbath=2), 3, 3, rank=1, nranks=2)
     assert not shard.real_vectors_available
+
+
+def test_full_size_c4_complex_hermiticity_and_linearity(built):
+    """BASELINE C4 at full size (BHZ 2x2 + 1 bath, Ns=16, Dim = 165 636 900, complex amplitudes, H_up != H_dw):
+    <x|H y> = conj(<y|H x>) and linearity through the complex-coefficient tiled / job kernels, and the tiled
+    product against the one-thread-per-element kernel."""
+    import torch
+    import hxv
+    from hxv import models
+
+    sec = hxv.HxvSector.from_model(models.bhz_2d(Nbath=1, Ust=0.5, Jh=0.1), 8, 8)
+    assert sec.stats()["real_h"] == 0
+    g = torch.Generator(device="cuda").manual_seed(23)
+    mk = lambda: torch.randn(sec.Dim, dtype=torch.float64, device="cuda", generator=g) + 1j * torch.randn(sec.Dim, dtype=torch.float64, device="cuda", generator=g)
+    x, y = mk(), mk()
+    hx, hy = sec.apply_device(x).clone(), sec.apply_device(y).clone()
+    a = torch.vdot(x, hy).item()
+    b = torch.vdot(y, hx).item()
+    scale = (x.norm() * hy.norm()).item()
+    assert abs(a - b.conjugate()) <= 1e-12 * scale
+    al, be = 0.3 - 1.1j, -0.7 + 0.2j
+    hz = sec.apply_device(al * x + be * y)
+    torch.cuda.synchronize()
+    assert (hz - (al * hx + be * hy)).abs().max().item() <= 1e-12 * hz.abs().max().item()
+    for opt in ("job_up", "kernel"):   # job kernels -> one-tile-per-workgroup kernels -> one thread per element
+        sec.set_option(opt, 0)
+        h2 = sec.apply_device(x)
+        torch.cuda.synchronize()
+        assert (h2 - hx).abs().max().item() <= 1e-13 * hx.abs().max().item(), opt
+    sec.close()
+
+
+def _fill_randn(v, seed):
+    import torch
+
+    vr = torch.view_as_real(v).view(-1)
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    for a in range(0, vr.numel(), 1 << 28):
+        b = min(a + (1 << 28), vr.numel())
+        vr[a:b] = torch.randn(b - a, dtype=torch.float64, device="cuda", generator=g)
+
+
+def _chunked(fn, n, step=1 << 27):
+    out = []
+    for a in range(0, n, step):
+        out.append(fn(slice(a, min(a + step, n))))
+    return out
+
+
+def test_c5_ns18_full_size_single_gpu(built):
+    """BASELINE config 5 (Ns=18, sector (9,9), Dim = 2 363 904 400, 37.8 GB per vector) on ONE GPU at full size:
+    tiled/job kernels vs the one-thread-per-element kernel, Hermiticity and linearity (64-bit indexing: Dim > 2^31)."""
+    import torch
+    import hxv
+    from hxv import models
+
+    free, _ = torch.cuda.mem_get_info()
+    if free < 210e9:
+        pytest.skip("needs ~200 GB of free HBM")
+    sec = hxv.HxvSector.from_model(models.hm_ring(6, 2), 9, 9)
+    assert sec.Dim == 2363904400 and sec.get_option("nblocks_up") == 64
+    n = sec.fullElems
+    x = torch.empty(n, dtype=torch.complex128, device="cuda")
+    y = torch.empty_like(x)
+    _fill_randn(x, 5)
+    _fill_randn(y, 6)
+    # pad rows of the device layout (hxv.h) must not enter the dot products: zero them
+    pitch, du = sec.pitch, sec.DimUp
+    if pitch != du:
+        x.view(-1, pitch)[:, du:] = 0
+        y.view(-1, pitch)[:, du:] = 0
+    hx = torch.empty_like(x)
+    hy = torch.empty_like(x)
+    sec.apply_device(x, hx)
+    sec.apply_device(y, hy)
+    torch.cuda.synchronize()
+    if pitch != du:
+        hx.view(-1, pitch)[:, du:] = 0
+        hy.view(-1, pitch)[:, du:] = 0
+    a = sum(_chunked(lambda s: torch.vdot(x[s], hy[s]).item(), n))
+    b = sum(_chunked(lambda s: torch.vdot(y[s], hx[s]).item(), n))
+    scale = (sum(_chunked(lambda s: (x[s].abs() ** 2).sum().item(), n)) * sum(_chunked(lambda s: (hy[s].abs() ** 2).sum().item(), n))) ** 0.5
+    assert abs(a - b.conjugate()) <= 1e-12 * scale
+    # one-thread-per-element kernel and the one-tile-per-workgroup kernels against the default path, into y's storage
+    hmax = max(_chunked(lambda s: hx[s].abs().max().item(), n))
+    for opt in ("job_up", "kernel"):
+        sec.set_option(opt, 0)
+        sec.apply_device(x, y)
+        torch.cuda.synchronize()
+        if pitch != du:
+            y.view(-1, pitch)[:, du:] = 0
+        assert max(_chunked(lambda s: (y[s] - hx[s]).abs().max().item(), n)) <= 1e-13 * hmax, opt
+    sec.set_option("kernel", 1)
+    sec.set_option("job_up", 1)
+    # linearity: z = al x + be (old y is gone: use hx as the second vector) -> H z = al H x + be H hx
+    al, be = 0.3 - 1.1j, -0.7 + 0.2j
+    sec.apply_device(hx, y)                       # y := H hx
+    _chunked(lambda s: x[s].mul_(al).add_(hx[s], alpha=be), n)   # x := z
+    _chunked(lambda s: hx[s].mul_(al).add_(y[s], alpha=be), n)   # hx := al H x + be H hx
+    sec.apply_device(x, y)                        # y := H z
+    torch.cuda.synchronize()
+    if pitch != du:
+        y.view(-1, pitch)[:, du:] = 0
+        hx.view(-1, pitch)[:, du:] = 0
+    zmax = max(_chunked(lambda s: y[s].abs().max().item(), n))
+    assert max(_chunked(lambda s: (y[s] - hx[s]).abs().max().item(), n)) <= 1e-12 * zmax
+    sec.close()
+
+
+def test_c5_ns18_slab_matches_oracle_matrices(built):
+    """A 1/512 slab of the Ns=18 sector against the oracle's H_up, H_dw and diagonal (the pattern of
+    test_full_size_slab_matches_oracle_matrices); only the columns H_dw couples to the slab are copied to the host."""
+    import scipy.sparse as sp
+    import torch
+    import hxv
+    from hxv import models
+    from oracle.oracle import OracleSector
+
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60e9:
+        pytest.skip("needs ~50 GB of free HBM")
+    m = models.hm_ring(6, 2)
+    P, rank = 512, 3
+    sec = hxv.HxvSector.from_model(m, 9, 9, rank=rank, nranks=P)
+    orc = OracleSector(m, 9, 9, rank, P)
+    assert (sec.vecDim, sec.mpiQdw, sec.mpiIshift) == (orc.vecDim, orc.mpiQdw, orc.mpiIshift)
+    du, dd, q = orc.DimUp, orc.DimDw, orc.mpiQdw
+    c0 = orc.mpiIshift // du
+    # the gathered vector on the device (all-gather layout: P slabs of cmax*pitch), seeded random numbers
+    v = torch.empty(sec.fullElems, dtype=torch.complex128, device="cuda")
+    _fill_randn(v, 18)
+    hv = sec.unpad(sec.apply_device(v))
+    torch.cuda.synchronize()
+    # host reference from the oracle's matrices
+    rp, cols, vals = orc.csr("up")
+    Hup = sp.csr_matrix((vals, cols - 1, rp), shape=(du, du))
+    rp, cols, vals = orc.csr("dw")
+    Hdw = sp.csr_matrix((vals, cols - 1, rp), shape=(dd, dd))[c0:c0 + q, :].tocsc()
+    src = np.flatnonzero(np.diff(Hdw.indptr))                 # dw columns the slab couples to (CSC: non-empty columns)
+    pitch = sec.pitch
+    cmax = -(-dd // P)
+    base, rem = dd // P, dd % P
+    def slot(c):                                             # column -> slot of the all-gather layout (hxv.h)
+        r = c // (base + 1) if c < rem * (base + 1) else rem + (c - rem * (base + 1)) // base
+        cfirst = r * base + min(r, rem)
+        return r * cmax + (c - cfirst)
+    def col(c):
+        s = slot(int(c))
+        return v[s * pitch:s * pitch + du].cpu().numpy()
+    Vloc = np.stack([col(c0 + k) for k in range(q)], axis=1)  # (du, q)
+    Vsrc = np.stack([col(c) for c in src], axis=1)            # (du, len(src))
+    out = orc.diag().reshape((du, q), order="F") * Vloc + Hup @ Vloc + (Hdw[:, src] @ Vsrc.T).T
+    ref = np.asarray(out).reshape(-1, order="F")
+    assert _rel(hv.cpu().numpy(), ref) <= TOL
+    sec.close()
