@@ -389,6 +389,10 @@ int hxv_set_option(hxv_handle* h, const char* name, int64_t value) {
     h->lz_graph = value ? 1 : 0;
     return HXV_OK;
   }
+  if (!strcmp(name, "eigh_degenerate")) {
+    h->eigh_degenerate = value ? 1 : 0;
+    return HXV_OK;
+  }
   if (!strcmp(name, "debug")) {
     h->plan.opt.debug = (int)value;
     return HXV_OK;
@@ -437,6 +441,7 @@ int64_t hxv_get_option(const hxv_handle* h, const char* name) {
   if (!h || !name) return -1;
   if (!strcmp(name, "real_vectors")) return h->real_vectors;
   if (!strcmp(name, "lanczos_graph")) return h->lz_graph;
+  if (!strcmp(name, "eigh_degenerate")) return h->eigh_degenerate;
   if (!strcmp(name, "lanczos_real_last")) return h->last_real;
   if (!strcmp(name, "kernel")) return h->kernel;
   if (!strcmp(name, "tile_bits_up")) return h->plan.up.lowbits;

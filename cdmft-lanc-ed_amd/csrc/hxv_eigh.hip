@@ -321,32 +321,20 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
   hipStream_t st = h->stream;
   auto vec = [&](int j) { return V + (int64_t)j * n; };
 
-  // start vector
-  if (real)
-    launch_init_real(h, (double*)vec(0), (uint64_t)0x5EED5EEDull, st);
-  else
-    hipLaunchKernelGGL(tr_init, dim3(g), dim3(256), 0, st, n, vec(0), (uint64_t)0x5EED5EEDull, h->host.dimup, h->host.pitch, h->host.dw0);
-  double nrm2 = 0.0;
-  hipLaunchKernelGGL(tr_scale_nrm, dim3(g), dim3(256), 0, st, n, vec(0), 1.0, d_npart);
-  hipLaunchKernelGGL(tr_colsum, dim3(1), dim3(256), 0, st, d_npart, g, 1, 1, d_nrm, 0);
-  if (int rca = comm_allreduce_sum(h, d_nrm, 1, st)) return rca;  // split sector: projections and norms are sums over the ranks
-  HIPCHK(hipMemcpyAsync(&nrm2, d_nrm, sizeof(double), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-  hipLaunchKernelGGL(tr_scale_nrm, dim3(g), dim3(256), 0, st, n, vec(0), 1.0 / std::sqrt(nrm2), (double*)nullptr);
-
-  // One Gram-Schmidt pass of w = V[j+1] against V[0..j].  ALL j+1 projections are measured every step (tr_mdot), so the
-  // orthogonality of the basis is known, not assumed; but only those that matter are subtracted (tr_maxpy): the two
-  // local ones (alpha_j v_j, beta_j v_{j-1}), everything right after a restart (the arrow) or in a refinement pass, and
-  // whatever exceeds GS_TAU*|w| -- in practice the kept Ritz vectors that are close to convergence, which is where a
-  // Lanczos basis loses orthogonality (Paige).  The rest are rounding noise (<= 1e-13 relative): skipping them leaves
-  // the basis orthogonal to ~1e-12 and saves about two thirds of the update traffic.
+  // One Gram-Schmidt pass of w = V[jt+1] against V[0..jt] (jt = absolute index; the first `nlock` vectors are LOCKED
+  // eigenvectors, see below).  ALL jt+1 projections are measured every step (tr_mdot), so the orthogonality of the basis
+  // is known, not assumed; but only those that matter are subtracted (tr_maxpy): the locked vectors, the two local ones
+  // (alpha_j v_j, beta_j v_{j-1}), everything right after a restart (the arrow) or in a refinement pass, and whatever
+  // exceeds GS_TAU*|w| -- in practice the kept Ritz vectors that are close to convergence, which is where a Lanczos basis
+  // loses orthogonality (Paige).  The rest are rounding noise (<= 1e-13 relative): skipping them leaves the basis
+  // orthogonal to ~1e-12 and saves about two thirds of the update traffic.
   std::vector<double> c(2 * (MAXCV + 1)), csel(2 * (MAXCV + 1));
   std::vector<int> isel(MAXCV + 1);
-  auto gs_pass = [&](int j, bool all, double* nrm2_after) -> int {
-    const int nj = j + 1;
+  auto gs_pass = [&](int jt, int nlock, bool all, double* nrm2_after) -> int {
+    const int nj = jt + 1;
     for (int g0 = 0; g0 < nj; g0 += JB) {
       const int nb = std::min(JB, nj - g0);
-      hipLaunchKernelGGL(tr_mdot, dim3(g), dim3(256), 0, st, n, vec(g0), n, nb, vec(j + 1), d_part);
+      hipLaunchKernelGGL(tr_mdot, dim3(g), dim3(256), 0, st, n, vec(g0), n, nb, vec(jt + 1), d_part);
       hipLaunchKernelGGL(tr_colsum, dim3(1), dim3(256), 0, st, d_part, g, 2 * JB, 2 * nb, d_coef + 2 * g0, real ? 1 : 0);
     }
     if (int rca = comm_allreduce_sum(h, d_coef, (size_t)2 * nj, st)) return rca;
@@ -357,7 +345,7 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
     const double thr2 = GS_TAU * GS_TAU * ssum;
     int nsel = 0;
     for (int i = 0; i < nj; ++i)
-      if (all || i + 1 >= j || c[2 * i] * c[2 * i] + c[2 * i + 1] * c[2 * i + 1] > thr2) {
+      if (all || i < nlock || i + 1 >= jt || c[2 * i] * c[2 * i] + c[2 * i + 1] * c[2 * i + 1] > thr2) {
         isel[nsel] = i;
         csel[2 * nsel] = c[2 * i];
         csel[2 * nsel + 1] = c[2 * i + 1];
@@ -365,88 +353,176 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
       }
     HIPCHK(hipMemcpyAsync(d_csel, csel.data(), (size_t)2 * nsel * sizeof(double), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d_isel, isel.data(), (size_t)nsel * sizeof(int), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(tr_maxpy, dim3(g), dim3(256), 0, st, n, V, n, nsel, d_isel, d_csel, vec(j + 1), d_npart);
+    hipLaunchKernelGGL(tr_maxpy, dim3(g), dim3(256), 0, st, n, V, n, nsel, d_isel, d_csel, vec(jt + 1), d_npart);
     hipLaunchKernelGGL(tr_colsum, dim3(1), dim3(256), 0, st, d_npart, g, 1, 1, d_nrm, 0);
     if (int rca = comm_allreduce_sum(h, d_nrm, 1, st)) return rca;
     HIPCHK(hipMemcpyAsync(nrm2_after, d_nrm, sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     return HXV_OK;
   };
+  auto norm2_of = [&](double2* x, double* out) -> int {
+    hipLaunchKernelGGL(tr_scale_nrm, dim3(g), dim3(256), 0, st, n, x, 1.0, d_npart);
+    hipLaunchKernelGGL(tr_colsum, dim3(1), dim3(256), 0, st, d_npart, g, 1, 1, d_nrm, 0);
+    if (int rca = comm_allreduce_sum(h, d_nrm, 1, st)) return rca;  // split sector: projections and norms are sums over the ranks
+    HIPCHK(hipMemcpyAsync(out, d_nrm, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return HXV_OK;
+  };
 
-  std::vector<double> T((size_t)m * m, 0.0), A, theta, S;
-  auto t_at = [&](int i, int j) -> double& { return T[i + (size_t)j * m]; };
-  int k = 0, nmv = 0, meff = m, nconv = 0, ne = neigen;
-  double beta_last = 0.0;
-  for (int it = 0;; ++it) {
-    meff = m;
-    beta_last = 0.0;
-    for (int j = k; j < m; ++j) {
-      int rc = real ? hxv_apply_device_real(h, vec(j), vec(j + 1), st) : apply_slab(h, vec(j), vec(j + 1), st);
-      if (rc) return rc;
-      ++nmv;
-      double w2 = 0.0;
-      rc = gs_pass(j, j == k, &w2);
-      if (rc) return rc;
-      t_at(j, j) = c[2 * j];
-      double c2sum = 0.0;
-      for (int t = 0; t < 2 * (j + 1); ++t) c2sum += c[t] * c[t];
-      double nrm = std::sqrt(std::max(w2, 0.0));
-      // One classical Gram-Schmidt pass leaves an orthogonality error ~ eps*|w_before|/|w_after|.  H v_j always carries
-      // alpha_j v_j + beta_j v_{j-1}, so the textbook DGKS bound 1/sqrt(2) would refine nearly every step; Lanczos only
-      // needs semi-orthogonality (sqrt(eps)), so refine when the norm dropped by more than 10x (error <= ~1e-14 otherwise).
-      if (w2 < DGKS_ETA2 * (c2sum + w2)) {
-        double w3 = 0.0;
-        rc = gs_pass(j, true, &w3);
+  // Thick-restart Lanczos for the `nwant` lowest pairs of H restricted to the orthogonal complement of the `nlock`
+  // LOCKED eigenvectors V[0..nlock) (nlock = 0: H itself).  The active basis is V[nlock..nlock+ma]; on return its first
+  // `ne` vectors are the Ritz vectors of theta[0..ne).
+  std::vector<double> T, A, theta, S;
+  int nmv = 0, nconv = 0, ne = neigen;
+  bool closed = false;  // the Krylov space closed (invariant subspace): every returned pair is exact
+  bool above = false;   // a check round stopped early: the lowest Ritz value minus its residual bound is already above `stop_above`
+  auto trl = [&](int nlock, int nwant, uint64_t seed, double stop_above) -> int {
+    above = false;
+    const int ma = m - nlock;  // active basis size
+    double2* Va = vec(nlock);
+    auto av = [&](int j) { return vec(nlock + j); };
+    T.assign((size_t)ma * ma, 0.0);
+    auto t_at = [&](int i, int j) -> double& { return T[i + (size_t)j * ma]; };
+    // start vector (deterministic hash of the global index; a different seed per round), made orthogonal to the locked set
+    if (real)
+      launch_init_real(h, (double*)av(0), seed, st);
+    else
+      hipLaunchKernelGGL(tr_init, dim3(g), dim3(256), 0, st, n, av(0), seed, h->host.dimup, h->host.pitch, h->host.dw0);
+    double nrm2 = 0.0;
+    if (nlock > 0) {
+      for (int pass = 0; pass < 2; ++pass) {  // V[nlock] plays w: project the locked vectors out, twice
+        int rc = gs_pass(nlock - 1, nlock, true, &nrm2);
         if (rc) return rc;
-        t_at(j, j) += c[2 * j];
-        double nrm_b = std::sqrt(std::max(w3, 0.0));
-        if (nrm_b < 0.5 * nrm) nrm_b = 0.0;  // w lies in span(V): invariant subspace
-        nrm = nrm_b;
       }
-      double tscale = 1.0;
-      for (int a = 0; a <= j; ++a)
-        for (int b = 0; b <= j; ++b) tscale = std::max(tscale, std::fabs(t_at(a, b)));
-      if (nrm <= 1e-13 * tscale) {
-        meff = j + 1;
-        beta_last = 0.0;
+    } else {
+      int rc = norm2_of(av(0), &nrm2);
+      if (rc) return rc;
+    }
+    if (!(nrm2 > 0.0)) return fail(HXV_ERR_STATE, "hxv_eigh_lowest: start vector vanished");
+    hipLaunchKernelGGL(tr_scale_nrm, dim3(g), dim3(256), 0, st, n, av(0), 1.0 / std::sqrt(nrm2), (double*)nullptr);
+    int k = 0, meff = ma;
+    double beta_last = 0.0;
+    for (int it = 0;; ++it) {
+      meff = ma;
+      beta_last = 0.0;
+      for (int j = k; j < ma; ++j) {
+        int rc = real ? hxv_apply_device_real(h, av(j), av(j + 1), st) : apply_slab(h, av(j), av(j + 1), st);
+        if (rc) return rc;
+        ++nmv;
+        double w2 = 0.0;
+        rc = gs_pass(nlock + j, nlock, j == k, &w2);
+        if (rc) return rc;
+        t_at(j, j) = c[2 * (nlock + j)];
+        double c2sum = 0.0;
+        for (int t = 0; t < 2 * (nlock + j + 1); ++t) c2sum += c[t] * c[t];
+        double nrm = std::sqrt(std::max(w2, 0.0));
+        // One classical Gram-Schmidt pass leaves an orthogonality error ~ eps*|w_before|/|w_after|.  H v_j always carries
+        // alpha_j v_j + beta_j v_{j-1}, so the textbook DGKS bound 1/sqrt(2) would refine nearly every step; Lanczos only
+        // needs semi-orthogonality (sqrt(eps)), so refine when the norm dropped by more than 10x (error <= ~1e-14 otherwise).
+        if (w2 < DGKS_ETA2 * (c2sum + w2)) {
+          double w3 = 0.0;
+          rc = gs_pass(nlock + j, nlock, true, &w3);
+          if (rc) return rc;
+          t_at(j, j) += c[2 * (nlock + j)];
+          double nrm_b = std::sqrt(std::max(w3, 0.0));
+          if (nrm_b < 0.5 * nrm) nrm_b = 0.0;  // w lies in span(V): invariant subspace
+          nrm = nrm_b;
+        }
+        double tscale = 1.0;
+        for (int a = 0; a <= j; ++a)
+          for (int b = 0; b <= j; ++b) tscale = std::max(tscale, std::fabs(t_at(a, b)));
+        if (nrm <= 1e-13 * tscale) {
+          meff = j + 1;
+          beta_last = 0.0;
+          break;
+        }
+        if (j + 1 < ma) t_at(j + 1, j) = t_at(j, j + 1) = nrm;
+        beta_last = nrm;
+        hipLaunchKernelGGL(tr_scale_nrm, dim3(g), dim3(256), 0, st, n, av(j + 1), 1.0 / nrm, (double*)nullptr);
+      }
+      A.assign((size_t)meff * meff, 0.0);
+      for (int a = 0; a < meff; ++a)
+        for (int b = 0; b < meff; ++b) A[a + (size_t)b * meff] = t_at(a, b);
+      if (!jacobi_eigh(meff, A, theta, S)) return fail(HXV_ERR_STATE, "hxv_eigh_lowest: projected eigenproblem did not converge");
+      ne = std::min(nwant, meff);
+      nconv = 0;
+      for (int i = 0; i < ne; ++i) {
+        const double res = std::fabs(beta_last * S[(meff - 1) + (size_t)i * meff]);
+        if (res <= tol * std::max(eps23, std::fabs(theta[i]))) ++nconv;
+      }
+      closed = meff < ma;
+      // check rounds only ask "is there a state below stop_above?": Ritz values come down monotonically and the residual
+      // bounds how far the lowest one can still move, so the answer "no" does not need a converged pair
+      if (ne >= 1 && theta[0] - std::fabs(beta_last * S[(meff - 1)]) > stop_above) {
+        above = true;
         break;
       }
-      if (j + 1 < m) t_at(j + 1, j) = t_at(j, j + 1) = nrm;
-      beta_last = nrm;
-      hipLaunchKernelGGL(tr_scale_nrm, dim3(g), dim3(256), 0, st, n, vec(j + 1), 1.0 / nrm, (double*)nullptr);
+      if (nconv == ne || closed || it >= maxrestart) break;
+      k = keep_count(ma, nwant, nconv);
+      HIPCHK(hipMemcpyAsync(d_S, S.data(), (size_t)ma * k * sizeof(double), hipMemcpyHostToDevice, st));
+      launch_rotate(g, st, n, Va, n, ma, k, d_S);
+      HIPCHK(hipMemcpyAsync(av(k), av(ma), (size_t)n * sizeof(double2), hipMemcpyDeviceToDevice, st));
+      HIPCHK(hipStreamSynchronize(st));  // S (host) is reused below
+      std::fill(T.begin(), T.end(), 0.0);
+      for (int i = 0; i < k; ++i) {
+        t_at(i, i) = theta[i];
+        t_at(k, i) = t_at(i, k) = beta_last * S[(ma - 1) + (size_t)i * ma];
+      }
     }
-    A.assign((size_t)meff * meff, 0.0);
-    for (int a = 0; a < meff; ++a)
-      for (int b = 0; b < meff; ++b) A[a + (size_t)b * meff] = t_at(a, b);
-    if (!jacobi_eigh(meff, A, theta, S)) return fail(HXV_ERR_STATE, "hxv_eigh_lowest: projected eigenproblem did not converge");
-    ne = std::min(neigen, meff);
-    nconv = 0;
-    for (int i = 0; i < ne; ++i) {
-      const double res = std::fabs(beta_last * S[(meff - 1) + (size_t)i * meff]);
-      if (res <= tol * std::max(eps23, std::fabs(theta[i]))) ++nconv;
-    }
-    if (nconv == ne || meff < m || it >= maxrestart) break;
-    k = keep_count(m, neigen, nconv);
-    HIPCHK(hipMemcpyAsync(d_S, S.data(), (size_t)m * k * sizeof(double), hipMemcpyHostToDevice, st));
-    launch_rotate(g, st, n, V, n, m, k, d_S);
-    HIPCHK(hipMemcpyAsync(vec(k), vec(m), (size_t)n * sizeof(double2), hipMemcpyDeviceToDevice, st));
-    HIPCHK(hipStreamSynchronize(st));  // S (host) is reused below
-    std::fill(T.begin(), T.end(), 0.0);
-    for (int i = 0; i < k; ++i) {
-      t_at(i, i) = theta[i];
-      t_at(k, i) = t_at(i, k) = beta_last * S[(m - 1) + (size_t)i * m];
+    if (above) return HXV_OK;
+    // Ritz vectors of the wanted pairs to the front of the active basis
+    HIPCHK(hipMemcpyAsync(d_S, S.data(), (size_t)meff * ne * sizeof(double), hipMemcpyHostToDevice, st));
+    launch_rotate(g, st, n, Va, n, meff, ne, d_S);
+    HIPCHK(hipStreamSynchronize(st));
+    return HXV_OK;
+  };
+
+  int rc0 = trl(0, neigen, (uint64_t)0x5EED5EEDull, 1e300);
+  if (rc0) return rc0;
+  // values and (absolute) basis slots of the pairs found so far
+  std::vector<double> fval(theta.begin(), theta.begin() + ne);
+  int nfound = ne;
+  const int nconv0 = nconv, ne0 = ne;
+  const bool closed0 = closed;
+  // A single-vector Krylov method sees ONE vector of an exactly degenerate level (ARPACK included; the reference keeps
+  // every state within gs_threshold of the minimum, ED_DIAG.f90:234-244, and relies on the copies showing up).  So:
+  // lock what was found and look, in its orthogonal complement, for a state BELOW the current neigen-th lowest value --
+  // a second copy of a degenerate level that displaces a higher one; repeat until there is none.
+  if (h->eigh_degenerate && (nconv0 == ne0 || closed0)) {
+    for (int round = 1; round <= 2 * neigen && nfound + std::max(neigen, 1) + 2 <= m && nfound < dim; ++round) {
+      double kth = 1e300;  // fewer pairs than wanted so far (the first Krylov space closed early): take whatever comes
+      if (nfound >= neigen) {
+        std::vector<double> sorted(fval);
+        std::sort(sorted.begin(), sorted.end());
+        kth = sorted[neigen - 1] - 1e-9 * std::max(1.0, std::fabs(sorted[neigen - 1]));
+      }
+      int rc = trl(nfound, 1, (uint64_t)0x5EED5EEDull + 0x9E3779B97F4A7C15ull * (uint64_t)round, kth);
+      if (rc) return rc;
+      if (above) break;                  // nothing below the wanted set
+      if (nconv < 1 && !closed) break;   // could not settle the question within maxrestart: keep what is certain
+      if (!(theta[0] < kth)) break;
+      fval.push_back(theta[0]);  // its vector sits at V[nfound]: locked from now on
+      ++nfound;
     }
   }
+  // the neigen lowest of everything found, ascending, vectors gathered to the end of the basis and copied out
+  std::vector<int> order(nfound);
+  for (int i = 0; i < nfound; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return fval[a] < fval[b]; });
+  ne = std::min(neigen, nfound);
+  theta.assign(ne, 0.0);
+  for (int i = 0; i < ne; ++i) theta[i] = fval[order[i]];
+  nconv = (nconv0 == ne0 || closed0) ? ne : std::min(nconv0, ne);  // (pairs added by the locking rounds had converged)
   for (int i = 0; i < neigen; ++i) evals[i] = i < ne ? theta[i] : 0.0;
   if (nconv_out) *nconv_out = nconv;
   if (nmatvec_out) *nmatvec_out = nmv;
   if (d_evecs) {
-    HIPCHK(hipMemcpyAsync(d_S, S.data(), (size_t)meff * ne * sizeof(double), hipMemcpyHostToDevice, st));
-    launch_rotate(g, st, n, V, n, meff, ne, d_S);
-    if (real)
-      for (int i = 0; i < ne; ++i) launch_to_complex(h, (const double*)vec(i), (double2*)d_evecs + (int64_t)i * nc, st);
-    else
-      HIPCHK(hipMemcpyAsync(d_evecs, V, (size_t)ne * nc * sizeof(double2), hipMemcpyDeviceToDevice, st));
+    for (int i = 0; i < ne; ++i) {
+      if (real)
+        launch_to_complex(h, (const double*)vec(order[i]), (double2*)d_evecs + (int64_t)i * nc, st);
+      else
+        HIPCHK(hipMemcpyAsync((double2*)d_evecs + (int64_t)i * nc, vec(order[i]), (size_t)nc * sizeof(double2), hipMemcpyDeviceToDevice, st));
+    }
     if (ne < neigen) HIPCHK(hipMemsetAsync((double2*)d_evecs + (int64_t)ne * nc, 0, (size_t)(neigen - ne) * nc * sizeof(double2), st));
   }
   HIPCHK(hipStreamSynchronize(st));

@@ -59,6 +59,7 @@ struct hxv_handle {
   int64_t lz_partial_n = 0;
   int lz_fused = 1;                // option "lanczos_fused"
   int lz_graph = 1;                // option "lanczos_graph": fixed-length tridiagonalisations run device-only, three iterations per hipGraph
+  int eigh_degenerate = 1;         // option "eigh_degenerate": hxv_eigh_lowest looks for further copies of degenerate levels (locking rounds)
   int real_vectors = 1;            // option "real_vectors": device Lanczos drivers use real vectors when H and the start vector are real
   int lz_buf_mode = 0;             // layout the d_lz work vectors were last used in (0 complex, 1 real): the pad rows differ
   int last_real = 0;               // did the last device Lanczos run use real vectors (get_option "lanczos_real_last")
