@@ -111,6 +111,14 @@ int finish_create(hxv_handle* h, int device, hxv_handle** out) {
   d.vcol = vcol;
   d.vcol_identity = (s.nranks == 1) ? 1 : 0;
   d.nd = s.nd;
+  d.nd_up = d.nd_dw = nullptr;
+  if (!s.nd_up.empty()) {
+    uint32_t *ndu = nullptr, *ndd = nullptr;
+    HC(h->upload(&ndu, s.nd_up));
+    HC(h->upload(&ndd, s.nd_dw));
+    d.nd_up = ndu;
+    d.nd_dw = ndd;
+  }
   d.real_h = (s.up.real_vals && s.dw.real_vals) ? 1 : 0;
   HC(h->alloc(&h->d_partials, 2 * RED_BLOCKS));
   HC(h->alloc(&h->d_scalars, 8));

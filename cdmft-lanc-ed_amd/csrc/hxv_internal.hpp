@@ -22,6 +22,7 @@ using cplx = std::complex<double>;
 // 0xFFFFFFFF = empty slot.  Layout [k][row] so consecutive rows are consecutive words.
 // ---------------------------------------------------------------------------------------
 constexpr uint32_t ELL_EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t ND_INVALID = 0xFFFFFFFFu;
 constexpr int ELL_SRC_BITS = 20;
 constexpr uint32_t ELL_SRC_MASK = (1u << ELL_SRC_BITS) - 1u;
 constexpr uint32_t ELL_COEF_MASK = 0x3FFu;
@@ -70,6 +71,10 @@ struct SectorHost {
   CrossParams cross;
   NonLocalParams nd;
   std::vector<double> diag_stored; // from_csr path: explicit local diagonal
+  // spH0nd (Jx/Jp) as Kronecker products of one-spin moves on a site: table [nlat*norb*norb][dim] per spin, entry
+  // (il,x,y) of state i = c^+_{il,y} c_{il,x}|i>: target index | sign << 31, ND_INVALID if not applicable
+  // (dw targets are column SLOTS of the gather layout).  Empty: the kernel falls back to searching the basis.
+  std::vector<uint32_t> nd_up, nd_dw;
 };
 
 // host builders (hxv_sector.cpp); return "" on success, else an error message
@@ -113,6 +118,8 @@ struct DevSector {
   const uint32_t* vcol;   // [dimdw] column -> column slot (identity when nranks==1)
   int vcol_identity;
   NonLocalParams nd;
+  const uint32_t* nd_up;  // move tables of the spH0nd block (SectorHost::nd_up / nd_dw), null: search the basis instead
+  const uint32_t* nd_dw;
   int real_h;
 };
 

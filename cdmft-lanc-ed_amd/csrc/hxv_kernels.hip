@@ -120,9 +120,64 @@ __global__ void __launch_bounds__(256) hxv_nonlocal_kernel(DevSector s, const do
   }
 }
 
+// Same block from the one-spin move tables (SectorHost::nd_up / nd_dw): spH0nd = sum over sites and orbital pairs of
+//   Jx [c^+_j c_i]_dw [c^+_i c_j]_up + Jp [c^+_i c_j]_dw [c^+_i c_j]_up,   Kronecker products of two one-body moves,
+// so an element's partner is (up-move of the row) x (dw-move of the column).  One workgroup per (column, 1024 rows): the
+// dw moves of the column are wave-uniform (no work at all for the terms the column's dw state rules out), the up moves
+// come from a coalesced table row, the partner values from ONE other column with rows in increasing order.  No search.
+__global__ void __launch_bounds__(1024) hxv_nonlocal_tab(DevSector s, const double2* __restrict__ v, double2* __restrict__ hv, int rchunks) {
+  const int cl = blockIdx.x / rchunks;                      // local column
+  const int i = (blockIdx.x - cl * rchunks) * 1024 + threadIdx.x;
+  const bool row_ok = i < s.dimup;
+  const int ir = min(i, s.dimup - 1);
+  const int c = cl + s.dw0;
+  const int O = s.nd.norb;
+  double2 acc = make_double2(0.0, 0.0);
+  bool any = false;
+  for (int il = 0; il < s.nd.nlat; ++il)
+    for (int io = 0; io < O; ++io)
+      for (int jo = 0; jo < O; ++jo) {
+        if (io == jo) continue;
+        const int q = (il * O + io) * O + jo, r = (il * O + jo) * O + io;
+        // dw: spin exchange moves i -> j (entry q), pair hopping moves j -> i (entry r); wave-uniform
+        const uint32_t dse = s.nd.jx != 0.0 ? __builtin_amdgcn_readfirstlane(s.nd_dw[(int64_t)q * s.dimdw + c]) : ND_INVALID;
+        const uint32_t dph = s.nd.jp != 0.0 ? __builtin_amdgcn_readfirstlane(s.nd_dw[(int64_t)r * s.dimdw + c]) : ND_INVALID;
+        if (dse == ND_INVALID && dph == ND_INVALID) continue;
+        const uint32_t u = s.nd_up[(int64_t)r * s.dimup + ir];   // up: both terms move j -> i
+        if (u == ND_INVALID) continue;
+        const int jup = (int)(u & 0x7FFFFFFFu);
+        if (dse != ND_INVALID) {
+          const double2 x = v[(int64_t)(dse & 0x7FFFFFFFu) * s.pitch + jup];
+          const double cf = ((u ^ dse) >> 31) ? -s.nd.jx : s.nd.jx;
+          acc.x += cf * x.x;
+          acc.y += cf * x.y;
+          any = true;
+        }
+        if (dph != ND_INVALID) {
+          const double2 x = v[(int64_t)(dph & 0x7FFFFFFFu) * s.pitch + jup];
+          const double cf = ((u ^ dph) >> 31) ? -s.nd.jp : s.nd.jp;
+          acc.x += cf * x.x;
+          acc.y += cf * x.y;
+          any = true;
+        }
+      }
+  if (any && row_ok) {
+    const int64_t o = (int64_t)cl * s.pitch + i;
+    double2 h = hv[o];
+    h.x += acc.x;
+    h.y += acc.y;
+    hv[o] = h;
+  }
+}
+
 hipError_t launch_hxv_nonlocal(const DevSector& s, const double2* v_full, double2* hv_local, hipStream_t st) {
   const int64_t nloc = (int64_t)s.qdw * s.dimup;
   if (nloc == 0 || !s.nd.active) return hipSuccess;
+  if (s.nd_up && s.nd_dw) {
+    const int rchunks = (s.dimup + 1023) / 1024;
+    hipLaunchKernelGGL(hxv_nonlocal_tab, dim3((unsigned)((int64_t)s.qdw * rchunks)), dim3(1024), 0, st, s, v_full, hv_local, rchunks);
+    return hipGetLastError();
+  }
   int64_t blocks = (nloc + 255) / 256;
   if (blocks > 256 * 32) blocks = 256 * 32;
   hipLaunchKernelGGL(hxv_nonlocal_kernel, dim3((unsigned)blocks), dim3(256), 0, st, s, v_full, hv_local);

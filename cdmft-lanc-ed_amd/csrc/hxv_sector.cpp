@@ -314,6 +314,31 @@ std::string build_sector_from_model(const hxv_model& m, int nup, int ndw, int ra
   s.nd.norb = O;
   s.nd.jx = m.jx;
   s.nd.jp = m.jp;
+  s.nd_up.clear();
+  s.nd_dw.clear();
+  if (s.nd.active && panel_rows == 0 && (int64_t)L * O * O * (int64_t)std::max(s.dimup, s.dimdw) <= (int64_t)32 << 20) {
+    auto moves = [&](const std::vector<uint32_t>& map, const std::vector<uint32_t>* slot, std::vector<uint32_t>& tab) {
+      const int dim = (int)map.size();
+      tab.assign((size_t)L * O * O * dim, ND_INVALID);
+      for (int il = 0; il < L; ++il)
+        for (int x = 0; x < O; ++x)
+          for (int y = 0; y < O; ++y) {
+            if (x == y) continue;
+            const int a = mv.imp(il, x), b = mv.imp(il, y);  // c^+_b c_a
+            uint32_t* row = &tab[(size_t)((il * O + x) * O + y) * dim];
+            for (int i = 0; i < dim; ++i) {
+              const uint32_t m0 = map[i];
+              if (!((m0 >> a) & 1u) || ((m0 >> b) & 1u)) continue;
+              const uint32_t m1 = m0 & ~(1u << a), m2 = m1 | (1u << b);
+              const int sg = parity_below(m0, a) ^ parity_below(m1, b);
+              const int j = (int)(std::lower_bound(map.begin(), map.end(), m2) - map.begin());
+              row[i] = (slot ? (*slot)[j] : (uint32_t)j) | ((uint32_t)sg << 31);
+            }
+          }
+    };
+    moves(s.map_up, nullptr, s.nd_up);
+    moves(s.map_dw, &s.vcol, s.nd_dw);
+  }
   s.cross = CrossParams();
   s.cross.norb = O;
   s.cross.nlat = L;

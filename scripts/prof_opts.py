@@ -5,7 +5,7 @@ import torch, hxv
 from hxv import models
 wl = os.environ.get("WORKLOAD", "C3")
 m, (nup, ndw) = {"C2": (models.hm_1dchain(), (6, 6)), "C3": (models.hm_2dsquare(Nbath=3), (8, 8)),
-                 "C4": (models.bhz_2d(Nbath=1), (8, 8)), "C5": (models.hm_ring(6, 2), (9, 9))}[wl]
+                 "C4": (models.bhz_2d(Nbath=1), (8, 8)), "C4K": (models.bhz_2d(Nbath=1, Ust=0.5, Jh=0.1, Jx=0.1, Jp=0.1), (8, 8)), "C5": (models.hm_ring(6, 2), (9, 9))}[wl]
 sec = hxv.HxvSector.from_model(m, nup, ndw)
 for kv in (sys.argv[1] if len(sys.argv) > 1 else "").split(","):
     if kv:
