@@ -28,6 +28,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT / "cdmft-lanc-ed_amd"))
 sys.path.insert(0, str(ROOT))
 
+KERNELS_STAMP = "r02-jobA"   # bumped whenever the product kernels change: profiles/traffic.json is quoted only for the same stamp
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
@@ -69,9 +70,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lanczos", action="store_true", help="skip the Lanczos-iteration timing (N=1; second half of BASELINE's metric)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 path on one GPU)")
-    ap.add_argument("--exchange", default="allgather", choices=["allgather", "alltoall"],
+    ap.add_argument("--exchange", default="allgather", choices=["allgather", "alltoall", "halo"],
                     help="N>1: allgather = one RCCL all-gather per product (BASELINE's mandated exchange, default); "
-                         "alltoall = the reference's own two transposes per product (lower traffic)")
+                         "alltoall = the reference's own two transposes per product (lower traffic); "
+                         "halo = only the columns H_dw couples across ranks travel (one all-to-all with per-peer counts)")
     ap.add_argument("--parallelism", default="dimdw", choices=["dimdw", "sectors"],
                     help="N>1: dimdw = ONE sector split along DimDw with an exchange per product (BASELINE's scheme, strong scaling, default); "
                          "sectors = every GPU runs its own whole sector, no exchange (how independent sectors / Green's-function channels "
@@ -111,6 +113,9 @@ def main():
         model, (nup, ndw) = models.hm_ring(6, 2), (9, 9)
 
     by_sector = world > 1 and args.parallelism == "sectors"
+    halo = world > 1 and args.exchange == "halo" and not by_sector
+    if halo:
+        hxv.set_exchange_default("halo")          # the handle's gathered-vector layout is chosen when the sector is opened
     if by_sector:
         sec = hxv.HxvSector.from_model(model, nup, ndw, device=local_rank)      # the whole sector on every GPU
     else:
@@ -119,7 +124,13 @@ def main():
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     v_local = torch.randn(Nloc, dtype=torch.float64, device=dev, generator=g) + 1j * torch.randn(Nloc, dtype=torch.float64, device=dev, generator=g)
     hv_local = torch.empty(Nloc, dtype=torch.complex128, device=dev)
+    hxv.set_exchange_default("allgather")
     sh = hxv.ShardedHxv(sec.DimUp, sec.DimDw, 0 if by_sector else rank, 1 if by_sector else world, sec.apply_device, pitch=sec.pitch)
+    hx = None
+    if halo:
+        rp, cols, _ = sec.csr("dw")
+        need, send = hxv.halo_plan(rp, cols - 1, sec.DimDw, world)
+        hx = hxv.HaloHxv(sec.DimUp, sec.DimDw, rank, world, need, send, sec.apply_device, pitch=sec.pitch, stage_on_host=(args.backend != "nccl"))
     if world > 1 and args.exchange == "alltoall" and not by_sector:
         nrows = hxv.dw_split(sec.DimUp, rank, world)[0]
         panel = hxv.HxvSector.dw_panel(model, nup, ndw, nrows, device=local_rank)
@@ -129,6 +140,8 @@ def main():
     def step():
         if world > 1 and args.exchange == "alltoall" and not by_sector:
             th(Nloc, v_local, hv_local)
+        elif halo:
+            hx(Nloc, v_local, hv_local)
         else:
             sh(Nloc, v_local, hv_local)
 
@@ -164,21 +177,24 @@ def main():
     value = (world if by_sector else 1) * 32.0 * Dim / (ms_step * 1e-3) / 1e9   # sectors: every rank finished a whole product
 
     # roofline of the product's kernels on this rank: HIP events on the stream they are launched on
-    vfull = sh.gather(v_local)
+    vfull = hx.exchange(v_local) if halo else sh.gather(v_local)
     torch.cuda.synchronize()
     k_ms = sec.time_apply(vfull, hv_local, max(5, min(args.steps, 20)))
     achieved = 32.0 * sec.vecDim / (k_ms * 1e-3) / 1e9
-    traffic = None
+    # HBM-side bytes per product come from a separate rocprofv3 --pmc collection (scripts/prof_traffic.sh ->
+    # profiles/traffic.json); the figure is only quoted for the kernel build it was collected on (its `kernels` stamp)
+    traffic, traffic_src = None, None
     tf = ROOT / "profiles" / "traffic.json"
     if tf.exists():
         try:
             tj = json.loads(tf.read_text())
-            if tj.get("workload") == args.workload and tj.get("n_gpus", 1) == world:
+            if tj.get("workload") == args.workload and tj.get("n_gpus", 1) == world and tj.get("kernels_stamp") == KERNELS_STAMP:
                 traffic = tj.get("hbm_bytes_per_product")
+                traffic_src = f"profiles/traffic.json (rocprofv3 --pmc, kernels {KERNELS_STAMP})"
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": traffic, "kernel": "hxv_pass_up + hxv_pass_dw (one product)", "kernel_ms": round(k_ms, 4),
+                "traffic": traffic, "traffic_source": traffic_src, "kernel": "hxv_up_job + hxv_pass_dw (one product)", "kernel_ms": round(k_ms, 4),
                 "algorithmic_bytes": 32 * sec.vecDim}
 
     ns = {"C2": 12, "C3": 16, "C4": 16, "C5": 18}[args.workload]
@@ -194,7 +210,13 @@ def main():
         # what the exchange moves into every GPU per product: the xGMI links, not HBM, bound the N>1 product
         slab = 16 * sh.slab
         out["config"]["exchange"] = args.exchange
-        out["config"]["exchange_ingest_bytes_per_gpu"] = (world - 1) * slab if args.exchange == "allgather" else 2 * (world - 1) * slab // world
+        out["config"]["exchange_ingest_bytes_per_gpu"] = ((world - 1) * slab if args.exchange == "allgather" else
+                                                          16 * sec.pitch * hx.ingest_columns if halo else 2 * (world - 1) * slab // world)
+    if world == 1:
+        # what each of the three exchanges would move into one GPU per product at 8 ranks
+        rp, cols, _ = sec.csr("dw")
+        need8, _ = hxv.halo_plan(rp, cols - 1, sec.DimDw, 8)
+        out["config"]["exchange_ingest_bytes_per_gpu_at_8_ranks"] = hxv.exchange_ingest_bytes(sec.DimUp, sec.DimDw, 8, need8)
     if not args.no_lanczos and world == 1:
         # full iterations: product + fused recurrence + 2 reductions, vectors in HBM.  Headline = complex(8) vectors, the
         # reference's data type; when H is real (C2, C3) the device drivers also run on real vectors (half the bytes).

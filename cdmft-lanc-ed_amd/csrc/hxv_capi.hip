@@ -107,7 +107,7 @@ int finish_create(hxv_handle* h, int device, hxv_handle** out) {
   d.pitch = s.pitch;
   d.qdw = s.qdw;
   d.dw0 = s.dw0;
-  d.slab0 = s.rank * s.cmax;
+  d.slab0 = s.exchange == 1 ? 0 : s.rank * s.cmax;
   d.vcol = vcol;
   d.vcol_identity = (s.nranks == 1) ? 1 : 0;
   d.nd = s.nd;
@@ -217,7 +217,31 @@ int hxv_destroy(hxv_handle* h) {
 }
 
 int64_t hxv_vecdim(const hxv_handle* h) { return h ? (int64_t)h->host.qdw * h->host.dimup : -1; }
-int64_t hxv_fullvec_elems(const hxv_handle* h) { return h ? (int64_t)h->host.nranks * h->host.cmax * h->host.pitch : -1; }
+int64_t hxv_fullvec_elems(const hxv_handle* h) {
+  if (!h) return -1;
+  if (h->host.exchange == 1) return (int64_t)(h->host.qdw + (int64_t)h->host.halo_cols.size()) * h->host.pitch;
+  return (int64_t)h->host.nranks * h->host.cmax * h->host.pitch;
+}
+int32_t hxv_exchange_mode(const hxv_handle* h) { return h ? h->host.exchange : -1; }
+int hxv_halo_counts(const hxv_handle* h, int32_t* recv_counts, int32_t* send_counts) {
+  if (!h || h->host.exchange != 1) return fail(HXV_ERR_STATE, "hxv_halo_counts: the handle does not use the halo exchange");
+  for (int r = 0; r < h->host.nranks; ++r) {
+    if (recv_counts) recv_counts[r] = h->host.halo_ptr[r + 1] - h->host.halo_ptr[r];
+    if (send_counts) send_counts[r] = h->host.send_ptr[r + 1] - h->host.send_ptr[r];
+  }
+  return HXV_OK;
+}
+int hxv_halo_lists(const hxv_handle* h, int32_t* recv_cols, int32_t* send_cols) {
+  if (!h || h->host.exchange != 1) return fail(HXV_ERR_STATE, "hxv_halo_lists: the handle does not use the halo exchange");
+  if (recv_cols) std::copy(h->host.halo_cols.begin(), h->host.halo_cols.end(), recv_cols);
+  if (send_cols) std::copy(h->host.send_cols.begin(), h->host.send_cols.end(), send_cols);
+  return HXV_OK;
+}
+int hxv_set_exchange_default(int32_t mode) {
+  if (mode < 0 || mode > 1) return fail(HXV_ERR_ARG, "exchange mode must be 0 (all-gather) or 1 (halo)");
+  set_default_exchange(mode);
+  return HXV_OK;
+}
 int64_t hxv_localvec_elems(const hxv_handle* h) { return h ? (int64_t)h->host.qdw * h->host.pitch : -1; }
 int32_t hxv_pitch(const hxv_handle* h) { return h ? h->host.pitch : -1; }
 

@@ -28,6 +28,10 @@ struct Rccl {
   decltype(&ncclAllGather) AllGather = nullptr;
   decltype(&ncclAllReduce) AllReduce = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
   std::string err;
 };
 Rccl* rccl() {
@@ -51,6 +55,10 @@ Rccl* rccl() {
     SYM(AllGather, ncclAllGather)
     SYM(AllReduce, ncclAllReduce)
     SYM(GetErrorString, ncclGetErrorString)
+    SYM(Send, ncclSend)
+    SYM(Recv, ncclRecv)
+    SYM(GroupStart, ncclGroupStart)
+    SYM(GroupEnd, ncclGroupEnd)
 #undef SYM
   });
   return &r;
@@ -79,6 +87,32 @@ int apply_slab(hxv_handle* h, const double2* d_v_local, double2* d_hv_local, hip
   if (s.nranks == 1 && !h->comm) return hxv_apply_device(h, d_v_local, d_hv_local, st);
   if (!h->comm) return fail(HXV_ERR_STATE, "split sector without a communicator: call hxv_comm_init after opening the sector");
   HIPCHK(hipSetDevice(h->device));
+  if (s.exchange == 1) {
+    // HALO exchange: only the columns H_dw couples to another rank's rows travel -- packed per destination, one grouped
+    // send/receive; they land behind the local slab, where the column -> slot table of this layout expects them
+    const size_t nfull = (size_t)(s.qdw + s.halo_cols.size()) * s.pitch;
+    if (!h->d_gather) {
+      HIPCHK(pool_alloc(h->device, std::max<size_t>(nfull, 1) * sizeof(double2), (void**)&h->d_gather));
+      HIPCHK(pool_alloc(h->device, std::max<size_t>(s.send_cols.size(), 1) * s.pitch * sizeof(double2), (void**)&h->d_send));
+      HIPCHK(hipMalloc((void**)&h->d_send_cols, std::max<size_t>(s.send_cols.size(), 1) * sizeof(int32_t)));
+      HIPCHK(hipMemcpy(h->d_send_cols, s.send_cols.data(), s.send_cols.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipMemcpyAsync(h->d_gather, d_v_local, (size_t)s.qdw * s.pitch * sizeof(double2), hipMemcpyDeviceToDevice, st));
+    hipError_t pe = launch_pack_columns(d_v_local, h->d_send, h->d_send_cols, (int)s.send_cols.size(), s.pitch, st);
+    if (pe != hipSuccess) return fail(HXV_ERR_HIP, std::string("pack kernel: ") + hipGetErrorString(pe));
+    Rccl* r = rccl();
+    ncclResult_t e = r->GroupStart();
+    for (int p = 0; p < s.nranks && e == ncclSuccess; ++p) {
+      if (p == s.rank) continue;
+      const size_t ns = (size_t)(s.send_ptr[p + 1] - s.send_ptr[p]) * s.pitch, nr = (size_t)(s.halo_ptr[p + 1] - s.halo_ptr[p]) * s.pitch;
+      if (ns) e = r->Send(h->d_send + (size_t)s.send_ptr[p] * s.pitch, ns * 2, ncclFloat64, p, (ncclComm_t)h->comm, st);
+      if (nr && e == ncclSuccess) e = r->Recv(h->d_gather + (size_t)(s.qdw + s.halo_ptr[p]) * s.pitch, nr * 2, ncclFloat64, p, (ncclComm_t)h->comm, st);
+    }
+    ncclResult_t e2 = r->GroupEnd();
+    if (e != ncclSuccess || e2 != ncclSuccess) return nccl_fail("halo send/recv", e != ncclSuccess ? e : e2);
+    h->n_exchange++;
+    return hxv_apply_device(h, h->d_gather, d_hv_local, st);
+  }
   const size_t slot = (size_t)s.cmax * s.pitch;
   if (!h->d_gather) {
     HIPCHK(pool_alloc(h->device, slot * s.nranks * sizeof(double2), (void**)&h->d_gather));
@@ -101,6 +135,14 @@ void comm_release(hxv_handle* h) {
   if (h->d_gather) {
     pool_free(h->device, h->d_gather);
     h->d_gather = nullptr;
+  }
+  if (h->d_send) {
+    pool_free(h->device, h->d_send);
+    h->d_send = nullptr;
+  }
+  if (h->d_send_cols) {
+    (void)hipFree(h->d_send_cols);
+    h->d_send_cols = nullptr;
   }
 }
 

@@ -66,7 +66,9 @@ struct hxv_handle {
   int kernel = 1;
   // split sector: RCCL communicator over the nranks handles (hxv_comm_init) and the gathered vector
   void* comm = nullptr;          // ncclComm_t
-  double2* d_gather = nullptr;   // nranks * cmax * pitch elements (all-gather layout)
+  double2* d_gather = nullptr;   // nranks * cmax * pitch elements (all-gather layout) / (qdw + halo) * pitch (halo layout)
+  double2* d_send = nullptr;     // halo exchange: packed columns, grouped by destination rank
+  int32_t* d_send_cols = nullptr;
   int64_t n_exchange = 0;
   int64_t n_apply = 0;
   int64_t device_bytes = 0;

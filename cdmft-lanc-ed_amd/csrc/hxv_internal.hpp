@@ -63,6 +63,13 @@ struct SectorHost {
   int rank = 0, nranks = 1, qdw = 0, dw0 = 0;
   int cmax = 0;                     // columns per rank in the padded all-gather layout
   std::vector<uint32_t> vcol;       // [dimdw] column -> column slot in the padded layout
+  // HALO exchange (exchange == 1): the gathered vector holds this rank's qdw columns (slots 0..qdw-1) followed by only
+  // those columns of other ranks that H_dw couples to its rows, ascending (= grouped by owner rank)
+  int exchange = 0;                 // 0 all-gather layout, 1 halo layout
+  std::vector<int32_t> halo_cols;   // global columns received, in slot order
+  std::vector<int32_t> halo_ptr;    // [nranks+1] offsets into halo_cols by owner rank
+  std::vector<int32_t> send_cols;   // LOCAL column indices to send, grouped by destination rank
+  std::vector<int32_t> send_ptr;    // [nranks+1]
   int64_t ishift = 0;
   std::vector<uint32_t> map_up, map_dw;
   SpinOp up, dw;
@@ -85,6 +92,9 @@ std::string build_sector_from_csr(int dimup, int dimdw, const int64_t* up_rp, co
 std::string build_ell(SpinOp& op);
 void dw_split(int dimdw, int rank, int nranks, int& qdw, int& dw0);
 void make_vcol(SectorHost& s);
+void make_halo(SectorHost& s);     // needs s.dw (CSR); replaces the all-gather layout by the halo layout
+int default_exchange();            // hxv_set_exchange_default / HXV_EXCHANGE=halo
+void set_default_exchange(int mode);
 std::vector<uint32_t> translate_ell_src(const std::vector<uint32_t>& ell, const std::vector<uint32_t>& vcol);
 double host_diag_element(const SectorHost& s, int iup, int idw);
 
@@ -129,6 +139,8 @@ hipError_t launch_hxv_naive(const DevSector& s, const double2* v_full, double2* 
 hipError_t launch_ladder(const uint32_t* map_from, int dim_from, const uint32_t* map_to, int dim_to, int pitch_from, int dimup_to,
                          int pitch_to, int dimdw_to, int orbital, int spin, int create, const double2* psi, double2* out, hipStream_t st,
                          double2 coef = double2{1.0, 0.0}, int accumulate = 0);
+// d_out[k*pitch + i] = d_in[cols[k]*pitch + i]: the columns a peer needs, packed for the halo exchange
+hipError_t launch_pack_columns(const double2* d_in, double2* d_out, const int32_t* d_cols, int ncols, int pitch, hipStream_t st);
 hipError_t launch_hxv_nonlocal(const DevSector& s, const double2* v_full, double2* hv_local, hipStream_t st);
 
 }  // namespace hxv

@@ -170,6 +170,19 @@ __global__ void __launch_bounds__(1024) hxv_nonlocal_tab(DevSector s, const doub
   }
 }
 
+__global__ void __launch_bounds__(256) pack_columns_kernel(const double2* __restrict__ in, double2* __restrict__ out, const int32_t* __restrict__ cols,
+                                                          int pitch) {
+  const double2* __restrict__ src = in + (int64_t)cols[blockIdx.x] * pitch;
+  double2* __restrict__ dst = out + (int64_t)blockIdx.x * pitch;
+  for (int i = threadIdx.x; i < pitch; i += 256) dst[i] = src[i];
+}
+
+hipError_t launch_pack_columns(const double2* d_in, double2* d_out, const int32_t* d_cols, int ncols, int pitch, hipStream_t st) {
+  if (ncols <= 0) return hipSuccess;
+  hipLaunchKernelGGL(pack_columns_kernel, dim3((unsigned)ncols), dim3(256), 0, st, d_in, d_out, d_cols, pitch);
+  return hipGetLastError();
+}
+
 hipError_t launch_hxv_nonlocal(const DevSector& s, const double2* v_full, double2* hv_local, hipStream_t st) {
   const int64_t nloc = (int64_t)s.qdw * s.dimup;
   if (nloc == 0 || !s.nd.active) return hipSuccess;

@@ -12,6 +12,7 @@
 // orbital hops (a <- b, amplitude), then applied to every basis state with bit arithmetic.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <map>
 
 #include "hxv_internal.hpp"
@@ -179,6 +180,58 @@ void make_vcol(SectorHost& s) {
   }
 }
 
+namespace {
+int g_exchange_default = -1;
+}
+int default_exchange() {
+  if (g_exchange_default >= 0) return g_exchange_default;
+  const char* e = std::getenv("HXV_EXCHANGE");
+  return (e && std::string(e) == "halo") ? 1 : 0;
+}
+void set_default_exchange(int mode) { g_exchange_default = mode; }
+
+// Halo layout: which columns of the other ranks do the rows of H_dw owned by each rank reference?  Every rank knows the
+// whole one-spin matrix, so it derives its own receive list and what every other rank expects from it without talking.
+void make_halo(SectorHost& s) {
+  const int P = s.nranks;
+  std::vector<int> owner(s.dimdw), first(P + 1, 0);
+  for (int r = 0; r < P; ++r) {
+    int q, c0;
+    dw_split(s.dimdw, r, P, q, c0);
+    first[r] = c0;
+    for (int c = 0; c < q; ++c) owner[c0 + c] = r;
+  }
+  first[P] = s.dimdw;
+  auto needed_by = [&](int r) {
+    std::vector<char> mark(s.dimdw, 0);
+    for (int c = first[r]; c < first[r + 1]; ++c)
+      for (int64_t p = s.dw.rowptr[c]; p < s.dw.rowptr[c + 1]; ++p)
+        if (owner[s.dw.cols[p]] != r) mark[s.dw.cols[p]] = 1;
+    std::vector<int32_t> out;
+    for (int c = 0; c < s.dimdw; ++c)
+      if (mark[c]) out.push_back(c);
+    return out;
+  };
+  s.halo_cols = needed_by(s.rank);
+  s.halo_ptr.assign(P + 1, 0);
+  for (int32_t c : s.halo_cols) s.halo_ptr[owner[c] + 1]++;
+  for (int r = 0; r < P; ++r) s.halo_ptr[r + 1] += s.halo_ptr[r];
+  s.send_cols.clear();
+  s.send_ptr.assign(P + 1, 0);
+  for (int r = 0; r < P; ++r) {
+    if (r != s.rank)
+      for (int32_t c : needed_by(r))
+        if (owner[c] == s.rank) s.send_cols.push_back(c - s.dw0);
+    s.send_ptr[r + 1] = (int32_t)s.send_cols.size();
+  }
+  // columns nobody here references keep slot 0: pass B's tile loads touch every column of a block that holds a local
+  // column, but only referenced columns are ever gathered from the tile
+  s.vcol.assign(s.dimdw, 0u);
+  for (int c = 0; c < s.qdw; ++c) s.vcol[s.dw0 + c] = (uint32_t)c;
+  for (size_t k = 0; k < s.halo_cols.size(); ++k) s.vcol[s.halo_cols[k]] = (uint32_t)(s.qdw + k);
+  s.exchange = 1;
+}
+
 std::vector<uint32_t> translate_ell_src(const std::vector<uint32_t>& ell, const std::vector<uint32_t>& vcol) {
   std::vector<uint32_t> out(ell);
   for (auto& e : out)
@@ -269,6 +322,8 @@ std::string build_sector_from_model(const hxv_model& m, int nup, int ndw, int ra
     apply_hops(s.map_up, hops_up, s.up);
   }
   apply_hops(s.map_dw, hops_dw, s.dw);
+  // (the spH0nd block reaches columns that H_dw does not: it keeps the all-gather layout)
+  if (nranks > 1 && panel_rows == 0 && default_exchange() == 1 && !(m.norb > 1 && (m.jx != 0.0 || m.jp != 0.0))) make_halo(s);
   e = build_ell(s.up);
   if (!e.empty()) return e;
   e = build_ell(s.dw);

@@ -85,6 +85,101 @@ class ShardedHxv:
         return self.apply_local(self.gather(v_local), hv_local)
 
 
+def halo_plan(rowptr, cols, DimDw: int, size: int):
+    """Halo exchange plan from the one-spin matrix H_dw (CSR, 0-based cols) and the reference's DimDw split:
+    need[r] = sorted global columns of OTHER ranks that the rows owned by rank r reference (what r receives, in slot
+    order; ascending = grouped by owner), send[r][p] = LOCAL column indices rank r sends to rank p.  Pure numpy: the same
+    plan the engine derives in C++ (hxv_halo_lists), used by the CPU tests and for the exchange-volume report."""
+    import numpy as np
+
+    rowptr = np.asarray(rowptr)
+    cols = np.asarray(cols)
+    owner = np.empty(DimDw, dtype=np.int64)
+    first = []
+    for r in range(size):
+        q, c0 = dw_split(DimDw, r, size)
+        owner[c0:c0 + q] = r
+        first.append(c0)
+    first.append(DimDw)
+    need = []
+    for r in range(size):
+        src = np.unique(cols[rowptr[first[r]]:rowptr[first[r + 1]]])
+        need.append(src[owner[src] != r])
+    send = [[(need[p][owner[need[p]] == r] - first[r]) for p in range(size)] for r in range(size)]
+    return need, send
+
+
+def exchange_ingest_bytes(DimUp: int, DimDw: int, size: int, need=None, elem_bytes: int = 16):
+    """Bytes one GPU receives per product (largest over the ranks) for the three exchanges of DESIGN.md section 4."""
+    slab = -(-DimDw // size)
+    out = {"allgather": (size - 1) * slab * DimUp * elem_bytes,
+           "alltoall": 2 * (size - 1) * slab * (-(-DimUp // size)) * elem_bytes}
+    if need is not None:
+        out["halo"] = max(len(n) for n in need) * DimUp * elem_bytes
+    return out
+
+
+class HaloHxv:
+    """spHtimesV_p for MpiStatus=T with the HALO exchange: each product moves only the columns of other ranks that
+    H_dw couples to this rank's rows (one all_to_all_single with per-peer counts; RCCL send/recv underneath), instead
+    of all-gathering every slab.  The gathered buffer has the engine's halo layout (include/hxv.h): the local slab
+    first, then the received columns in ascending order; apply_local(v_halo, hv_local) is the per-rank product
+    (HxvSector.apply_device of a handle created in halo mode; CPU tests inject a stand-in)."""
+
+    def __init__(self, DimUp: int, DimDw: int, rank: int, size: int, need, send, apply_local, group=None, pitch: int | None = None,
+                 stage_on_host: bool = False):
+        import torch.distributed as dist
+
+        self.dist, self.group = dist, group
+        self.stage_on_host = stage_on_host   # rehearsals with gloo on CUDA tensors: run the collective on host copies
+        self.DimUp, self.DimDw, self.rank, self.size = DimUp, DimDw, rank, size
+        self.pitch = DimUp if pitch is None else pitch
+        self.qdw, self.dw0 = dw_split(DimDw, rank, size)
+        self.Nloc = self.qdw * self.pitch
+        self.need = need[rank]                       # global columns received, slot order
+        self.send = send[rank]                       # per destination: local column indices
+        owner_first = [dw_split(DimDw, r, size)[1] for r in range(size)] + [DimDw]
+        self.recv_counts = [int(((self.need >= owner_first[r]) & (self.need < owner_first[r + 1])).sum()) for r in range(size)]
+        self.send_counts = [len(self.send[p]) for p in range(size)]
+        self.apply_local = apply_local
+        self._full = None
+        self._idx = None
+
+    @property
+    def ingest_columns(self) -> int:
+        return len(self.need)
+
+    def exchange(self, v_local):
+        import torch
+
+        assert v_local.numel() == self.Nloc
+        nfull = (self.qdw + len(self.need)) * self.pitch
+        if self._full is None or self._full.device != v_local.device:
+            self._full = torch.zeros(nfull, dtype=v_local.dtype, device=v_local.device)
+            cat = [torch.as_tensor(x, dtype=torch.long) for x in self.send if len(x)]
+            self._idx = (torch.cat(cat) if cat else torch.zeros(0, dtype=torch.long)).to(v_local.device)
+        self._full[: self.Nloc].copy_(v_local)
+        if self.size > 1:
+            packed = v_local.view(self.qdw, self.pitch)[self._idx].contiguous().view(-1)
+            out = self._full[self.Nloc:]
+            o = torch.view_as_real(out).view(-1) if out.is_complex() else out
+            i = torch.view_as_real(packed).view(-1) if packed.is_complex() else packed
+            k = 2 * self.pitch if out.is_complex() else self.pitch
+            osp, isp = [c * k for c in self.recv_counts], [c * k for c in self.send_counts]
+            if self.stage_on_host and o.is_cuda:
+                oc = torch.empty(o.shape, dtype=o.dtype)
+                self.dist.all_to_all_single(oc, i.cpu(), osp, isp, group=self.group)
+                o.copy_(oc)
+            else:
+                self.dist.all_to_all_single(o, i, osp, isp, group=self.group)
+        return self._full
+
+    def __call__(self, Nloc: int, v_local, hv_local):
+        if Nloc != self.Nloc:
+            raise ValueError("spMatVec_mpi_cc ERROR: Nloc /= DimUp*mpiQdw")
+        return self.apply_local(self.exchange(v_local), hv_local)
+
+
 class TransposedHxv:
     """The reference's own exchange (two all-to-all transposes per product, ED_HAMILTONIAN_SPARSE_HxV.f90:272-296,
     ED_HAMILTONIAN_COMMON.f90:30-94) on device tensors -- the lower-traffic alternative to ShardedHxv's all-gather:

@@ -44,6 +44,7 @@ EXPORTS = [
     "hxv_apply_device", "hxv_apply_device_real", "hxv_real_vectors_available", "hxv_pitch_real", "hxv_realvec_elems", "hxv_fullvec_elems", "hxv_localvec_elems", "hxv_pitch", "hxv_time_apply", "hxv_lanczos_tridiag", "hxv_lanczos_eigh", "hxv_lanczos_tridiag_host", "hxv_lanczos_eigh_host", "hxv_eigh_lowest", "hxv_eigh_lowest_host", "hxv_time_lanczos", "hxv_apply_ladder", "hxv_apply_ladder_axpy", "hxv_get_maps",
     "hxv_nnz", "hxv_get_csr", "hxv_get_diag", "hxv_set_option", "hxv_get_option", "hxv_get_stats", "hxv_pool_trim", "hxv_pool_stats", "hxv_last_error",
     "hxv_version", "hxv_comm_unique_id", "hxv_comm_init", "hxv_comm_free", "hxv_apply_device_slab", "hxv_exchange_count",
+    "hxv_set_exchange_default", "hxv_exchange_mode", "hxv_halo_counts", "hxv_halo_lists",
 ]
 
 _lib = None
@@ -115,8 +116,19 @@ def load_library():
     L.hxv_apply_device_slab.argtypes = [vp, vp, vp, vp]
     L.hxv_exchange_count.argtypes = [vp]
     L.hxv_exchange_count.restype = i64
+    L.hxv_set_exchange_default.argtypes = [i32]
+    L.hxv_exchange_mode.argtypes = [vp]
+    L.hxv_exchange_mode.restype = i32
+    L.hxv_halo_counts.argtypes = [vp, pi32, pi32]
+    L.hxv_halo_lists.argtypes = [vp, pi32, pi32]
     _lib = L
     return L
+
+
+def set_exchange_default(mode: str | int):
+    """Exchange of the split sectors created from now on: "allgather" / 0 [default] or "halo" / 1 (include/hxv.h)."""
+    m = {"allgather": 0, "halo": 1}.get(mode, mode)
+    _chk(load_library().hxv_set_exchange_default(int(m)), "hxv_set_exchange_default")
 
 
 def pool_trim(device: int = -1):
@@ -343,6 +355,20 @@ class HxvSector:
     @property
     def exchange_count(self) -> int:
         return load_library().hxv_exchange_count(self._h)
+
+    @property
+    def exchange_mode(self) -> str:
+        return "halo" if load_library().hxv_exchange_mode(self._h) == 1 else "allgather"
+
+    def halo_lists(self, nranks: int):
+        """(recv_counts[nranks], send_counts[nranks], recv_cols (global, slot order), send_cols (local, by destination))."""
+        rc = np.zeros(nranks, dtype=np.int32)
+        sc = np.zeros(nranks, dtype=np.int32)
+        _chk(load_library().hxv_halo_counts(self._h, _p(rc, C.c_int32), _p(sc, C.c_int32)), "hxv_halo_counts")
+        rcols = np.zeros(max(int(rc.sum()), 1), dtype=np.int32)
+        scols = np.zeros(max(int(sc.sum()), 1), dtype=np.int32)
+        _chk(load_library().hxv_halo_lists(self._h, _p(rcols, C.c_int32), _p(scols, C.c_int32)), "hxv_halo_lists")
+        return rc, sc, rcols[: int(rc.sum())], scols[: int(sc.sum())]
 
     # -- REAL-vector mode (H real; include/hxv.h) ----------------------------------------------
     @property

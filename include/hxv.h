@@ -97,7 +97,19 @@ int hxv_comm_free(hxv_handle *h);
 /* d_hv_local = (H v)|slab from this rank's slab d_v_local (hxv_localvec_elems() elements each, padded device layout):
  * exchange + product, asynchronous on `stream`.  nranks==1 without a communicator: the plain product.              */
 int hxv_apply_device_slab(hxv_handle *h, const void *d_v_local, void *d_hv_local, void *stream);
-int64_t hxv_exchange_count(const hxv_handle *h); /* all-gathers since creation */
+int64_t hxv_exchange_count(const hxv_handle *h); /* exchanges since creation */
+/* HALO exchange (the lower-traffic alternative, replaces the transposes of ED_HAMILTONIAN_COMMON.f90:30-94 differently): with
+ * the reference's own DimDw split a rank's rows of H_dw reference only a subset of the other ranks' columns (C3, 8 ranks:
+ * 4.2 slabs instead of the 7 an all-gather moves).  A handle created in halo mode (hxv_set_exchange_default(1) or
+ * HXV_EXCHANGE=halo before the create call; not with the spH0nd block) expects d_v_full of hxv_apply_device in the HALO
+ * LAYOUT: its own qdw columns first, then the columns listed by hxv_halo_lists (ascending = grouped by owner rank);
+ * hxv_fullvec_elems() reports the length.  hxv_apply_host / hxv_apply_device_slab / the drivers then exchange exactly
+ * those columns (grouped ncclSend/ncclRecv).  recv_counts/send_counts: columns per peer rank; recv_cols: global column
+ * indices in slot order; send_cols: LOCAL column indices grouped by destination rank.                                */
+int hxv_set_exchange_default(int32_t mode); /* 0 all-gather [default], 1 halo; applies to handles created afterwards */
+int32_t hxv_exchange_mode(const hxv_handle *h);
+int hxv_halo_counts(const hxv_handle *h, int32_t *recv_counts, int32_t *send_counts);
+int hxv_halo_lists(const hxv_handle *h, int32_t *recv_cols, int32_t *send_cols);
 
 /* Device-resident product.  d_v_full: the FULL vector in the ALL-GATHER LAYOUT: nranks slabs of
  * cmax*pitch elements each, cmax = ceil(DimDw/nranks), slab r holding rank r's columns (ranks

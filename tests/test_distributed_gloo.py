@@ -208,3 +208,82 @@ def test_sharded_lanczos_gloo(world, sector, tmp_path):
     assert np.abs(Xf.conj().T @ Xf - np.eye(3)).max() < 1e-11 and np.linalg.norm(H @ Xf - Xf * res[0]["ev"], axis=0).max() < 1e-9
     # the slabs of the start vector are the slabs of the single-GPU driver's deterministic start vector
     assert np.array_equal(np.concatenate([r["start"] for r in res]), start_vector(s.Dim))
+
+
+def _worker_halo(rank, world, port, nup, ndw, out):
+    import torch
+    import torch.distributed as dist
+    import scipy.sparse as sp
+    import hxv
+    from hxv import models
+    from oracle.oracle import OracleSector
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = models.hm_1dchain(Nlat=2, Nbath=2, eps_bath=[0.3, 0.6])
+    orc = OracleSector(m, nup, ndw, rank, world)
+    du, dd, q = orc.DimUp, orc.DimDw, orc.mpiQdw
+    rp, cols, vals = orc.csr("up")
+    Hup = sp.csr_matrix((vals, cols - 1, rp), shape=(du, du))
+    rp, cols, vals = orc.csr("dw")
+    Hdw = sp.csr_matrix((vals, cols - 1, rp), shape=(dd, dd))
+    need, send = hxv.halo_plan(rp, cols - 1, dd, world)
+    c0 = orc.mpiIshift // du
+    have = np.concatenate([np.arange(c0, c0 + q), need[rank]])          # global column of every slot of the halo layout
+
+    def apply_local(v_halo, hv_local):  # CPU stand-in for HxvSector.apply_device of a halo-mode handle (same contract)
+        Vh = v_halo.numpy().reshape(len(have), du)                      # [slot][row]
+        sub = Hdw[c0:c0 + q, :][:, have]                                # every referenced column must be present
+        assert abs(Hdw[c0:c0 + q, :]).sum() == abs(sub).sum()
+        res = orc.diag().reshape(q, du) * Vh[:q] + (Hup @ Vh[:q].T).T + sub @ Vh
+        hv_local.copy_(torch.from_numpy(np.ascontiguousarray(res).reshape(-1)))
+        return hv_local
+
+    hx = hxv.HaloHxv(du, dd, rank, world, need, send, apply_local)
+    assert (hx.qdw, hx.dw0 * du, hx.Nloc) == (q, orc.mpiIshift, orc.vecDim)
+    v_full = models.deterministic_vector(orc.Dim)
+    v_local = torch.from_numpy(v_full[orc.mpiIshift: orc.mpiIshift + orc.vecDim].copy())
+    hv_local = torch.empty(orc.vecDim, dtype=torch.complex128)
+    hx(hx.Nloc, v_local, hv_local)
+    # the halo buffer holds exactly the columns it claims to
+    got = hx.exchange(v_local).numpy().reshape(len(have), du)
+    assert np.array_equal(got, v_full.reshape(dd, du)[have])
+    assert hx.ingest_columns < (world - 1) * (-(-dd // world)) or world == 2
+    np.save(os.path.join(out, f"hv_{rank}.npy"), hv_local.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,sector", [(2, (3, 3)), (4, (3, 3)), (4, (2, 4)), (3, (3, 2))])
+def test_halo_exchange_gloo(world, sector, tmp_path):
+    """The halo exchange (only the columns H_dw couples across ranks travel) at world sizes 2, 3 and 4 against the oracle."""
+    import torch.multiprocessing as mp
+    from hxv import models
+    from oracle.oracle import OracleSector
+
+    nup, ndw = sector
+    mp.spawn(_worker_halo, args=(world, _free_port(), nup, ndw, str(tmp_path)), nprocs=world, join=True)
+    m = models.hm_1dchain(Nlat=2, Nbath=2, eps_bath=[0.3, 0.6])
+    s = OracleSector(m, nup, ndw)
+    ref = s.spMatVec_main(models.deterministic_vector(s.Dim))
+    got = np.concatenate([np.load(tmp_path / f"hv_{r}.npy") for r in range(world)])
+    assert np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max()
+
+
+def test_halo_plan_volume_c3():
+    """Exchange volume of the three schemes for BASELINE C3 at 8 ranks (what bench.py reports as exchange_ingest_bytes_per_gpu)."""
+    import hxv
+    from hxv import models
+    from oracle.oracle import OracleSector
+
+    orc = OracleSector(models.hm_2dsquare(Nbath=3), 8, 8)
+    rp, cols, _ = orc.csr("dw")
+    need, send = hxv.halo_plan(rp, cols - 1, orc.DimDw, 8)
+    b = hxv.exchange_ingest_bytes(orc.DimUp, orc.DimDw, 8, need)
+    assert b["halo"] < 0.62 * b["allgather"] and b["alltoall"] < b["halo"]
+    # what a rank sends is what the others need from it
+    for r in range(8):
+        for p in range(8):
+            if p != r:
+                q, c0 = hxv.dw_split(orc.DimDw, r, 8)
+                assert np.array_equal(np.sort(send[r][p] + c0), need[p][(need[p] >= c0) & (need[p] < c0 + q)])

@@ -119,3 +119,46 @@ def test_experiment_options_are_gated(built):
         if old is not None:
             os.environ["HXV_EXPERIMENTS"] = old
     sec.close()
+
+
+@pytest.mark.parametrize("world", [3, 4])
+def test_halo_layout_rehearsal_one_gpu(built, world):
+    """The engine's own halo layout (C++ plan, column -> slot table, tiled and job kernels) with every rank of a split sector
+    opened in ONE process: each rank's halo-layout vector is filled from the global vector by the lists the engine reports,
+    its slab of H v is compared with the oracle, and the C++ plan with the numpy one."""
+    import torch
+    import hxv
+    from hxv import models
+    from oracle.oracle import OracleSector
+
+    hxv.set_exchange_default("halo")
+    try:
+        for m, (nup, ndw) in ((models.hm_2dsquare(Nbath=1), (4, 4)), (models.hm_1dchain(eps_bath=[0.3, 0.6]), (6, 6)), (models.bhz_2d(Nbath=0, Ust=0.4, Jh=0.1), (3, 5))):
+            full = OracleSector(m, nup, ndw)
+            du, dd = full.DimUp, full.DimDw
+            v = models.deterministic_vector(full.Dim)
+            ref = full.spMatVec_main(v)
+            rp, cols, _ = full.csr("dw")
+            need, send = hxv.halo_plan(rp, cols - 1, dd, world)
+            V = v.reshape(dd, du)
+            for rank in range(world):
+                sec = hxv.HxvSector.from_model(m, nup, ndw, rank=rank, nranks=world)
+                assert sec.exchange_mode == "halo"
+                rc, sc, rcols, scols = sec.halo_lists(world)
+                assert np.array_equal(rcols, need[rank]) and np.array_equal(scols, np.concatenate([send[rank][p] for p in range(world)]).astype(np.int32))
+                q, c0 = hxv.dw_split(dd, rank, world)
+                have = np.concatenate([np.arange(c0, c0 + q), rcols])
+                assert sec.fullElems == len(have) * sec.pitch
+                buf = np.zeros((len(have), sec.pitch), dtype=np.complex128)
+                buf[:, :du] = V[have]
+                for job in (1, 0):
+                    sec.set_option("job_up", job)
+                    hv = sec.unpad(sec.apply_device(torch.from_numpy(buf.reshape(-1)).cuda()))
+                    torch.cuda.synchronize()
+                    assert _rel(hv.cpu().numpy(), ref[c0 * du:(c0 + q) * du]) <= TOL, (m.name, world, rank, job)
+                sec.set_option("kernel", 0)
+                hv = sec.unpad(sec.apply_device(torch.from_numpy(buf.reshape(-1)).cuda()))
+                assert _rel(hv.cpu().numpy(), ref[c0 * du:(c0 + q) * du]) <= TOL
+                sec.close()
+    finally:
+        hxv.set_exchange_default("allgather")
