@@ -153,8 +153,12 @@ __global__ void __launch_bounds__(1024) hxv_up_job(DevSector s, DevTiles t, JobU
         char* base = wtb + (size_t)(G & 1) * jb.wt_bytes;
         const VT* __restrict__ src = jb.wc ? wt + ((int64_t)G * s.dimup + r0) * wcw : wt + (int64_t)G * s.pitch + r0;
         for (int q = 0; q < wpieces; ++q)
-          __builtin_amdgcn_global_load_lds((glb_void_t*)(src + min(q * 64 + lane, n * wcw - 1)), (lds_void_t*)(base + (size_t)q * 64 * sizeof(VT)), 16, 0,
-                                           0);
+          if (jb.debug & 64)  // (experiment: streaming policy for the once-read scratch)
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(src + min(q * 64 + lane, n * wcw - 1)), (lds_void_t*)(base + (size_t)q * 64 * sizeof(VT)), 16,
+                                             0, 2);
+          else
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(src + min(q * 64 + lane, n * wcw - 1)), (lds_void_t*)(base + (size_t)q * 64 * sizeof(VT)), 16,
+                                             0, 0);
         ops += wpieces;
       }
       if (lane == 0) wdone[G & 1] = ops;

@@ -687,8 +687,13 @@ static int real_wc(const TilePlan& plan) { return std::max(real_cols(plan), std:
 // Pass A runs as jobs (hxv_jobs.hip) when the plan allows it and the tile ring fits the LDS; wc_out = scratch group width.
 static bool use_job_up(const DevSector& s, const TilePlan& plan, bool real_vec, bool lz, bool wt_natural, int* wc_out = nullptr) {
   if (real_vec || !plan.opt.job_up || plan.opt.sort_mode != 0 || plan.opt.debug != 0 || !job_up_usable(s, plan)) return false;
-  const int wc = wt_natural ? 0 : std::max(plan.opt.job_cols, plan.opt.wt_cols);
-  if (!job_up_fits(s, plan, lz, wc)) return false;
+  int wc = wt_natural ? 0 : std::max(plan.opt.job_cols, plan.opt.wt_cols);
+  if (!job_up_fits(s, plan, lz, wc)) {
+    // the Lanczos epilogue streams a third vector through the tile ring: narrower scratch groups (two buffers of
+    // wc columns each sit beside the ring) can make room for it
+    if (wt_natural || wc <= 2 || plan.opt.job_cols > 2 || !job_up_fits(s, plan, lz, 2)) return false;
+    wc = 2;
+  }
   if (wc_out) *wc_out = wc;
   return true;
 }
