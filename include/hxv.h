@@ -162,9 +162,10 @@ int hxv_apply_device_real(hxv_handle *h, const void *d_v_real, void *d_hv_real, 
 int hxv_time_apply(hxv_handle *h, const void *d_v_full, void *d_hv_local, int32_t nrep, float *ms_per_apply);
 
 /* ---- Lanczos on device (SciFortran sp_lanc_tridiag / sp_lanc_eigh call shapes,
- * ED_GF_NORMAL.f90:215-220, ED_DIAG.f90:176-184).  nranks==1.
+ * ED_GF_NORMAL.f90:215-220, ED_DIAG.f90:176-184).  Split sectors (nranks>1) after hxv_comm_init:
+ * vectors are this rank's slab, dot products are all-reduced.
  * All vectors in the padded device layout (hxv_localvec_elems() elements, pad rows zero).
- * tridiag: d_vin = caller-normalised start vector; alanc[nlanc], blanc[nlanc]
+ * tridiag: d_vin = start vector (normalised by the driver if it is not, as SciFortran does); alanc[nlanc], blanc[nlanc]
  *   filled as alanc(k)=<q_k|H|q_k>, blanc(k+1)=beta_{k+1}, blanc(1)=0 (ED_GF_NORMAL.f90:949-951);
  *   *nsteps = iterations done (early exit when beta < threshold).
  * eigh: lowest eigenvalue *egs and eigenvector d_vect (device, Dim, written) from a
@@ -201,9 +202,11 @@ int hxv_lanczos_eigh_host(hxv_handle *h, int32_t nitermax, double threshold, dou
  *   evecs_host   : host, eig_basis(Dim,neigen) in the reference's contiguous layout, or NULL
  *   *nconv       : how many of the neigen pairs met the test; *nmatvec: H x V products spent.
  * Needs (ncv+1) vectors of HBM; fails with HXV_ERR_HIP and a message naming the shortfall otherwise.
- * Like any single-vector Krylov method (ARPACK included) it sees ONE vector of an exactly degenerate level: with
- * neigen beyond a degenerate level the next distinct levels follow.  If Dim <= ncv the Krylov space closes and all
- * returned pairs are exact.                                                                                      */
+ * A single Krylov space sees ONE vector of an exactly degenerate level (ARPACK included), while ED_DIAG.f90:234-244 keeps
+ * every state within gs_threshold of the minimum: so, once the wanted pairs have converged, they are locked and the
+ * same iteration in their orthogonal complement looks for a state below the current neigen-th lowest value (a hidden
+ * copy), repeatedly (option "eigh_degenerate", default 1; costs up to ~2/3 more products when there is nothing to find).
+ * Split sectors: after hxv_comm_init (vectors = slabs).  If Dim <= ncv the Krylov space closes and all returned pairs are exact. */
 int hxv_eigh_lowest(hxv_handle *h, int32_t neigen, int32_t ncv, int32_t maxrestart, double tol, double *evals, void *d_evecs,
                     int32_t *nconv, int32_t *nmatvec);
 int hxv_eigh_lowest_host(hxv_handle *h, int32_t neigen, int32_t ncv, int32_t maxrestart, double tol, double *evals,
@@ -247,13 +250,19 @@ int hxv_get_diag(const hxv_handle *h, double *diag);
  *   "real_vectors"    1 [default] = device Lanczos drivers run on real vectors when H and the start vector are real
  *   "lanczos_fused"   1 [default] = recurrence fused into the product's epilogue; 0 = separate vector kernels
  *   "lanczos_graph"   1 [default] = fixed-length tridiagonalisations run device-only, three iterations per hipGraph
+ *   "eigh_degenerate" 1 [default] = hxv_eigh_lowest locks the converged pairs and looks for further copies of degenerate levels
+ * Pass A as pipelined jobs (LDS-DMA tile ring, one workgroup per CU): "job_up" 1 [default] | 0 (one tile per
+ *   workgroup), "job_groups" columns per job [50], "job_cols" 1|2 columns per tile [1], "job_stages" ring depth 2..8 [4, clamped
+ *   to what fits the LDS].  The engine falls back to the one-tile kernels by itself where jobs do not apply (real vectors,
+ *   stored diagonal, more than 24 in-block / 16 out-of-block entries per row, blocks over 960 rows).
  * Tile shape (changing one rebuilds the plan; invalid combinations are refused with a message):
  *   "cols_per_tile" 2|4|8 [4], "rows_per_tile" 2|4|8 [4], "lds_budget_kb[_up|_dw]" 8..144 [64], "threads_up|_dw"
  *   256|512|1024 [1024], "sort_mode" 0..2 [0], "sort_mode_dw" 0|1 [1], "wt_cols" 2|4|8|16 [4], "tile_bits_up|_dw" (force the block bits),
  *   "lds_min_kb_up|_dw".
- * Timing experiments only (results are wrong or partial when set): "passes" 1|2|3 [3], "debug" bit mask.
- * hxv_get_option additionally reports plan statistics ("tile_bits_up", "nblocks_up", "slots_in_up_x100", ...,
- * "lanczos_real_last").                                                                                      */
+ * Timing experiments (results are wrong or partial when set; refused unless HXV_EXPERIMENTS=1 is in the environment):
+ *   "passes" 1|2|3 [3], "debug" bit mask, "job_debug" bit mask.
+ * hxv_get_option additionally reports plan statistics ("tile_bits_up", "nblocks_up", "slots_in_up_x100", "max_outer_up",
+ *   "job_up_active", ..., "lanczos_real_last").                                                                  */
 int hxv_set_option(hxv_handle *h, const char *name, int64_t value);
 int64_t hxv_get_option(const hxv_handle *h, const char *name);
 
