@@ -425,6 +425,10 @@ int hxv_set_option(hxv_handle* h, const char* name, int64_t value) {
     h->eigh_degenerate = value ? 1 : 0;
     return HXV_OK;
   }
+  if (!strcmp(name, "eigh_measure_all")) {
+    h->eigh_measure_all = value ? 1 : 0;
+    return HXV_OK;
+  }
   if (!strcmp(name, "debug")) {
     h->plan.opt.debug = (int)value;
     return HXV_OK;
@@ -474,6 +478,9 @@ int64_t hxv_get_option(const hxv_handle* h, const char* name) {
   if (!strcmp(name, "real_vectors")) return h->real_vectors;
   if (!strcmp(name, "lanczos_graph")) return h->lz_graph;
   if (!strcmp(name, "eigh_degenerate")) return h->eigh_degenerate;
+  if (!strcmp(name, "eigh_measure_all")) return h->eigh_measure_all;
+  if (!strcmp(name, "eigh_last_full_passes")) return h->eigh_last_full;
+  if (!strcmp(name, "eigh_last_local_passes")) return h->eigh_last_local;
   if (!strcmp(name, "lanczos_real_last")) return h->last_real;
   if (!strcmp(name, "kernel")) return h->kernel;
   if (!strcmp(name, "tile_bits_up")) return h->plan.up.lowbits;

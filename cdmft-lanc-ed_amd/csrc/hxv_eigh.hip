@@ -12,6 +12,8 @@
 // kernels are plain streaming kernels (HBM-bound); per Lanczos step they read the j+1 basis vectors twice
 // (multi-dot, multi-axpy), which dominates the HxV itself -- the same trade ARPACK makes on the host.
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "hxv_handle.hpp"
@@ -369,11 +371,37 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
     return HXV_OK;
   };
 
+  // The two LOCAL projections only (alpha_j on V[jt], beta_j on V[jt-1]): what a Lanczos step needs when the basis is
+  // known (by the omega recurrence below) to be semi-orthogonal.  c[2*(jt-1)], c[2*jt] are set.
+  auto gs_local = [&](int jt, bool has_prev, double* nrm2_after) -> int {
+    const int b0 = has_prev ? jt - 1 : jt, nb = has_prev ? 2 : 1;
+    hipLaunchKernelGGL(tr_mdot, dim3(g), dim3(256), 0, st, n, vec(b0), n, nb, vec(jt + 1), d_part);
+    hipLaunchKernelGGL(tr_colsum, dim3(1), dim3(256), 0, st, d_part, g, 2 * JB, 2 * nb, d_coef, real ? 1 : 0);
+    if (int rca = comm_allreduce_sum(h, d_coef, (size_t)2 * nb, st)) return rca;
+    HIPCHK(hipMemcpyAsync(csel.data(), d_coef, (size_t)2 * nb * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int i = 0; i < nb; ++i) {
+      isel[i] = b0 + i;
+      c[2 * (b0 + i)] = csel[2 * i];
+      c[2 * (b0 + i) + 1] = csel[2 * i + 1];
+    }
+    HIPCHK(hipMemcpyAsync(d_csel, csel.data(), (size_t)2 * nb * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_isel, isel.data(), (size_t)nb * sizeof(int), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(tr_maxpy, dim3(g), dim3(256), 0, st, n, V, n, nb, d_isel, d_csel, vec(jt + 1), d_npart);
+    hipLaunchKernelGGL(tr_colsum, dim3(1), dim3(256), 0, st, d_npart, g, 1, 1, d_nrm, 0);
+    if (int rca = comm_allreduce_sum(h, d_nrm, 1, st)) return rca;
+    HIPCHK(hipMemcpyAsync(nrm2_after, d_nrm, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return HXV_OK;
+  };
+
   // Thick-restart Lanczos for the `nwant` lowest pairs of H restricted to the orthogonal complement of the `nlock`
   // LOCKED eigenvectors V[0..nlock) (nlock = 0: H itself).  The active basis is V[nlock..nlock+ma]; on return its first
   // `ne` vectors are the Ritz vectors of theta[0..ne).
   std::vector<double> T, A, theta, S;
+  std::vector<double> lockval;  // eigenvalues of the locked vectors V[0..nlock)
   int nmv = 0, nconv = 0, ne = neigen;
+  int n_full = 0, n_local = 0;  // Gram-Schmidt passes against the whole basis / against the two local vectors only
   bool closed = false;  // the Krylov space closed (invariant subspace): every returned pair is exact
   bool above = false;   // a check round stopped early: the lowest Ritz value minus its residual bound is already above `stop_above`
   auto trl = [&](int nlock, int nwant, uint64_t seed, double stop_above) -> int {
@@ -402,6 +430,8 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
     hipLaunchKernelGGL(tr_scale_nrm, dim3(g), dim3(256), 0, st, n, av(0), 1.0 / std::sqrt(nrm2), (double*)nullptr);
     int k = 0, meff = ma;
     double beta_last = 0.0;
+    std::vector<double> om_prev(m + 2, eps), om_cur(m + 2, eps), om_next(m + 2, eps), theta_keep, s_keep;
+    bool force_full = false;
     for (int it = 0;; ++it) {
       meff = ma;
       beta_last = 0.0;
@@ -410,20 +440,93 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
         if (rc) return rc;
         ++nmv;
         double w2 = 0.0;
-        rc = gs_pass(nlock + j, nlock, j == k, &w2);
+        const int jt = nlock + j;
+        // Partial re-orthogonalisation (Simon 1984) in its thick-restart form: the loss of orthogonality of the next
+        // vector against every earlier basis vector is ESTIMATED from the recurrence the exact quantities obey
+        // (om_*: <q_j, v_b>), and the whole basis is only touched when an estimate passes sqrt(eps) -- then for two
+        // consecutive vectors.  Otherwise a step costs the two local projections.  (Option "eigh_measure_all" = 1
+        // restores the round-1 behaviour: every projection measured at every step.)
+        const bool first_after_restart = j == k;
+        bool full = h->eigh_measure_all || first_after_restart || force_full;
+        if (full) {
+          rc = gs_pass(jt, nlock, first_after_restart || force_full, &w2);
+          ++n_full;
+        } else {
+          rc = gs_local(jt, j > k, &w2);
+          ++n_local;
+        }
         if (rc) return rc;
-        t_at(j, j) = c[2 * (nlock + j)];
+        t_at(j, j) = c[2 * jt];
         double c2sum = 0.0;
-        for (int t = 0; t < 2 * (nlock + j + 1); ++t) c2sum += c[t] * c[t];
+        if (full)
+          for (int t = 0; t < 2 * (jt + 1); ++t) c2sum += c[t] * c[t];
+        else
+          c2sum = c[2 * jt] * c[2 * jt] + c[2 * jt + 1] * c[2 * jt + 1] + (j > k ? c[2 * (jt - 1)] * c[2 * (jt - 1)] + c[2 * (jt - 1) + 1] * c[2 * (jt - 1) + 1] : 0.0);
         double nrm = std::sqrt(std::max(w2, 0.0));
+        bool was_forced = force_full;
+        force_full = false;
+        if (!h->eigh_measure_all) {
+          double tsc = 1.0;
+          for (int a = 0; a <= j; ++a) tsc = std::max(tsc, std::fabs(t_at(a, a)));
+          const double noise = 2.0 * eps * tsc / std::max(nrm, 1e-300);
+          if (full) {
+            for (int b = 0; b <= jt; ++b) om_next[b] = noise;  // measured and removed: orthogonal to rounding
+          } else {
+            auto omc = [&](int x) -> double { return x == jt ? 1.0 : (x == jt - 1 ? noise : om_cur[x]); };
+            const double alpha_j = t_at(j, j), beta_j = j > k ? t_at(j, j - 1) : 0.0;
+            double maxom = 0.0;
+            for (int b = 0; b < jt - 1; ++b) {
+              double at;
+              if (b < nlock) {
+                at = lockval[b] * om_cur[b];
+              } else {
+                const int l = b - nlock;
+                if (l < k) {
+                  at = theta_keep[l] * om_cur[b] + s_keep[l] * omc(nlock + k);
+                } else {
+                  at = t_at(l, l) * om_cur[b] + t_at(l + 1, l) * omc(b + 1);
+                  if (l > k)
+                    at += t_at(l, l - 1) * omc(b - 1);
+                  else
+                    for (int i2 = 0; i2 < k; ++i2) at += s_keep[i2] * omc(nlock + i2);
+                }
+              }
+              double val = (at - alpha_j * om_cur[b] - beta_j * om_prev[b]) / std::max(nrm, 1e-300);
+              val += std::copysign(noise, val);
+              om_next[b] = val;
+              maxom = std::max(maxom, std::fabs(val));
+            }
+            om_next[jt - 1 < 0 ? 0 : jt - 1] = noise;
+            om_next[jt] = noise;
+            // sqrt(eps) would keep the EIGENVALUES at rounding level (Simon); the eigenvectors are handed to the Green's-function
+            // stage, so the basis is kept orthogonal to 1e-12 instead and the returned vectors are orthonormalised once more at the end
+            if (maxom > 1e-12) {  // about to be lost: remove everything now, and again at the next step
+              double w3 = 0.0;
+              rc = gs_pass(jt, nlock, true, &w3);
+              ++n_full;
+              if (rc) return rc;
+              t_at(j, j) += c[2 * jt];
+              nrm = std::sqrt(std::max(w3, 0.0));
+              for (int b = 0; b <= jt; ++b) om_next[b] = noise;
+              force_full = !was_forced;
+              full = true;
+              c2sum = 0.0;
+              for (int t = 0; t < 2 * (jt + 1); ++t) c2sum += c[t] * c[t];
+              w2 = w3;
+            }
+          }
+          om_prev.swap(om_cur);
+          om_cur.swap(om_next);
+        }
         // One classical Gram-Schmidt pass leaves an orthogonality error ~ eps*|w_before|/|w_after|.  H v_j always carries
         // alpha_j v_j + beta_j v_{j-1}, so the textbook DGKS bound 1/sqrt(2) would refine nearly every step; Lanczos only
         // needs semi-orthogonality (sqrt(eps)), so refine when the norm dropped by more than 10x (error <= ~1e-14 otherwise).
         if (w2 < DGKS_ETA2 * (c2sum + w2)) {
           double w3 = 0.0;
-          rc = gs_pass(nlock + j, nlock, true, &w3);
+          rc = gs_pass(jt, nlock, true, &w3);
+          ++n_full;
           if (rc) return rc;
-          t_at(j, j) += c[2 * (nlock + j)];
+          t_at(j, j) += c[2 * jt];
           double nrm_b = std::sqrt(std::max(w3, 0.0));
           if (nrm_b < 0.5 * nrm) nrm_b = 0.0;  // w lies in span(V): invariant subspace
           nrm = nrm_b;
@@ -450,6 +553,9 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
         const double res = std::fabs(beta_last * S[(meff - 1) + (size_t)i * meff]);
         if (res <= tol * std::max(eps23, std::fabs(theta[i]))) ++nconv;
       }
+      if (getenv("HXV_EIGH_TRACE"))
+        fprintf(stderr, "[eigh] nlock %d restart %d k %d meff %d theta0 %.10f theta1 %.10f beta_last %.3e nconv %d full %d local %d\n", nlock, it, k, meff,
+                theta[0], meff > 1 ? theta[1] : 0.0, beta_last, nconv, n_full, n_local);
       closed = meff < ma;
       // check rounds only ask "is there a state below stop_above?": Ritz values come down monotonically and the residual
       // bounds how far the lowest one can still move, so the answer "no" does not need a converged pair
@@ -463,11 +569,28 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
       launch_rotate(g, st, n, Va, n, ma, k, d_S);
       HIPCHK(hipMemcpyAsync(av(k), av(ma), (size_t)n * sizeof(double2), hipMemcpyDeviceToDevice, st));
       HIPCHK(hipStreamSynchronize(st));  // S (host) is reused below
+      if (!h->eigh_measure_all) {
+        // The residual vector inherits whatever orthogonality the old basis had lost against the directions that are now
+        // the kept Ritz vectors: clean it once per restart, so that the estimates of the new cycle start from rounding
+        // level for every pair they track
+        double r2 = 0.0;
+        int rcr = gs_pass(nlock + k - 1, nlock, true, &r2);
+        if (rcr) return rcr;
+        ++n_full;
+        if (r2 > 0.0) hipLaunchKernelGGL(tr_scale_nrm, dim3(g), dim3(256), 0, st, n, av(k), 1.0 / std::sqrt(r2), (double*)nullptr);
+      }
       std::fill(T.begin(), T.end(), 0.0);
+      theta_keep.assign(k, 0.0);
+      s_keep.assign(k, 0.0);
       for (int i = 0; i < k; ++i) {
         t_at(i, i) = theta[i];
         t_at(k, i) = t_at(i, k) = beta_last * S[(ma - 1) + (size_t)i * ma];
+        theta_keep[i] = theta[i];
+        s_keep[i] = t_at(k, i);
       }
+      std::fill(om_prev.begin(), om_prev.end(), eps);
+      std::fill(om_cur.begin(), om_cur.end(), eps);
+      force_full = false;
     }
     if (above) return HXV_OK;
     // Ritz vectors of the wanted pairs to the front of the active basis
@@ -481,6 +604,7 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
   if (rc0) return rc0;
   // values and (absolute) basis slots of the pairs found so far
   std::vector<double> fval(theta.begin(), theta.begin() + ne);
+  lockval = fval;
   int nfound = ne;
   const int nconv0 = nconv, ne0 = ne;
   const bool closed0 = closed;
@@ -502,9 +626,18 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
       if (nconv < 1 && !closed) break;   // could not settle the question within maxrestart: keep what is certain
       if (!(theta[0] < kth)) break;
       fval.push_back(theta[0]);  // its vector sits at V[nfound]: locked from now on
+      lockval = fval;
       ++nfound;
     }
   }
+  // the found vectors (slots 0..nfound-1) come from bases that were orthogonal to ~1e-10: one Gram-Schmidt sweep among them
+  if (!h->eigh_measure_all && d_evecs)
+    for (int b = 1; b < nfound; ++b) {
+      double r2 = 0.0;
+      int rc = gs_pass(b - 1, 0, true, &r2);
+      if (rc) return rc;
+      if (r2 > 0.0) hipLaunchKernelGGL(tr_scale_nrm, dim3(g), dim3(256), 0, st, n, vec(b), 1.0 / std::sqrt(r2), (double*)nullptr);
+    }
   // the neigen lowest of everything found, ascending, vectors gathered to the end of the basis and copied out
   std::vector<int> order(nfound);
   for (int i = 0; i < nfound; ++i) order[i] = i;
@@ -516,6 +649,8 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
   for (int i = 0; i < neigen; ++i) evals[i] = i < ne ? theta[i] : 0.0;
   if (nconv_out) *nconv_out = nconv;
   if (nmatvec_out) *nmatvec_out = nmv;
+  h->eigh_last_full = n_full;
+  h->eigh_last_local = n_local;
   if (d_evecs) {
     for (int i = 0; i < ne; ++i) {
       if (real)

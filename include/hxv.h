@@ -251,6 +251,8 @@ int hxv_get_diag(const hxv_handle *h, double *diag);
  *   "lanczos_fused"   1 [default] = recurrence fused into the product's epilogue; 0 = separate vector kernels
  *   "lanczos_graph"   1 [default] = fixed-length tridiagonalisations run device-only, three iterations per hipGraph
  *   "eigh_degenerate" 1 [default] = hxv_eigh_lowest locks the converged pairs and looks for further copies of degenerate levels
+ *   "eigh_measure_all" 0 [default] = partial re-orthogonalisation (loss of orthogonality estimated by the omega recurrence, whole-basis
+ *                     Gram-Schmidt only when needed); 1 = every projection measured at every step (round-1 behaviour)
  * Pass A as pipelined jobs (LDS-DMA tile ring, one workgroup per CU): "job_up" 1 [default] | 0 (one tile per
  *   workgroup), "job_groups" columns per job [50], "job_cols" 1|2 columns per tile [1], "job_stages" ring depth 2..8 [4, clamped
  *   to what fits the LDS].  The engine falls back to the one-tile kernels by itself where jobs do not apply (real vectors,

@@ -362,6 +362,34 @@ def test_eigh_lowest_recovers_degenerate_levels(built):
     s2.close()
 
 
+def test_eigh_lowest_partial_reorthogonalisation(built):
+    """The omega-recurrence (estimated loss of orthogonality, whole-basis Gram-Schmidt only when an estimate passes
+    sqrt(eps)) against the round-1 scheme that measured every projection at every step: same eigenpairs, residuals and
+    orthonormality to the same tolerances, most steps local."""
+    import hxv
+    from hxv import models
+    from oracle.oracle import OracleSector
+    from helpers_matrix import oracle_full_matrix
+
+    for m, sector, neig, ncv in ((models.hm_1dchain(eps_bath=[0.3, 0.6]), (6, 6), 3, 24), (models.bhz_2d(Nbath=0, Ust=0.4, Jh=0.1), (4, 4), 4, 30),
+                                 (models.hm_2dsquare(Nbath=1), (4, 4), 2, 12)):
+        sec = hxv.HxvSector.from_model(m, *sector)
+        H = oracle_full_matrix(OracleSector(m, *sector))
+        res = {}
+        for mode in (1, 0):
+            sec.set_option("eigh_measure_all", mode)
+            ev, X, nconv, nmv = sec.eigh_lowest(neig, ncv, 512, 0.0)
+            Xh = X.cpu().numpy().T
+            assert nconv == neig
+            assert np.linalg.norm(H @ Xh - Xh * ev, axis=0).max() < 1e-8, (m.name, mode)
+            assert np.abs(Xh.conj().T @ Xh - np.eye(neig)).max() < 1e-9, (m.name, mode)
+            res[mode] = (ev, nmv, sec.get_option("eigh_last_full_passes"), sec.get_option("eigh_last_local_passes"))
+        assert np.abs(res[0][0] - res[1][0]).max() < 1e-10, m.name
+        assert res[1][3] == 0 and res[0][3] > res[0][2], (m.name, res)      # measure-all has no local passes; the default is mostly local
+        assert res[0][1] <= 1.3 * res[1][1] + 20, (m.name, res)               # and needs about as many products
+        sec.close()
+
+
 # ---- REAL-vector mode of the device Lanczos drivers (H real + real start vector -> double instead of complex(8)) ---
 def test_real_vector_lanczos_matches_complex_mode(built):
     import torch
