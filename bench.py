@@ -202,8 +202,8 @@ def main():
            "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
            "higher_is_better": True, "scaling": "weak" if by_sector else "strong", "vs_baseline": None, "dtype": "complex128 (f64)", "data": "synthetic",
            "config": {"workload": f"{args.workload}: {model.name} sector ({nup},{ndw}) Dim={Dim}", "DimUp": sec.DimUp, "DimDw": sec.DimDw,
-                      "parallelism": f"{world} independent sectors, one per GPU, no exchange" if by_sector else f"DimDw split x{world}" + ((" + RCCL allgather per product" if args.exchange == "allgather"
-                                                                 else " + 2 RCCL all-to-all transposes per product") if world > 1 else ""),
+                      "parallelism": f"{world} independent sectors, one per GPU, no exchange" if by_sector else f"DimDw split x{world}" + ({"allgather": " + RCCL allgather per product", "halo": " + RCCL send/recv of the columns H_dw couples across ranks",
+                                                                  "alltoall": " + 2 RCCL all-to-all transposes per product"}[args.exchange] if world > 1 else ""),
                       "matvecs_per_s": round((world if by_sector else 1) * 1e3 / ms_step, 2)},
            "roofline": roofline}
     if world > 1 and not by_sector:

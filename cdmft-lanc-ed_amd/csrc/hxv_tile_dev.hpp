@@ -42,6 +42,32 @@ __device__ __forceinline__ void store_stream(double* p, double a) { __builtin_no
 
 constexpr uint32_t TILE_OFF_MASK = (1u << TILE_COEF_SHIFT) - 1u;
 
+// LDS by byte offset (a kernel's dynamic LDS starts at 0 when it declares no static LDS): addressing through the
+// extern __shared__ symbol costs one vector add per access that the compiler cannot fold.
+template <typename X>
+__device__ __forceinline__ X lds_ld(uint32_t off) { return *(__attribute__((address_space(3))) const X*)(off); }
+template <typename X>
+__device__ __forceinline__ void lds_st(uint32_t off, X x) { *(__attribute__((address_space(3))) X*)(off) = x; }
+template <>
+__device__ __forceinline__ double2 lds_ld<double2>(uint32_t off) {
+  const dbl2_t x = *(__attribute__((address_space(3))) const dbl2_t*)(off);
+  return make_double2(x.x, x.y);
+}
+template <>
+__device__ __forceinline__ void lds_st<double2>(uint32_t off, double2 a) {
+  dbl2_t x;
+  x.x = a.x;
+  x.y = a.y;
+  *(__attribute__((address_space(3))) dbl2_t*)(off) = x;
+}
+// (a << SH) + b in one instruction (the compiler turns (x & m) << SH into shift, mask, add)
+template <int SH>
+__device__ __forceinline__ uint32_t shl_add(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "n"(SH), "s"(b));
+  return r;
+}
+
 // Vector element type VT: double2 (complex vectors, the reference's complex(8)) or double (REAL vectors: when H is real,
 // a real start vector keeps every Lanczos vector real -- half the bytes of every pass; device Lanczos only).
 template <typename VT>

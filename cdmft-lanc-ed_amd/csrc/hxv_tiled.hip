@@ -177,10 +177,14 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
 }
 
 // ---------------------------------------------------------------------------------------
-// pass B.  The tile is kept TRANSPOSED in LDS (lds[r*n + col]) so that in the inner phase a
-// thread owns one column and R rows: one ELL decode serves R gathers.  The out-of-block hops
-// are done afterwards with lanes along the contiguous row direction (coalesced 16*R-byte
-// segments of other columns), after the inner sums have been parked in the tile.
+// pass B.  Tile element (column c of the block, row r) sits at pair index q = c*R + r in LDS, which is also the order the
+// lanes touch global memory in (lanes along the R contiguous rows of a column: coalesced 16*R-byte segments), so the
+// streaming phases address LDS linearly.  In the in-block phase a thread owns one column and its R rows: one table decode
+// serves R gathers at immediate offsets.  The out-of-block hops run afterwards, lanes along the rows again, after the
+// in-block sums have been parked in the tile.
+// The address arithmetic is kept off the vector ALU (it was more than half of this kernel's instructions): blockDim.x is a
+// multiple of R, so a thread's pairs all have the same row; every global access is a uniform 64-bit base plus a per-thread
+// 32-bit byte offset that is computed once (tile load, block hops, scratch store), or one 64-bit multiply-add (row slots).
 // ---------------------------------------------------------------------------------------
 template <int R, int NP, bool REAL, typename VT>
 __global__ void __launch_bounds__(1024, 8) hxv_pass_dw(DevSector s, DevTiles t, const VT* __restrict__ v, VT* __restrict__ wt,
@@ -189,8 +193,9 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_dw(DevSector s, DevTiles t, 
   // loads are issued before the first use so a workgroup keeps NP requests per lane in flight.
   using CT = typename Coef<REAL>::type;
   extern __shared__ double2 lds_raw[];
-  VT* lds = reinterpret_cast<VT*>(lds_raw);
-  constexpr int SLOTS = 256 / (int)sizeof(VT);  // elements in one sweep of all LDS banks
+  constexpr int VB = (int)sizeof(VT);
+  constexpr int LR = R == 2 ? 1 : (R == 4 ? 2 : 3);
+  static_assert(R == 2 || R == 4 || R == 8, "R");
   const int b = blockIdx.x;
   const int xcd = b & 7, j = b >> 3;
   const int gl = j / t.nblocks;
@@ -201,66 +206,91 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_dw(DevSector s, DevTiles t, 
   const int n = (int)t.start[kb + 1] - cb0;
   if (cb0 + n <= s.dw0 || cb0 >= s.dw0 + s.qdw) return;  // block holds no local output column
   const int T = blockDim.x;
+  const int tid = threadIdx.x;
   const int i0 = rg * R;
-  const int npairs = n * R;
-  // padded row stride of the transposed tile: (stride mod SLOTS) = SLOTS/R spreads the R rows x (SLOTS/R) columns
-  // touched by SLOTS neighbouring lanes over all bank slots (16 sixteen-byte slots / 32 eight-byte slots)
-  const int ns = ((n + SLOTS - 1) & ~(SLOTS - 1)) + SLOTS / R;
-  CT* lcoef = reinterpret_cast<CT*>(lds + R * ns);
+  // LDS (by byte offset): the signed coefficients at 0 -- an in-block table word's coefficient field shifted down IS the
+  // coefficient's address, because a column offset within a block (< 1024) leaves the bits between the fields clear --
+  // and the tile behind them
+  constexpr int LCB = sizeof(CT) == 8 ? 3 : 4;
+  constexpr int LTB = LR + (VB == 8 ? 3 : 4);  // log2 of the bytes of one column of the tile
+  const uint32_t ltile = (uint32_t)((t.nscoef << LCB) + 255) & ~255u;
+  // XOR swizzle of the R row positions inside a column's chunk by the column's index among the columns that share its
+  // 256-byte bank sweep: without it the R gathers of an in-block hop (all lanes at the same row position of random
+  // columns) would use only 1/R of the banks.  The linear phases see a permutation inside each chunk: still conflict-free.
+  constexpr int LSW = 8 - LTB;                      // log2(columns per 256 B); LTB <= 7
+  constexpr int LVB = VB == 8 ? 3 : 4;
+  auto swz_of = [](uint32_t col) -> uint32_t { return ((col >> LSW) & (R - 1)) << LVB; };  // byte XOR of a column
+  const uint32_t tq = ltile + (((uint32_t)tid << LVB) ^ swz_of((uint32_t)tid >> LR));  // this thread's pair 0 (pair it: + it*T*VB)
   const uint32_t emptyz = (uint32_t)(t.nscoef - 1) << TILE_COEF_SHIFT;
-  for (int q = threadIdx.x; q < t.nscoef; q += T) lcoef[q] = Coef<REAL>::from(t.scoef[q]);
-  // phase 0: tile load, lanes along rows (R*16 B contiguous per column), transposed store
-  {
-    uint32_t slot[NP];
+  for (int q = tid; q < t.nscoef; q += T) lds_st<CT>(q << LCB, Coef<REAL>::from(t.scoef[q]));
+  // per-thread constants
+  const int r = tid & (R - 1);
+  const int cstep = T >> LR;                      // columns between a thread's consecutive pairs
+  const uint32_t pitchb = (uint32_t)s.pitch * VB;  // bytes per column
+  const uint32_t rowb = (uint32_t)(min(i0 + r, s.dimup - 1) - i0) * VB;
+  const char* __restrict__ vrows = reinterpret_cast<const char*>(v) + (int64_t)i0 * VB;  // uniform
+  uint32_t voff[NP];  // byte offset of pair it relative to (first column of a block, row i0)
+  uint32_t ccol[NP];  // its column within the block (clamped)
 #pragma unroll
-    for (int it = 0; it < NP; ++it) {
-      const int q = min(threadIdx.x + it * T, npairs - 1);
-      const int c = cb0 + q / R;
-      slot[it] = s.vcol_identity ? (uint32_t)c : s.vcol[c];
-    }
+  for (int it = 0; it < NP; ++it) {
+    ccol[it] = (uint32_t)min((tid >> LR) + it * cstep, n - 1);
+    voff[it] = ccol[it] * pitchb + rowb;
+  }
+  // phase 0: tile load
+  if (s.vcol_identity) {
+    const char* __restrict__ src = vrows + (int64_t)cb0 * pitchb;
     VT x[NP];
 #pragma unroll
-    for (int it = 0; it < NP; ++it) {
-      const int q = min(threadIdx.x + it * T, npairs - 1);
-      x[it] = v[(int64_t)slot[it] * s.pitch + min(i0 + q % R, s.dimup - 1)];
-    }
+    for (int it = 0; it < NP; ++it) x[it] = *reinterpret_cast<const VT*>(src + voff[it]);
 #pragma unroll
     for (int it = 0; it < NP; ++it) {
-      const int q = threadIdx.x + it * T;
-      if (q < npairs) lds[(q % R) * ns + q / R] = x[it];
+      if ((tid >> LR) + it * cstep < n) lds_st<VT>(tq + it * T * VB, x[it]);
+    }
+  } else {
+    uint32_t slot[NP];
+#pragma unroll
+    for (int it = 0; it < NP; ++it) slot[it] = s.vcol[cb0 + ccol[it]];
+    VT x[NP];
+#pragma unroll
+    for (int it = 0; it < NP; ++it) x[it] = *reinterpret_cast<const VT*>(vrows + ((uint64_t)slot[it] * pitchb + rowb));
+#pragma unroll
+    for (int it = 0; it < NP; ++it) {
+      if ((tid >> LR) + it * cstep < n) lds_st<VT>(tq + it * T * VB, x[it]);
     }
   }
   __syncthreads();
   // in-block hops, one column per thread (plan guarantees n <= blockDim.x)
-  const int p = threadIdx.x;
   {
     VT acc[R];
     int col1 = 0;
-    if (p < n) {
-      const uint32_t packed = __builtin_amdgcn_readfirstlane(t.gmax[t.gstart[kb] + (p >> 6)]);
+    if (tid < n) {
+      const uint32_t packed = __builtin_amdgcn_readfirstlane(t.gmax[t.gstart[kb] + (tid >> 6)]);
       const int kin = (t.debug & 2) ? 0 : (int)(packed & 0xFFFFu);
-      col1 = (int)t.perm[cb0 + p] - cb0;
+      col1 = (int)t.perm[cb0 + tid] - cb0;
+      const uint32_t* __restrict__ ellp = t.ell_in + cb0 + tid;
 #pragma unroll
-      for (int r = 0; r < R; ++r) acc[r] = vzero<VT>();
+      for (int rr = 0; rr < R; ++rr) acc[rr] = vzero<VT>();
       for (int k0 = 0; k0 < kin; k0 += HOP_CHUNK) {
         uint32_t e[HOP_CHUNK];
 #pragma unroll
-        for (int u = 0; u < HOP_CHUNK; ++u) e[u] = t.ell_in[(int64_t)(k0 + u) * s.dimdw + cb0 + p];
+        for (int u = 0; u < HOP_CHUNK; ++u) e[u] = ellp[(int64_t)(k0 + u) * s.dimdw];
 #pragma unroll
         for (int u = 0; u < HOP_CHUNK; ++u) {
           if (k0 + u < kin) {  // wave-uniform
-            const CT cf = lcoef[e[u] >> TILE_COEF_SHIFT];
-            const int off = (int)(e[u] & TILE_OFF_MASK);
+            const CT cf = lds_ld<CT>(e[u] >> (TILE_COEF_SHIFT - LCB));
+            const uint32_t col = e[u] & TILE_OFF_MASK;
+            const uint32_t src = shl_add<LTB>(col, ltile), sw = swz_of(col);
 #pragma unroll
-            for (int r = 0; r < R; ++r) Coef<REAL>::fma(acc[r], cf, lds[r * ns + off]);
+            for (int rr = 0; rr < R; ++rr) Coef<REAL>::fma(acc[rr], cf, lds_ld<VT>(src + ((uint32_t)(rr * VB) ^ sw)));
           }
         }
       }
     }
     __syncthreads();  // every in-block gather is done: the tile can be overwritten by the sums
-    if (p < n) {
+    if (tid < n) {
+      const uint32_t dst = ltile + ((uint32_t)col1 << LTB), sw = swz_of((uint32_t)col1);
 #pragma unroll
-      for (int r = 0; r < R; ++r) lds[r * ns + col1] = acc[r];
+      for (int rr = 0; rr < R; ++rr) lds_st<VT>(dst + ((uint32_t)(rr * VB) ^ sw), acc[rr]);
     }
   }
   __syncthreads();
@@ -269,6 +299,7 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_dw(DevSector s, DevTiles t, 
   // Pairs are handled HB at a time to bound the registers (two 1024-thread workgroups per CU need <= 64 VGPRs).
   if (!(t.debug & 1)) {
     constexpr int HB = NP > 4 ? 4 : NP;
+    const char* __restrict__ vrow64 = vrows + rowb;  // per-thread 64-bit base of the row-slot gathers
 #pragma unroll
     for (int base = 0; base < NP; base += HB) {
       VT osum[HB];
@@ -276,72 +307,93 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_dw(DevSector s, DevTiles t, 
       for (int it = 0; it < HB; ++it) osum[it] = vzero<VT>();
       // block hops: source column slot = start + column offset, one signed coefficient for the whole block
       for (uint32_t h = t.bh_ptr[kb]; h < t.bh_ptr[kb + 1]; ++h) {
-        const CT cf = lcoef[t.bh[2 * h + 1]];
-        const uint32_t s0 = t.bh[2 * h];
+        const CT cf = lds_ld<CT>(t.bh[2 * h + 1] << LCB);
+        const char* __restrict__ src = vrows + (int64_t)t.bh[2 * h] * pitchb;
         VT x[HB];
 #pragma unroll
-        for (int it = 0; it < HB; ++it) {
-          const int q = min((int)threadIdx.x + (base + it) * T, npairs - 1);
-          x[it] = v[(int64_t)(s0 + q / R) * s.pitch + min(i0 + q % R, s.dimup - 1)];
-        }
+        for (int it = 0; it < HB; ++it) x[it] = *reinterpret_cast<const VT*>(src + voff[base + it]);
 #pragma unroll
         for (int it = 0; it < HB; ++it) Coef<REAL>::fma(osum[it], cf, x[it]);
       }
-      // row slots: one table word per column of the block and (block, source block) pair
-      for (uint32_t sl = t.rs_ptr[kb]; sl < t.rs_ptr[kb + 1]; ++sl) {
-        const uint32_t* __restrict__ tab = t.rs_tab + t.rs_off[sl];
-        uint32_t e[HB];
-        bool none = true;
+      // row slots: one table word per column of the block and (block, source block) pair; the words of SB slots
+      // are fetched together so that the gathers that depend on them follow one table round trip, not SB
+      const uint32_t rs_end = t.rs_ptr[kb + 1];
+      constexpr int SB = 2;
+      for (uint32_t sl0 = t.rs_ptr[kb]; sl0 < rs_end; sl0 += SB) {
+        uint32_t e[SB][HB];
 #pragma unroll
-        for (int it = 0; it < HB; ++it) {
-          e[it] = tab[min((int)threadIdx.x + (base + it) * T, npairs - 1) / R];
-          none = none && (e[it] == emptyz);
-        }
-        if (__all(none)) continue;
-        VT x[HB];
+        for (int jj = 0; jj < SB; ++jj) {
+          if (sl0 + jj < rs_end) {  // uniform
+            const uint32_t* __restrict__ tab = t.rs_tab + t.rs_off[sl0 + jj];
 #pragma unroll
-        for (int it = 0; it < HB; ++it) {
-          const int q = min((int)threadIdx.x + (base + it) * T, npairs - 1);
-          x[it] = v[(int64_t)(e[it] & TILE_OFF_MASK) * s.pitch + min(i0 + q % R, s.dimup - 1)];
+            for (int it = 0; it < HB; ++it) e[jj][it] = tab[ccol[base + it]];
+          }
         }
 #pragma unroll
-        for (int it = 0; it < HB; ++it) Coef<REAL>::fma(osum[it], lcoef[e[it] >> TILE_COEF_SHIFT], x[it]);
+        for (int jj = 0; jj < SB; ++jj) {
+          if (sl0 + jj < rs_end) {
+            bool none = true;
+#pragma unroll
+            for (int it = 0; it < HB; ++it) none = none && (e[jj][it] == emptyz);
+            if (__all(none)) continue;
+            VT x[HB];
+#pragma unroll
+            for (int it = 0; it < HB; ++it)
+              x[it] = *reinterpret_cast<const VT*>(vrow64 + (uint64_t)(e[jj][it] & TILE_OFF_MASK) * pitchb);
+#pragma unroll
+            for (int it = 0; it < HB; ++it) Coef<REAL>::fma(osum[it], lds_ld<CT>((e[jj][it] >> TILE_COEF_SHIFT) << LCB), x[it]);
+          }
+        }
       }
 #pragma unroll
       for (int it = 0; it < HB; ++it) {
-        const int q = threadIdx.x + (base + it) * T;
-        if (q < npairs) {
-          VT a = lds[(q % R) * ns + q / R];
+        if ((tid >> LR) + (base + it) * cstep < n) {
+          const uint32_t q = tq + (base + it) * T * VB;
+          VT a = lds_ld<VT>(q);
           vadd(a, osum[it]);
-          lds[(q % R) * ns + q / R] = a;
+          lds_st<VT>(q, a);
         }
       }
     }
   }
   __syncthreads();
-  // store into the column-group-blocked scratch wt[group][row][WC] (WC = pass A's columns per tile): the R rows x
-  // WC columns of one group are R*WC*16 contiguous, aligned bytes -- strided WRITES need long aligned runs on this
-  // memory system -- and pass A later reads its whole tile of wt as one contiguous run.
   const int cl0 = max(cb0, s.dw0) - s.dw0, cl1 = min(cb0 + n, s.dw0 + s.qdw) - s.dw0;  // local output columns [cl0,cl1)
   if (wc == 0) {
     // natural layout [local column][pitch], lanes along the R rows (row-panel product of the all-to-all exchange:
     // 1/P of the data, so the short strided write runs do not matter)
-    for (int q = threadIdx.x; q < npairs; q += T) {
-      const int r = q % R, lc = cb0 + q / R - s.dw0;
-      if (lc >= cl0 && lc < cl1 && i0 + r < s.dimup) wt[(int64_t)lc * s.pitch + i0 + r] = lds[r * ns + q / R];
+    for (int q = tid, k = 0; q < n * R; q += T, ++k) {
+      const int lc = cb0 + (q >> LR) - s.dw0;
+      if (lc >= cl0 && lc < cl1 && i0 + r < s.dimup) wt[(int64_t)lc * s.pitch + i0 + r] = lds_ld<VT>(tq + k * T * VB);
     }
     return;
   }
-  const int g0 = cl0 / wc, g1 = (cl1 + wc - 1) / wc;
-  const int per = R * wc;
-  for (int q = threadIdx.x; q < (g1 - g0) * per; q += T) {
-    const int gq = g0 + q / per, rem = q % per;
-    const int r = rem / wc, cc = rem % wc;
-    const int lc = gq * wc + cc;  // local column
-    if (lc >= cl0 && lc < cl1 && i0 + r < s.dimup)
+  // store into the column-group-blocked scratch wt[group][row][wc] (wc = pass A's scratch group width, a power of two): the
+  // R rows x wc columns of one group are R*wc*16 contiguous, aligned bytes -- strided WRITES need long aligned runs on this
+  // memory system -- and pass A later reads its whole tile of wt as one contiguous run.  A sweep of the workgroup covers
+  // T/(R*wc) groups = T/R columns; uniform base and LDS address advance by constants from sweep to sweep.
+  {
+    const int lw = 31 - __clz(wc);
+    const int g0 = cl0 >> lw, g1 = (cl1 + wc - 1) >> lw;
+    const int per = R << lw;                 // elements of one group's patch
+    const int gstep = T >> (LR + lw);        // groups per sweep (T >= R*wc)
+    const int rem = tid & (per - 1);
+    const int r2 = rem >> lw, cc = rem & (wc - 1);
+    const int gi = tid >> (LR + lw);
+    const bool rowok = i0 + r2 < s.dimup;
+    int lc = ((g0 + gi) << lw) + cc;         // local column of this thread in the current sweep
+    const uint32_t so = (uint32_t)gi * ((uint32_t)s.dimup * per / R * VB) + (uint32_t)rem * VB;
+    // LDS byte offset of (column, row); a sweep advances the column by T/R, which leaves its swizzle bits alone
+    uint32_t lo = ltile + (uint32_t)(((lc + s.dw0 - cb0) << LTB) + ((r2 << LVB) ^ (int)swz_of((uint32_t)(lc + s.dw0 - cb0))));
+    char* __restrict__ dstb = reinterpret_cast<char*>(wt) + ((int64_t)g0 * s.dimup + i0) * ((int64_t)VB << lw);
+    const int64_t dstep = (int64_t)gstep * s.dimup * ((int64_t)VB << lw);
+    for (int g = g0; g < g1; g += gstep) {
       // streaming store: wt is read back once, by pass A, long after it has left L2; not letting it linger leaves the L2
       // to the tile lines that the out-of-block gathers of the neighbouring workgroups hit (-3 % on pass B, measured)
-      store_stream(&wt[((int64_t)gq * s.dimup + i0 + r) * wc + cc], lds[r * ns + (lc + s.dw0 - cb0)]);
+      if (lc >= cl0 && lc < cl1 && rowok) store_stream(reinterpret_cast<VT*>(dstb + so), lds_ld<VT>(lo));
+      lc += gstep << lw;
+      lo += T * VB;
+      dstb += dstep;
+    }
   }
 }
 
@@ -722,10 +774,8 @@ static hipError_t launch_tiled_vt(const DevSector& s, const TilePlan& plan, cons
   int wc = wt_natural ? 0 : (RV ? real_wc(plan) : std::max(C, plan.opt.wt_cols));
   bool job_a = false;
   if constexpr (!RV) job_a = (passes & 1) && use_job_up(s, plan, false, lz != nullptr, wt_natural, &wc);
-  constexpr int SLOTS = 256 / (int)sizeof(VT);
   const int lds_a = std::max(plan.up.max_block * C * (int)sizeof(VT) + tu.nscoef * 16, plan.opt.lds_min_kb_up * 1024);
-  const int lds_b = std::max((((plan.dw.max_block + SLOTS - 1) & ~(SLOTS - 1)) + SLOTS / R) * R * (int)sizeof(VT) + td.nscoef * 16,
-                             plan.opt.lds_min_kb_dw * 1024);
+  const int lds_b = std::max(plan.dw.max_block * R * (int)sizeof(VT) + ((td.nscoef * 16 + 255) & ~255), plan.opt.lds_min_kb_dw * 1024);
   const int ta = plan.opt.threads_up, tb = plan.opt.threads_dw;
   const bool norb1 = s.diag.mode == 0 && s.diag.cross.norb == 1;
   hipError_t e = hipSuccess;
