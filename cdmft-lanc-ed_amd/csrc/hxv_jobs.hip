@@ -73,8 +73,9 @@ struct JobUp {
   int wt_bytes;        // one wt group buffer: block rows x max(wc,1) columns
   int kin_rows;        // rows of the in-block table (plan k_in)
   int max_outer;       // most out-of-block slots (row slots + block hops) of any block
-  int debug;           // timing experiments only (HXV_DEBUG builds of the options): 1 no out-of-block gathers, 2 no in-block hops,
-                       // 4 no compute at all, 8 loader skips wt, 16 loader issues nothing
+  int debug;           // timing experiments only (option job_debug): 1 no out-of-block gathers, 2 no in-block hops, 4 no compute at all,
+                       // 8 loader skips wt, 16 loader issues nothing, 32 no hv store, 64 nt policy for the wt DMA,
+                       // 128 every gather reads the thread's own row, 256 gathers scattered over the own block
   const uint32_t* order;  // [nblocks] blocks of a chunk, largest first
 };
 
@@ -84,8 +85,6 @@ template <int C, bool REALC, bool NORB1, bool LZ, int KIN, int KO, typename VT>
 __global__ void __launch_bounds__(1024) hxv_up_job(DevSector s, DevTiles t, JobUp jb, LzEpilogue lz) {
   using CT = typename Coef<REALC>::type;
   constexpr uint32_t OFFM = (1u << TILE_COEF_SHIFT) - 1u;
-  extern __shared__ double2 lds_raw[];
-  char* lds = reinterpret_cast<char*>(lds_raw);
   const int b = blockIdx.x;
   const int xcd = b & 7, j = b >> 3;
   const int chunk = j / t.nblocks;
@@ -104,8 +103,15 @@ __global__ void __launch_bounds__(1024) hxv_up_job(DevSector s, DevTiles t, JobU
   const int nch = (n + 63) >> 6;  // 1 KiB pieces per tile column
   const VT* __restrict__ v = reinterpret_cast<const VT*>(jb.v);
   const VT* __restrict__ wt = reinterpret_cast<const VT*>(jb.wt);
-  char* wtb = lds + (size_t)nst * jb.stage_bytes;  // two wt group buffers
-  CT* lcoef = reinterpret_cast<CT*>(wtb + 2 * (size_t)jb.wt_bytes);
+  // LDS by byte offset (hxv_tile_dev.hpp): signed coefficients at 0 (a shifted table word is their address), the loader's
+  // bookkeeping words, the tile ring, two wt group buffers
+  static_assert(sizeof(VT) == 16, "complex vectors only");
+  constexpr int LCB = REALC ? 3 : 4;
+  const uint32_t book = ((uint32_t)t.nscoef * 16 + 255) & ~255u;
+  const uint32_t ring0 = book + 256;
+  const uint32_t wtb = ring0 + (uint32_t)nst * jb.stage_bytes;
+  const int wcw = max(jb.wc, 1);
+  const int lw = 31 - __clz(wcw);  // wcw is a power of two
 
   if (wave == JOB_LOADER) {
     // ------------------------------------------------------------------ loader wave: LDS-DMA only, no register loads
@@ -114,10 +120,10 @@ __global__ void __launch_bounds__(1024) hxv_up_job(DevSector s, DevTiles t, JobU
     int ops = 0;              // LDS-DMA instructions issued so far (they retire in order)
     // value of `ops` after the last piece of the tile in each ring stage / of the wt group in each group buffer
     // (loader-private words in LDS: dynamic indexing without register arrays)
-    int* vdone = reinterpret_cast<int*>(lcoef + t.nscoef);
-    int* wdone = vdone + JOB_MAX_STAGES;
+    const uint32_t vdone = book, wdone = book + 4 * JOB_MAX_STAGES;
+    int st_issue = 0;         // ring stage of the next tile to issue
     auto issue_v = [&](int k) {
-      char* base = lds + (size_t)(k % nst) * jb.stage_bytes;
+      const uint32_t base = ring0 + (uint32_t)st_issue * jb.stage_bytes;
       const int c0 = (g0 + k) * C;
       if (!nodma) {
 #pragma unroll
@@ -126,7 +132,7 @@ __global__ void __launch_bounds__(1024) hxv_up_job(DevSector s, DevTiles t, JobU
           const VT* __restrict__ src = v + (int64_t)(s.slab0 + c) * s.pitch + r0;
           for (int ch = 0; ch < nch; ++ch)
             __builtin_amdgcn_global_load_lds((glb_void_t*)(src + min(ch * 64 + lane, n - 1)),
-                                             (lds_void_t*)(base + ((size_t)cc * ns + ch * 64) * sizeof(VT)), 16, 0, 0);
+                                             (lds_void_t*)(base + (uint32_t)(cc * ns + ch * 64) * 16), 16, 0, 0);
         }
         ops += C * nch;
         if (LZ && lz.xm) {
@@ -137,44 +143,44 @@ __global__ void __launch_bounds__(1024) hxv_up_job(DevSector s, DevTiles t, JobU
             const VT* __restrict__ src = xm + (int64_t)c * s.pitch + r0;
             for (int ch = 0; ch < nch; ++ch)
               __builtin_amdgcn_global_load_lds((glb_void_t*)(src + min(ch * 64 + lane, n - 1)),
-                                               (lds_void_t*)(base + ((size_t)(C + cc) * ns + ch * 64) * sizeof(VT)), 16, 0, 0);
+                                               (lds_void_t*)(base + (uint32_t)((C + cc) * ns + ch * 64) * 16), 16, 0, 0);
           }
           ops += C * nch;
         }
       }
-      if (lane == 0) vdone[k % nst] = ops;
+      if (lane == 0) lds_st<int>(vdone + 4 * st_issue, ops);
+      st_issue = st_issue + 1 == nst ? 0 : st_issue + 1;
     };
     // wt arrives one column GROUP at a time (all wcw columns of the block's rows: one contiguous run of the
     // column-group-blocked scratch, every line read exactly once) into one of two group buffers
-    const int wcw = max(jb.wc, 1);
     const int wpieces = (n * wcw + 63) >> 6;
     auto issue_w = [&](int G) {
       if (wt && !nodma) {
-        char* base = wtb + (size_t)(G & 1) * jb.wt_bytes;
+        const uint32_t base = wtb + (uint32_t)(G & 1) * jb.wt_bytes;
         const VT* __restrict__ src = jb.wc ? wt + ((int64_t)G * s.dimup + r0) * wcw : wt + (int64_t)G * s.pitch + r0;
         for (int q = 0; q < wpieces; ++q)
           if (jb.debug & 64)  // (experiment: streaming policy for the once-read scratch)
-            __builtin_amdgcn_global_load_lds((glb_void_t*)(src + min(q * 64 + lane, n * wcw - 1)), (lds_void_t*)(base + (size_t)q * 64 * sizeof(VT)), 16,
-                                             0, 2);
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(src + min(q * 64 + lane, n * wcw - 1)), (lds_void_t*)(base + (uint32_t)q * 1024), 16, 0, 2);
           else
-            __builtin_amdgcn_global_load_lds((glb_void_t*)(src + min(q * 64 + lane, n * wcw - 1)), (lds_void_t*)(base + (size_t)q * 64 * sizeof(VT)), 16,
-                                             0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(src + min(q * 64 + lane, n * wcw - 1)), (lds_void_t*)(base + (uint32_t)q * 1024), 16, 0, 0);
         ops += wpieces;
       }
-      if (lane == 0) wdone[G & 1] = ops;
+      if (lane == 0) lds_st<int>(wdone + 4 * (G & 1), ops);
     };
-    for (int q = lane; q < t.nscoef; q += 64) lcoef[q] = Coef<REALC>::from(t.scoef[q]);
+    for (int q = lane; q < t.nscoef; q += 64) lds_st<CT>((uint32_t)q << LCB, Coef<REALC>::from(t.scoef[q]));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the coefficient loads above are ordinary loads)
     const int cfirst = g0 * C, clast = min(g1 * C, s.qdw) - 1;
-    const int Gfirst = cfirst / wcw, Glast = clast / wcw;
+    const int Gfirst = cfirst >> lw, Glast = clast >> lw;
     issue_w(Gfirst);
     int issued = 0;
     for (; issued < min(nst - 1, ntile); ++issued) issue_v(issued);
     if (Gfirst < Glast) issue_w(Gfirst + 1);
     int Gprev = Gfirst;
+    int st_wait = 0;
     for (int k = 0; k < ntile; ++k) {
-      const int Gk = ((g0 + k) * C) / wcw;  // (C divides wcw or wcw == 1: a tile never straddles two groups)
-      const int need = __builtin_amdgcn_readfirstlane(max(vdone[k % nst], wdone[Gk & 1]));
+      const int Gk = ((g0 + k) * C) >> lw;  // (C divides wcw or wcw == 1: a tile never straddles two groups)
+      const int need = __builtin_amdgcn_readfirstlane(max(lds_ld<int>(vdone + 4 * st_wait), lds_ld<int>(wdone + 4 * (Gk & 1))));
+      st_wait = st_wait + 1 == nst ? 0 : st_wait + 1;
       wait_vmcnt(min(63, ops - need));  // tile k and its wt group have landed; younger pieces stay in flight
       wg_barrier();                     // A(k): publishes tile k, frees the buffer of tile k-1
       if (issued < ntile) {
@@ -193,15 +199,21 @@ __global__ void __launch_bounds__(1024) hxv_up_job(DevSector s, DevTiles t, JobU
   const int p = threadIdx.x;
   const bool row_ok = p < n;
   const bool wave_on = (wave << 6) < n;
-  const uint32_t EMPTY = (uint32_t)(t.nscoef - 1) << TILE_COEF_SHIFT;
+  // Table words are re-packed once per job so that a hop in the tile loop decodes in two instructions:
+  //   in-block      (coefficient's LDS byte address) << 16 | (source row * 16)
+  //   out-of-block  (coefficient index) << 23            | (source row of the column * 16)     [dimup < 65536: job_up_usable]
   uint32_t tin[KIN], tou[KO];
   int kin = 0, nouter = 0;
   double au = 0.0;
   uint32_t mu = 0;
   if (wave_on) {
     const int pr = min(p, n - 1);
+    const uint32_t EMPTY = (uint32_t)(t.nscoef - 1) << TILE_COEF_SHIFT;
 #pragma unroll
-    for (int k = 0; k < KIN; ++k) tin[k] = (row_ok && k < jb.kin_rows) ? t.ell_in[(int64_t)k * s.dimup + r0 + pr] : EMPTY;
+    for (int k = 0; k < KIN; ++k) {
+      const uint32_t e = (row_ok && k < jb.kin_rows) ? t.ell_in[(int64_t)k * s.dimup + r0 + pr] : EMPTY;
+      tin[k] = ((e >> TILE_COEF_SHIFT) << (16 + LCB)) | ((e & OFFM) << 4);
+    }
     const int rs0 = (int)t.rs_ptr[kb], nrs = (int)t.rs_ptr[kb + 1] - rs0;
     const int bh0 = (int)t.bh_ptr[kb], nbh = (int)t.bh_ptr[kb + 1] - bh0;
     nouter = __builtin_amdgcn_readfirstlane(nrs + nbh);
@@ -214,7 +226,10 @@ __global__ void __launch_bounds__(1024) hxv_up_job(DevSector s, DevTiles t, JobU
         const int h = bh0 + i - nrs;
         e = (t.bh[2 * h + 1] << TILE_COEF_SHIFT) | (t.bh[2 * h] + (uint32_t)pr);
       }
-      tou[i] = row_ok ? e : EMPTY;
+      if (!row_ok) e = EMPTY;
+      tou[i] = ((e >> TILE_COEF_SHIFT) << 23) | ((e & OFFM) << 4);
+      if (jb.debug & 128) tou[i] = (tou[i] & ~0x7FFFFFu) | ((uint32_t)(r0 + pr) << 4);  // experiment: every gather reads the thread's own row
+      if (jb.debug & 256) tou[i] = (tou[i] & ~0x7FFFFFu) | ((uint32_t)(r0 + ((pr * 37 + i * 101) % n)) << 4);  // experiment: scattered rows of the own block
     }
     kin = (int)(__builtin_amdgcn_readfirstlane(t.gmax[t.gstart[kb] + wave]) & 0xFFFFu);
     if (s.diag.mode == 0) {
@@ -225,57 +240,66 @@ __global__ void __launch_bounds__(1024) hxv_up_job(DevSector s, DevTiles t, JobU
   double asum = 0.0;
   const double sc = LZ ? lz.scal[lz.i_s] : 1.0;
   const double cm = (LZ && lz.xm) ? lz.scal[lz.i_c] : 0.0;
-  VT* __restrict__ hv = reinterpret_cast<VT*>(jb.hv);
-  const int wcw = max(jb.wc, 1);
+  char* __restrict__ hvb = reinterpret_cast<char*>(jb.hv) + (int64_t)r0 * 16;
+  const char* __restrict__ vb = reinterpret_cast<const char*>(v);
+  const uint32_t p16 = (uint32_t)p << 4, pw16 = p16 << lw;
+  const int64_t pitchb = (int64_t)s.pitch * 16;
+  const bool outer_on = !(jb.debug & 1), inner_on = !(jb.debug & 2);
   VT pend[C];       // result of the previous tile, stored one tile late
   int pend_c0 = 0;
   auto flush_pending = [&](int ncols) {
     if (row_ok && !(jb.debug & 32)) {
 #pragma unroll
-      for (int cc = 0; cc < C; ++cc)
-        if (cc < ncols) store_stream(&hv[(int64_t)(pend_c0 + cc) * s.pitch + r0 + p], pend[cc]);
+      for (int cc = 0; cc < C; ++cc) {
+        if (cc < ncols) store_stream(reinterpret_cast<VT*>(hvb + (int64_t)(pend_c0 + cc) * pitchb + p16), pend[cc]);
+      }
     }
   };
 
-  for (int k = 0; k < ntile; ++k) {
+  uint32_t stage_off = ring0;  // ring stage of tile k
+  int stage = 0;
+  // out-of-block gathers (slots 0..7) of a tile
+  auto issue_outer = [&](VT (&xo)[8][C], int k) {
+    const int c0 = (g0 + k) * C;
+    const int nc = min(C, s.qdw - c0);
+    const char* __restrict__ vcol0 = vb + (int64_t)(s.slab0 + c0) * pitchb;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      // (blocks have 4..8 slots at C3; a wave-uniform guard skips the rest)
+      if (i < 4 || i < nouter) {
+        const uint32_t off = tou[i] & 0x7FFFFFu;
+#pragma unroll
+        for (int cc = 0; cc < C; ++cc)
+          xo[i][cc] = *reinterpret_cast<const VT*>((C == 1 ? vcol0 : vcol0 + (int64_t)min(cc, nc - 1) * pitchb) + off);
+      }
+    }
+  };
+  auto tile = [&](VT (&xo)[8][C], int k) {
     wg_barrier();  // A(k)
-    if (!wave_on || (jb.debug & 4)) continue;
+    const uint32_t tile_off = stage_off;
+    stage = stage + 1 == nst ? 0 : stage + 1;
+    stage_off = ring0 + (uint32_t)stage * jb.stage_bytes;
+    if (!wave_on || (jb.debug & 4)) return;
     // keep the table words opaque per tile: otherwise the compiler hoists the decoded LDS address and coefficient address
     // of every entry out of the tile loop (two more registers per entry) and spills
 #pragma unroll
     for (int q = 0; q < KIN; ++q) asm volatile("" : "+v"(tin[q]));
 #pragma unroll
     for (int q = 0; q < KO; ++q) asm volatile("" : "+v"(tou[q]));
-    const VT* ldsv = reinterpret_cast<const VT*>(lds + (size_t)(k % nst) * jb.stage_bytes);
     const int c0 = (g0 + k) * C;
     const int nc = min(C, s.qdw - c0);
-    const VT* __restrict__ vcol0 = v + (int64_t)(s.slab0 + c0) * s.pitch;
-    // out-of-block sources first (slots 0..7): their L2 latency runs under the in-block LDS phase
-    VT xo[8][C];
-    // (the previous tile's result is stored AFTER these loads are issued: vector-memory operations retire in order, so a
-    //  store issued first would put its write acknowledgement in front of the gathers this tile waits for)
-    if (!(jb.debug & 1)) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const VT* __restrict__ src = vcol0 + (tou[i] & OFFM);
-#pragma unroll
-        for (int cc = 0; cc < C; ++cc) xo[i][cc] = src[(int64_t)min(cc, nc - 1) * s.pitch];
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int cc = 0; cc < C; ++cc) xo[i][cc] = vzero<VT>();
-    }
+    const char* __restrict__ vcol0 = vb + (int64_t)(s.slab0 + c0) * pitchb;
+    // (the previous tile's result is stored AFTER the gathers are issued: vector-memory operations retire in order, so a
+    //  store issued first would put its write acknowledgement in front of them)
+    if (outer_on) issue_outer(xo, k);
     if (k > 0) flush_pending(C);
     VT acc[C], xq[C];
 #pragma unroll
     for (int cc = 0; cc < C; ++cc) {
-      xq[cc] = ldsv[cc * ns + p];
+      xq[cc] = lds_ld<VT>(tile_off + (uint32_t)(cc * ns) * 16 + p16);
       if (wt) {
         const int c = c0 + min(cc, nc - 1);
-        const VT* wg = reinterpret_cast<const VT*>(wtb + (size_t)((c / wcw) & 1) * jb.wt_bytes);
-        acc[cc] = wg[p * wcw + (c % wcw)];
+        acc[cc] = lds_ld<VT>(wtb + (uint32_t)((c >> lw) & 1) * jb.wt_bytes + (uint32_t)(c & (wcw - 1)) * 16 + pw16);
       } else {
         acc[cc] = vzero<VT>();
       }
@@ -292,38 +316,42 @@ __global__ void __launch_bounds__(1024) hxv_up_job(DevSector s, DevTiles t, JobU
     // in-block hops: gathers from the LDS tile, tables in registers
 #pragma unroll
     for (int k4 = 0; k4 < KIN; k4 += 4) {
-      if (k4 < kin && !(jb.debug & 2)) {
+      if (k4 < kin && inner_on) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const uint32_t e = tin[k4 + u];
-          const CT cf = lcoef[e >> TILE_COEF_SHIFT];
-          const int off = (int)(e & OFFM);
+          const CT cf = lds_ld<CT>(e >> 16);
+          const uint32_t src = (e & 0xFFFFu) + tile_off;
 #pragma unroll
-          for (int cc = 0; cc < C; ++cc) Coef<REALC>::fma(acc[cc], cf, ldsv[cc * ns + off]);
+          for (int cc = 0; cc < C; ++cc) Coef<REALC>::fma(acc[cc], cf, lds_ld<VT>(src + (uint32_t)(cc * ns) * 16));
         }
       }
     }
+    if (outer_on) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const CT cf = lcoef[tou[i] >> TILE_COEF_SHIFT];
-#pragma unroll
-      for (int cc = 0; cc < C; ++cc) Coef<REALC>::fma(acc[cc], cf, xo[i][cc]);
-    }
-    // blocks with more than 8 out-of-block slots (wave-uniform): the rest in further batches of 8, latency exposed
-#pragma unroll
-    for (int b8 = 8; b8 < KO; b8 += 8) {
-      if (b8 < nouter && !(jb.debug & 1)) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const VT* __restrict__ src = vcol0 + (tou[b8 + i] & OFFM);
-#pragma unroll
-          for (int cc = 0; cc < C; ++cc) xo[i][cc] = src[(int64_t)min(cc, nc - 1) * s.pitch];
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const CT cf = lcoef[tou[b8 + i] >> TILE_COEF_SHIFT];
+      for (int i = 0; i < 8; ++i) {
+        if (i < 4 || i < nouter) {
+          const CT cf = lds_ld<CT>(REALC ? tou[i] >> 20 : (tou[i] >> 23) << LCB);
 #pragma unroll
           for (int cc = 0; cc < C; ++cc) Coef<REALC>::fma(acc[cc], cf, xo[i][cc]);
+        }
+      }
+      // blocks with more than 8 out-of-block slots (wave-uniform): the rest in further batches of 8, latency exposed
+#pragma unroll
+      for (int b8 = 8; b8 < KO; b8 += 8) {
+        if (b8 < nouter) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const uint32_t off = tou[b8 + i] & 0x7FFFFFu;
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc) xo[i][cc] = *reinterpret_cast<const VT*>(vcol0 + (int64_t)min(cc, nc - 1) * pitchb + off);
+          }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const CT cf = lds_ld<CT>(REALC ? tou[b8 + i] >> 20 : (tou[b8 + i] >> 23) << LCB);
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc) Coef<REALC>::fma(acc[cc], cf, xo[i][cc]);
+          }
         }
       }
     }
@@ -332,25 +360,26 @@ __global__ void __launch_bounds__(1024) hxv_up_job(DevSector s, DevTiles t, JobU
       VT w = acc[cc];
       if (LZ) {
         vscale(w, sc);
-        if (lz.xm) Coef<true>::fma(w, -cm, ldsv[(C + cc) * ns + p]);
+        if (lz.xm) Coef<true>::fma(w, -cm, lds_ld<VT>(tile_off + (uint32_t)((C + cc) * ns) * 16 + p16));
         if (row_ok && cc < nc) asum += sc * vdot(xq[cc], w);
       }
       pend[cc] = w;
     }
     pend_c0 = c0;
-  }
+  };
+  VT xa[8][C];
+  for (int k = 0; k < ntile; ++k) tile(xa, k);
   if (wave_on && ntile > 0 && !(jb.debug & 4)) flush_pending(min(C, s.qdw - pend_c0));
   if (LZ) {
     // wavefront partial sums first (DPP/shuffle), one LDS word per wave afterwards
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) asum += __shfl_down(asum, off, 64);
     wg_barrier();  // every tile buffer is free (the loader has left)
-    double* red = reinterpret_cast<double*>(lds);
-    if (lane == 0) red[wave] = asum;
+    if (lane == 0) lds_st<double>(ring0 + 8 * wave, asum);
     wg_barrier();
     if (threadIdx.x == 0) {
       double tot = 0.0;
-      for (int w = 0; w < JOB_LOADER; ++w) tot += red[w];
+      for (int w = 0; w < JOB_LOADER; ++w) tot += lds_ld<double>(ring0 + 8 * w);
       lz.partial[blockIdx.x] = tot;
     }
   }
@@ -405,7 +434,7 @@ hipError_t launch_up_job_c(const DevSector& s, const DevTiles& t, const JobUp& j
 bool job_up_usable(const DevSector& s, const TilePlan& plan) {
   const SpinTiles& u = plan.up;
   return plan.usable && s.diag.mode == 0 && u.max_block <= 64 * JOB_LOADER && u.k_in <= JOB_KIN && u.max_outer <= JOB_KO &&
-         u.d_order != nullptr;
+         u.d_order != nullptr && s.dimup < 65536;  // (packed out-of-block words: hxv_up_job)
 }
 
 static void job_up_geometry(const DevSector& s, const TilePlan& plan, bool lz_xm, int wc, JobUp& jb, int& lds_bytes, int64_t& nwg) {
@@ -417,7 +446,7 @@ static void job_up_geometry(const DevSector& s, const TilePlan& plan, bool lz_xm
   jb.ns = (plan.up.max_block + 63) & ~63;
   jb.stage_bytes = (1 + (lz_xm ? 1 : 0)) * C * jb.ns * 16;
   jb.wt_bytes = jb.ns * std::max(wc, 1) * 16;
-  const int tab = (2 * plan.ncoef_up + 1) * 16 + 256;
+  const int tab = (((2 * plan.ncoef_up + 1) * 16 + 255) & ~255) + 256;  // coefficients, loader bookkeeping words
   jb.nst = std::min(std::min(plan.opt.job_stages, JOB_MAX_STAGES), (160 * 1024 - tab - 2 * jb.wt_bytes) / jb.stage_bytes);
   lds_bytes = jb.nst * jb.stage_bytes + 2 * jb.wt_bytes + tab;
   jb.kin_rows = std::min(plan.up.k_in, (plan.up.k_in_real + 3) & ~3);
