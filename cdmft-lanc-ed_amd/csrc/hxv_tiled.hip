@@ -229,19 +229,27 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_dw(DevSector s, DevTiles t, 
   const uint32_t pitchb = (uint32_t)s.pitch * VB;  // bytes per column
   const uint32_t rowb = (uint32_t)(min(i0 + r, s.dimup - 1) - i0) * VB;
   const char* __restrict__ vrows = reinterpret_cast<const char*>(v) + (int64_t)i0 * VB;  // uniform
-  uint32_t voff[NP];  // byte offset of pair it relative to (first column of a block, row i0)
-  uint32_t ccol[NP];  // its column within the block (clamped)
+  // column of pair `it` within the block (clamped) and its byte offset relative to (first column of a block, row i0);
+  // the offsets are kept in registers when a thread has few pairs and recomputed (two instructions) when it has eight
+  auto ccol = [&](int it) -> uint32_t { return (uint32_t)min((tid >> LR) + it * cstep, n - 1); };
+  constexpr bool KEEP = NP <= 4;
+  uint32_t voff_keep[KEEP ? NP : 1];
+  if constexpr (KEEP) {
 #pragma unroll
-  for (int it = 0; it < NP; ++it) {
-    ccol[it] = (uint32_t)min((tid >> LR) + it * cstep, n - 1);
-    voff[it] = ccol[it] * pitchb + rowb;
+    for (int it = 0; it < NP; ++it) voff_keep[it] = ccol(it) * pitchb + rowb;
   }
+  auto voff = [&](int it) -> uint32_t {
+    if constexpr (KEEP)
+      return voff_keep[it];
+    else
+      return ccol(it) * pitchb + rowb;
+  };
   // phase 0: tile load
   if (s.vcol_identity) {
     const char* __restrict__ src = vrows + (int64_t)cb0 * pitchb;
     VT x[NP];
 #pragma unroll
-    for (int it = 0; it < NP; ++it) x[it] = *reinterpret_cast<const VT*>(src + voff[it]);
+    for (int it = 0; it < NP; ++it) x[it] = *reinterpret_cast<const VT*>(src + voff(it));
 #pragma unroll
     for (int it = 0; it < NP; ++it) {
       if ((tid >> LR) + it * cstep < n) lds_st<VT>(tq + it * T * VB, x[it]);
@@ -249,7 +257,7 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_dw(DevSector s, DevTiles t, 
   } else {
     uint32_t slot[NP];
 #pragma unroll
-    for (int it = 0; it < NP; ++it) slot[it] = s.vcol[cb0 + ccol[it]];
+    for (int it = 0; it < NP; ++it) slot[it] = s.vcol[cb0 + ccol(it)];
     VT x[NP];
 #pragma unroll
     for (int it = 0; it < NP; ++it) x[it] = *reinterpret_cast<const VT*>(vrows + ((uint64_t)slot[it] * pitchb + rowb));
@@ -258,6 +266,7 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_dw(DevSector s, DevTiles t, 
       if ((tid >> LR) + it * cstep < n) lds_st<VT>(tq + it * T * VB, x[it]);
     }
   }
+  const uint32_t rs0 = t.rs_ptr[kb], rs_end = t.rs_ptr[kb + 1];
   __syncthreads();
   // in-block hops, one column per thread (plan guarantees n <= blockDim.x)
   {
@@ -311,22 +320,21 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_dw(DevSector s, DevTiles t, 
         const char* __restrict__ src = vrows + (int64_t)t.bh[2 * h] * pitchb;
         VT x[HB];
 #pragma unroll
-        for (int it = 0; it < HB; ++it) x[it] = *reinterpret_cast<const VT*>(src + voff[base + it]);
+        for (int it = 0; it < HB; ++it) x[it] = *reinterpret_cast<const VT*>(src + voff(base + it));
 #pragma unroll
         for (int it = 0; it < HB; ++it) Coef<REAL>::fma(osum[it], cf, x[it]);
       }
       // row slots: one table word per column of the block and (block, source block) pair; the words of SB slots
       // are fetched together so that the gathers that depend on them follow one table round trip, not SB
-      const uint32_t rs_end = t.rs_ptr[kb + 1];
       constexpr int SB = 2;
-      for (uint32_t sl0 = t.rs_ptr[kb]; sl0 < rs_end; sl0 += SB) {
+      for (uint32_t sl0 = rs0; sl0 < rs_end; sl0 += SB) {
         uint32_t e[SB][HB];
 #pragma unroll
         for (int jj = 0; jj < SB; ++jj) {
           if (sl0 + jj < rs_end) {  // uniform
             const uint32_t* __restrict__ tab = t.rs_tab + t.rs_off[sl0 + jj];
 #pragma unroll
-            for (int it = 0; it < HB; ++it) e[jj][it] = tab[ccol[base + it]];
+            for (int it = 0; it < HB; ++it) e[jj][it] = tab[ccol(base + it)];
           }
         }
 #pragma unroll
@@ -590,8 +598,9 @@ void build_spin_tiles(const SpinOp& op, const std::vector<uint32_t>& map, int lo
   t.bh_per_row = bh_rows / dim;
   t.rs_per_row = rs_rows / dim;
   t.max_outer = 0;
-  for (int k = 0; k < t.nblocks; ++k)
+  for (int k = 0; k < t.nblocks; ++k) {
     t.max_outer = std::max<int>(t.max_outer, (int)(h.bh_ptr[k + 1] - h.bh_ptr[k]) + (int)(h.rs_ptr[k + 1] - h.rs_ptr[k]));
+  }
   h.order.resize(t.nblocks);
   std::iota(h.order.begin(), h.order.end(), 0u);
   std::stable_sort(h.order.begin(), h.order.end(),
