@@ -329,8 +329,8 @@ int hxv_apply_host(hxv_handle* h, int64_t nloc, const void* v, void* hv) {
   if (!h->d_stage_v) {
     HIPCHK(pool_alloc(h->device, bytes, (void**)&h->d_stage_v));
     HIPCHK(pool_alloc(h->device, bytes, (void**)&h->d_stage_hv));
-    HIPCHK(hipMemset(h->d_stage_v, 0, bytes));
-    HIPCHK(hipMemset(h->d_stage_hv, 0, bytes));
+    HIPCHK(hipMemsetAsync(h->d_stage_v, 0, bytes, h->stream));  // (on the handle's stream: it does not synchronise with the null stream)
+    HIPCHK(hipMemsetAsync(h->d_stage_hv, 0, bytes, h->stream));
     h->device_bytes += 2 * (int64_t)bytes;
   }
   if (h->host.qdw > 0) HIPCHK(hipMemcpy2DAsync(h->d_stage_v, pit, v, col, col, (size_t)h->host.qdw, hipMemcpyHostToDevice, h->stream));

@@ -404,6 +404,7 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
   int n_full = 0, n_local = 0;  // Gram-Schmidt passes against the whole basis / against the two local vectors only
   bool closed = false;  // the Krylov space closed (invariant subspace): every returned pair is exact
   bool above = false;   // a check round stopped early: the lowest Ritz value minus its residual bound is already above `stop_above`
+  const bool local_fused = lanczos_local_step_available(h);
   auto trl = [&](int nlock, int nwant, uint64_t seed, double stop_above) -> int {
     above = false;
     const int ma = m - nlock;  // active basis size
@@ -436,11 +437,26 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
       meff = ma;
       beta_last = 0.0;
       for (int j = k; j < ma; ++j) {
-        int rc = real ? hxv_apply_device_real(h, av(j), av(j + 1), st) : apply_slab(h, av(j), av(j + 1), st);
-        if (rc) return rc;
-        ++nmv;
-        double w2 = 0.0;
         const int jt = nlock + j;
+        // a step that is known in advance to need only the two local projections runs through the fused product: pass A
+        // subtracts beta_j q_{j-1} and reduces alpha_j in its epilogue, one more pass subtracts alpha_j q_j and measures |w|
+        const bool fused_local = local_fused && !h->eigh_measure_all && j > k && !force_full;
+        int rc;
+        double w2 = 0.0;
+        if (fused_local) {
+          double al = 0.0, nw = 0.0;
+          rc = lanczos_local_step(h, real, av(j), av(j - 1), t_at(j, j - 1), av(j + 1), &al, &nw);
+          if (rc) return rc;
+          c[2 * jt] = al;
+          c[2 * jt + 1] = 0.0;
+          c[2 * (jt - 1)] = t_at(j, j - 1);
+          c[2 * (jt - 1) + 1] = 0.0;
+          w2 = nw * nw;
+        } else {
+          rc = real ? hxv_apply_device_real(h, av(j), av(j + 1), st) : apply_slab(h, av(j), av(j + 1), st);
+          if (rc) return rc;
+        }
+        ++nmv;
         // Partial re-orthogonalisation (Simon 1984) in its thick-restart form: the loss of orthogonality of the next
         // vector against every earlier basis vector is ESTIMATED from the recurrence the exact quantities obey
         // (om_*: <q_j, v_b>), and the whole basis is only touched when an estimate passes sqrt(eps) -- then for two
@@ -451,6 +467,8 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
         if (full) {
           rc = gs_pass(jt, nlock, first_after_restart || force_full, &w2);
           ++n_full;
+        } else if (fused_local) {
+          ++n_local;
         } else {
           rc = gs_local(jt, j > k, &w2);
           ++n_local;

@@ -30,6 +30,9 @@ void launch_to_real(const hxv_handle* h, const double2* src, double* dst, hipStr
 void launch_to_complex(const hxv_handle* h, const double* src, double2* dst, hipStream_t st);
 // deterministic start vector, real part of the complex one (imaginary part dropped)
 void launch_init_real(const hxv_handle* h, double* q, uint64_t seed, hipStream_t st);
+// one Lanczos step on normalised vectors through the fused product (hxv_lanczos.hip): w = H q - beta*qm, alpha = <q,w>, w -= alpha*q, |w|
+bool lanczos_local_step_available(const hxv_handle* h);
+int lanczos_local_step(hxv_handle* h, bool real, const double2* q, const double2* qm, double beta, double2* w, double* alpha, double* nrm_w);
 }  // namespace hxv
 
 #define HIPCHK(expr)                                                                                   \

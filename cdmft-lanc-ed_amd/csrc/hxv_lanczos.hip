@@ -491,7 +491,9 @@ int ensure_lz(hxv_handle* h, bool real) {
   for (auto& p : h->d_lz)
     if (!p) {
       HIPCHK(pool_alloc(h->device, bytes, (void**)&p));
-      HIPCHK(hipMemset(p, 0, bytes));
+      // on the handle's (non-blocking) stream: a null-stream memset is not ordered with the kernels that follow and could
+      // land on a recycled pool block after the start vector had been written into it
+      HIPCHK(hipMemsetAsync(p, 0, bytes, h->stream));
       h->device_bytes += (int64_t)bytes;
     }
   if (h->lz_buf_mode != (real ? 1 : 0)) {
@@ -513,6 +515,54 @@ void launch_to_complex(const hxv_handle* h, const double* src, double2* dst, hip
   hipLaunchKernelGGL(lz_to_complex, dim3(grid_for((int64_t)h->host.pitch * h->host.dimdw)), dim3(256), 0, st, h->host.dimup, h->host.dimdw,
                      h->host.pitch, pitch_real_of(h), src, dst);
 }
+// One Lanczos step on NORMALISED vectors for callers that keep their own basis (hxv_eigh_lowest): w = H q - beta*qm through
+// pass A's epilogue (qm may be null), alpha = <q,w> from its partial sums, then w -= alpha*q and |w|.  False if the fused
+// product does not apply to this handle (the caller then measures the two projections itself).
+bool lanczos_local_step_available(const hxv_handle* h) {
+  return h->kernel == 1 && h->plan.usable && !h->dev.nd.active && h->plan.opt.passes == 3 && h->plan.opt.debug == 0 && h->host.nranks == 1 &&
+         !comm_ready(h) && h->lz_fused;
+}
+
+int lanczos_local_step(hxv_handle* h, bool real, const double2* q, const double2* qm, double beta, double2* w, double* alpha, double* nrm_w) {
+  const int64_t n2 = real ? (int64_t)pitch_real_of(h) * h->host.dimdw / 2 : (int64_t)h->host.pitch * h->host.qdw;
+  const int g = grid_for(n2);
+  const int64_t nwg = tiled_pass_up_workgroups(h->dev, h->plan, real);
+  if (nwg > h->lz_partial_n) {
+    if (h->d_lz_partial) (void)hipFree(h->d_lz_partial);
+    HIPCHK(hipMalloc((void**)&h->d_lz_partial, (size_t)nwg * sizeof(double)));
+    h->lz_partial_n = nwg;
+  }
+  int rc = ensure_wt(h);
+  if (rc) return rc;
+  const double sc[2] = {1.0, qm ? beta : 0.0};
+  HIPCHK(hipMemcpyAsync(h->d_scalars + 2, sc, 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  LzEpilogue ep;
+  ep.xm = qm;
+  ep.scal = h->d_scalars;
+  ep.i_s = 2;
+  ep.i_c = 3;
+  ep.partial = h->d_lz_partial;
+  hipError_t e;
+  if (real) {
+    DevSector d = h->dev;
+    d.pitch = pitch_real_of(h);
+    e = launch_hxv_tiled_real(d, h->plan, (const double*)q, (double*)h->d_wt, (double*)w, h->stream, &ep);
+  } else {
+    e = launch_hxv_tiled(h->dev, h->plan, q, h->d_wt, w, h->stream, &ep);
+  }
+  if (e != hipSuccess) return fail(HXV_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+  h->n_apply++;
+  hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_lz_partial, (int)nwg, h->d_scalars, 0, 0);
+  hipLaunchKernelGGL(lz_sub_nrm, dim3(g), dim3(256), 0, h->stream, n2, w, q, h->d_scalars, 0, h->d_partials + RED_BLOCKS);
+  hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_partials + RED_BLOCKS, g, h->d_scalars, 1, 1);
+  double host[2];
+  HIPCHK(hipMemcpyAsync(host, h->d_scalars, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  *alpha = host[0];
+  *nrm_w = host[1];
+  return HXV_OK;
+}
+
 void launch_init_real(const hxv_handle* h, double* q, uint64_t seed, hipStream_t st) {
   const int64_t n = (int64_t)pitch_real_of(h) * h->host.dimdw;
   hipLaunchKernelGGL(lz_init_real, dim3(grid_for(n)), dim3(256), 0, st, n, q, seed, h->host.dimup, pitch_real_of(h));
@@ -749,8 +799,8 @@ int ensure_stage(hxv_handle* h) {
   if (!h->d_stage_v) {
     HIPCHK(pool_alloc(h->device, bytes, (void**)&h->d_stage_v));
     HIPCHK(pool_alloc(h->device, bytes, (void**)&h->d_stage_hv));
-    HIPCHK(hipMemset(h->d_stage_v, 0, bytes));
-    HIPCHK(hipMemset(h->d_stage_hv, 0, bytes));
+    HIPCHK(hipMemsetAsync(h->d_stage_v, 0, bytes, h->stream));  // (on the handle's stream: it does not synchronise with the null stream)
+    HIPCHK(hipMemsetAsync(h->d_stage_hv, 0, bytes, h->stream));
     h->device_bytes += 2 * (int64_t)bytes;
   }
   return HXV_OK;

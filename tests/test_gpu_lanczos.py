@@ -585,3 +585,23 @@ def test_graph_captured_tridiagonalisation_equals_the_stepwise_one(built, case):
         else:
             assert n1 == n0 == nl
             assert np.array_equal(a1, a0) and np.array_equal(b1, b0)
+
+
+def test_lanczos_after_eigh_on_a_fresh_handle_c4(built):
+    """The single-vector Lanczos right after the thick-restart solver on a handle that has not run Lanczos before: its
+    three vectors then come out of the pool block the solver's basis has just returned, and the zero-fill of a recycled
+    block has to be ordered with the kernels that follow (the handle's stream does not synchronise with the null stream;
+    at C4 size a null-stream memset used to land after the start vector had been written: E0 = 0 after one iteration)."""
+    import torch
+    import hxv
+    from hxv import models
+
+    sec = hxv.HxvSector.from_model(models.bhz_2d(Nbath=1), 8, 8)
+    ev, X, nconv, nmv = sec.eigh_lowest(2, 20, native=True)
+    del X
+    torch.cuda.empty_cache()
+    e0, vec, nit = sec.lanczos_eigh(512, 1e-13, native=True)
+    assert nit > 20 and abs(e0 - ev[0]) < 1e-9, (e0, ev, nit)
+    hv = sec.apply_device(vec)
+    assert (hv - e0 * vec).norm().item() < 1e-8
+    sec.close()
