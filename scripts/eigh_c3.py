@@ -10,6 +10,7 @@ wl = os.environ.get("SECTOR", "C3")
 m, (nup, ndw) = (models.hm_2dsquare(Nbath=3), (8, 8)) if wl == "C3" else (models.bhz_2d(Nbath=1), (8, 8)) if wl == "C4" else (models.hm_1dchain(), (6, 6))
 sec = hxv.HxvSector.from_model(m, nup, ndw)
 sec.set_option("eigh_measure_all", int(os.environ.get("MEASURE_ALL", 0)))
+sec.set_option("lanczos_fused", int(os.environ.get("FUSED", 1)))
 sec.set_option("real_vectors", int(os.environ.get("REAL_VECTORS", 1)))
 neigen, ncv = int(os.environ.get("NEIGEN", 2)), int(os.environ.get("NCV", 20))
 t = time.time()
