@@ -1,6 +1,6 @@
 """Host-only statistics of the prefix-block decomposition of one spin sector (no GPU needed):
 block sizes, in-block entries per row, row slots / block hops per block.  Used to dimension the
-register-resident tables of the persistent kernels (csrc/hxv_persist.hip).
+register-resident tables of the pipelined job kernels (csrc/hxv_jobs.hip).
 usage: plan_stats.py [C2|C3|C4|C5] [lowbits]"""
 import sys
 from itertools import combinations
