@@ -571,9 +571,6 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
         const double res = std::fabs(beta_last * S[(meff - 1) + (size_t)i * meff]);
         if (res <= tol * std::max(eps23, std::fabs(theta[i]))) ++nconv;
       }
-      if (getenv("HXV_EIGH_TRACE"))
-        fprintf(stderr, "[eigh] nlock %d restart %d k %d meff %d theta0 %.10f theta1 %.10f beta_last %.3e nconv %d full %d local %d\n", nlock, it, k, meff,
-                theta[0], meff > 1 ? theta[1] : 0.0, beta_last, nconv, n_full, n_local);
       closed = meff < ma;
       // check rounds only ask "is there a state below stop_above?": Ritz values come down monotonically and the residual
       // bounds how far the lowest one can still move, so the answer "no" does not need a converged pair
