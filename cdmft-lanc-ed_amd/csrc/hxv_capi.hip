@@ -437,6 +437,15 @@ int hxv_set_option(hxv_handle* h, const char* name, int64_t value) {
     h->plan.opt.job_debug = (int)value;
     return HXV_OK;
   }
+  if (!strcmp(name, "pair_rows")) {
+    if (value < -1 || value > 1) return fail(HXV_ERR_ARG, "pair_rows must be -1, 0 or 1");
+    h->plan.opt.pair_rows = (int)value;
+    return HXV_OK;
+  }
+  if (!strcmp(name, "job_max_blocks")) {
+    h->plan.opt.job_max_blocks = (int)value;
+    return HXV_OK;
+  }
   if (!strcmp(name, "passes")) {
     if (value < 1 || value > 3) return fail(HXV_ERR_ARG, "passes must be 1, 2 or 3");
     h->plan.opt.passes = (int)value;

@@ -434,7 +434,8 @@ hipError_t launch_up_job_c(const DevSector& s, const DevTiles& t, const JobUp& j
 bool job_up_usable(const DevSector& s, const TilePlan& plan) {
   const SpinTiles& u = plan.up;
   return plan.usable && s.diag.mode == 0 && u.max_block <= 64 * JOB_LOADER && u.k_in <= JOB_KIN && u.max_outer <= JOB_KO &&
-         u.d_order != nullptr && s.dimup < 65536;  // (packed out-of-block words: hxv_up_job)
+         u.d_order != nullptr && s.dimup < 65536 &&  // (packed out-of-block words: hxv_up_job)
+         u.nblocks <= plan.opt.job_max_blocks;
 }
 
 static void job_up_geometry(const DevSector& s, const TilePlan& plan, bool lz_xm, int wc, JobUp& jb, int& lds_bytes, int64_t& nwg) {

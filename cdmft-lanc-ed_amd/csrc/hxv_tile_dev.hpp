@@ -19,6 +19,7 @@ struct DevTiles {
   const uint32_t* rs_tab;
   int nblocks, nscoef;
   int debug;  // timing experiments only: 1 skip out-of-block hops, 2 skip in-block hops, 4 skip the hv read-modify-write (pass B)
+  int pair_rows;  // pass B: the two row groups that share 128-byte lines run back to back, block by block (large sectors)
 };
 
 constexpr int HOP_CHUNK = 8;
