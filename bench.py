@@ -194,7 +194,7 @@ def main():
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": traffic, "traffic_source": traffic_src, "kernel": "hxv_up_job + hxv_pass_dw (one product)", "kernel_ms": round(k_ms, 4),
+                "traffic": traffic, "traffic_source": traffic_src, "kernel": ("hxv_up_job" if sec.get_option("job_up_active") else "hxv_pass_up") + " + hxv_pass_dw (one product)", "kernel_ms": round(k_ms, 4),
                 "algorithmic_bytes": 32 * sec.vecDim}
 
     ns = {"C2": 12, "C3": 16, "C4": 16, "C5": 18}[args.workload]

@@ -49,7 +49,8 @@ struct SpinTiles {
 
 struct TileOptions {
   int cols_per_tile = 4;      // pass A (up hops): columns per workgroup tile
-  int rows_per_tile = 4;      // pass B (dw hops): rows per workgroup tile
+  int rows_per_tile = 0;      // pass B (dw hops): rows per workgroup tile; 0 = by sector size (4; 8 = whole 128-byte lines when the
+                              // panels of two neighbouring row groups no longer fit an XCD's L2), resolved when the plan is made
   int lds_budget_kb_up = 64;  // LDS per workgroup tile, pass A
   int lds_budget_kb_dw = 64;  // LDS per workgroup tile, pass B (two 1024-thread workgroups per CU)
   int force_bits_up = -1, force_bits_dw = -1;
