@@ -401,7 +401,10 @@ hipError_t allow_lds(const void* kern, int bytes) {
   return e;
 }
 
-constexpr int JOB_KIN = 24, JOB_KO = 16;
+// register-resident tables of a job: up to 24 in-block words and 8 out-of-block slots per row.  Blocks with more slots (BHZ: up
+// to 16) would need a second batch of gathers whose latency nothing covers: measured 5 % slower than one tile per
+// workgroup at C4, so such plans do not run as jobs.
+constexpr int JOB_KIN = 24, JOB_KO = 8;
 
 template <int C, bool LZ, int KIN, int KO>
 hipError_t launch_up_job_k(const DevSector& s, const DevTiles& t, const JobUp& jb, int lds_bytes, int64_t nwg, const LzEpilogue& lz,
@@ -422,10 +425,8 @@ template <int C, bool LZ>
 hipError_t launch_up_job_c(const DevSector& s, const DevTiles& t, const JobUp& jb, int lds_bytes, int64_t nwg, const LzEpilogue& lz,
                            hipStream_t st) {
   // fewer table registers when the longest in-block list / the out-of-block slot count allow it
-  if (jb.max_outer <= 8) {
-    if (jb.kin_rows <= 20) return launch_up_job_k<C, LZ, 20, 8>(s, t, jb, lds_bytes, nwg, lz, st);
-    return launch_up_job_k<C, LZ, JOB_KIN, 8>(s, t, jb, lds_bytes, nwg, lz, st);
-  }
+  if (jb.max_outer > JOB_KO) return hipErrorInvalidValue;  // (job_up_usable)
+  if (jb.kin_rows <= 20) return launch_up_job_k<C, LZ, 20, JOB_KO>(s, t, jb, lds_bytes, nwg, lz, st);
   return launch_up_job_k<C, LZ, JOB_KIN, JOB_KO>(s, t, jb, lds_bytes, nwg, lz, st);
 }
 
