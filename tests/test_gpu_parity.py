@@ -405,6 +405,8 @@ def test_c5_ns18_full_size_single_gpu(built):
     import hxv
     from hxv import models
 
+    torch.cuda.empty_cache()
+    hxv.pool_trim()  # (buffers cached by earlier sectors of this process)
     free, _ = torch.cuda.mem_get_info()
     if free < 210e9:
         pytest.skip("needs ~200 GB of free HBM")
@@ -467,6 +469,8 @@ def test_c5_ns18_slab_matches_oracle_matrices(built):
     from hxv import models
     from oracle.oracle import OracleSector
 
+    torch.cuda.empty_cache()
+    hxv.pool_trim()
     free, _ = torch.cuda.mem_get_info()
     if free < 60e9:
         pytest.skip("needs ~50 GB of free HBM")
