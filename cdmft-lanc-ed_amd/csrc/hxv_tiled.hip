@@ -164,15 +164,18 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
     }
   }
   if (LZ) {
-    __syncthreads();
+    // wavefront partial sums first (shuffles), one LDS word per wave afterwards: two barriers instead of a tree of eleven
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) asum += __shfl_down(asum, off, 64);
+    __syncthreads();  // every gather from the tile is done
     double* red = reinterpret_cast<double*>(lds);
-    red[threadIdx.x] = asum;
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = asum;
     __syncthreads();
-    for (int st = T >> 1; st > 0; st >>= 1) {
-      if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
-      __syncthreads();
+    if (threadIdx.x == 0) {
+      double tot = 0.0;
+      for (int w = 0; w < (T >> 6); ++w) tot += red[w];
+      lz.partial[blockIdx.x] = tot;
     }
-    if (threadIdx.x == 0) lz.partial[blockIdx.x] = red[0];
   }
 }
 
