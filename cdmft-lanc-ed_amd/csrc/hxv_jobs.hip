@@ -89,8 +89,9 @@ __global__ void __launch_bounds__(1024) hxv_up_job(DevSector s, DevTiles t, JobU
   const int xcd = b & 7, j = b >> 3;
   const int chunk = j / t.nblocks;
   const int kb = (int)jb.order[j - chunk * t.nblocks];
-  const int g0 = xcd * jb.gpx + chunk * jb.gc;
-  const int g1 = min(min(g0 + jb.gc, (xcd + 1) * jb.gpx), jb.ngroups);
+  // (the XCD's groups are cut into `chunks` runs of equal length +-1: no short last job)
+  const int g0 = xcd * jb.gpx + (int)(((int64_t)chunk * jb.gpx) / jb.chunks);
+  const int g1 = min(xcd * jb.gpx + (int)(((int64_t)(chunk + 1) * jb.gpx) / jb.chunks), jb.ngroups);
   const int ntile = g1 - g0;
   if (chunk >= jb.chunks || ntile <= 0) {
     if (LZ && threadIdx.x == 0) lz.partial[blockIdx.x] = 0.0;
@@ -444,7 +445,7 @@ static void job_up_geometry(const DevSector& s, const TilePlan& plan, bool lz_xm
   jb.ngroups = (s.qdw + C - 1) / C;
   jb.gpx = (jb.ngroups + 7) / 8;
   jb.gc = std::max(1, plan.opt.job_groups);
-  jb.chunks = (jb.gpx + jb.gc - 1) / jb.gc;
+  jb.chunks = std::max(1, (jb.gpx + jb.gc / 2) / jb.gc);  // about job_groups groups per job, all jobs of an XCD equally long
   jb.ns = (plan.up.max_block + 63) & ~63;
   jb.stage_bytes = (1 + (lz_xm ? 1 : 0)) * C * jb.ns * 16;
   jb.wt_bytes = jb.ns * std::max(wc, 1) * 16;

@@ -64,7 +64,7 @@ struct TileOptions {
   // pipelined job kernels (hxv_jobs.hip)
   int job_up = 1;      // pass A as jobs (block x run of column groups) with an LDS-DMA tile ring; 0 = one tile per workgroup
   int job_cols = 1;    // columns per tile of a pass-A job (1 or 2)
-  int job_groups = 50; // column groups per job
+  int job_groups = 100; // column groups per job (about: an XCD's groups are cut into equal runs)
   int job_stages = 4;  // depth of the LDS tile ring (clamped to what fits 160 KB)
   int job_debug = 0;   // timing experiments only (JobUp::debug); results are wrong when non-zero
   int debug = 0;   // timing experiments only (see DevTiles::debug); results are wrong when non-zero

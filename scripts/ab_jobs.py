@@ -14,7 +14,7 @@ hv = torch.empty_like(v)
 ref = None
 torch.cuda.synchronize()
 sets = sys.argv[1:] or ["job_up=0", "job_up=1"]
-defaults = {"job_up": 1, "job_cols": 1, "job_groups": 50, "job_stages": 4, "job_debug": 0}
+defaults = {"job_up": 1, "job_cols": 1, "job_groups": 100, "job_stages": 4, "job_debug": 0}
 for s in sets:
     opts = dict(defaults)
     for kv in s.split(","):
