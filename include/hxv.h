@@ -117,7 +117,10 @@ int hxv_halo_lists(const hxv_handle *h, int32_t *recv_cols, int32_t *send_cols);
  * equal-count ncclAllGather / MPI_Allgather of the padded slabs produces; hxv_fullvec_elems()
  * elements in all.  d_hv_local: this rank's slab (hxv_localvec_elems() elements), overwritten.  Asynchronous on `stream` (a hipStream_t; NULL = the legacy
  * default stream, as in every HIP API), so it orders with the caller's other work on that
- * stream.  d_v_full and d_hv_local must not overlap.                                     */
+ * stream.  d_v_full and d_hv_local must not overlap.
+ * When H is real (hxv_real_vectors_available) one complex product is two independent real products, H(x + i y) =
+ * Hx + i Hy: a caller with several real vectors to multiply (the Green's-function channels of one solve) gets two
+ * per call at 4.4 ms (C3) instead of 2.9 ms each through hxv_apply_device_real.                                     */
 int hxv_apply_device(hxv_handle *h, const void *d_v_full, void *d_hv_local, void *stream);
 /* DEVICE VECTOR LAYOUT.  On the device every column of DimUp elements is padded to hxv_pitch(h) =
  * DimUp rounded up to a multiple of 8 elements, so each column starts on a 128-byte line; element
