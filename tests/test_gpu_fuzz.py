@@ -78,7 +78,8 @@ def test_random_models_sectors_shards_and_tile_options(built, seed):
         want = ref[sec.mpiIshift: sec.mpiIshift + sec.vecDim]
         opts = [{}, {"lds_budget_kb": int(rng.choice([8, 16, 32])), "cols_per_tile": int(rng.choice([2, 4, 8])), "rows_per_tile": int(rng.choice([2, 4, 8])),
                      "threads_up": int(rng.choice([256, 512, 1024])), "threads_dw": int(rng.choice([256, 512, 1024])), "sort_mode": int(rng.integers(3)),
-                     "wt_cols": int(rng.choice([2, 4, 8, 16])), "job_cols": int(rng.choice([1, 2]))},
+                     "wt_cols": int(rng.choice([2, 4, 8, 16])), "job_cols": int(rng.choice([1, 2])), "pair_rows": int(rng.choice([0, 1])),
+                     "job_groups": int(rng.choice([1, 3, 100])), "job_max_blocks": int(rng.choice([0, 32]))},
                 {"kernel": 0}]
         for o in opts:
             try:
