@@ -516,6 +516,8 @@ int64_t hxv_get_option(const hxv_handle* h, const char* name) {
   if (!strcmp(name, "max_block_up")) return h->plan.up.max_block;
   if (!strcmp(name, "max_block_dw")) return h->plan.dw.max_block;
   if (!strcmp(name, "nblocks_up")) return h->plan.up.nblocks;
+  if (!strcmp(name, "table_classes_up")) return h->plan.up.table_classes;
+  if (!strcmp(name, "table_classes_dw")) return h->plan.dw.table_classes;
   if (!strcmp(name, "nblocks_dw")) return h->plan.dw.nblocks;
   if (!strcmp(name, "job_up")) return h->plan.opt.job_up;
   if (!strcmp(name, "job_up_active"))

@@ -209,10 +209,11 @@ __global__ void __launch_bounds__(1024) hxv_up_job(DevSector s, DevTiles t, JobU
   uint32_t mu = 0;
   if (wave_on) {
     const int pr = min(p, n - 1);
+    const int tb0 = (int)t.tstart[kb];  // the block whose in-block tables this one shares
     const uint32_t EMPTY = (uint32_t)(t.nscoef - 1) << TILE_COEF_SHIFT;
 #pragma unroll
     for (int k = 0; k < KIN; ++k) {
-      const uint32_t e = (row_ok && k < jb.kin_rows) ? t.ell_in[(int64_t)k * s.dimup + r0 + pr] : EMPTY;
+      const uint32_t e = (row_ok && k < jb.kin_rows) ? t.ell_in[(int64_t)k * s.dimup + tb0 + pr] : EMPTY;
       tin[k] = ((e >> TILE_COEF_SHIFT) << (16 + LCB)) | ((e & OFFM) << 4);
     }
     const int rs0 = (int)t.rs_ptr[kb], nrs = (int)t.rs_ptr[kb + 1] - rs0;

@@ -7,6 +7,7 @@ namespace hxv {
 
 struct DevTiles {
   const uint32_t* start;   // [nblocks+1]
+  const uint32_t* tstart;  // [nblocks] start of the block whose in-block tables (perm, ell_in; gstart is aliased likewise) this block shares
   const uint32_t* perm;    // [dim]   sorted position -> index
   const uint32_t* gstart;  // [nblocks+1] first 64-position group of each block
   const uint32_t* gmax;    // [groups] longest in-block list of each 64-position group (low 16 bits)

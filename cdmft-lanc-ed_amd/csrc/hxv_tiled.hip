@@ -42,6 +42,7 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
   const int T = blockDim.x;
   const int r0 = (int)t.start[kb];
   const int n = (int)t.start[kb + 1] - r0;
+  const int tb0 = (int)t.tstart[kb];  // the block whose in-block tables this one shares
   const int c0 = g * C;  // local column
   const int nc = min(C, s.qdw - c0);
   CT* lcoef = reinterpret_cast<CT*>(lds + C * n);
@@ -128,7 +129,7 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
     for (int k0 = 0; k0 < ((t.debug & 2) ? 0 : kin); k0 += HOP_CHUNK) {
       uint32_t e[HOP_CHUNK];
 #pragma unroll
-      for (int u = 0; u < HOP_CHUNK; ++u) e[u] = t.ell_in[(int64_t)(k0 + u) * s.dimup + r0 + p];
+      for (int u = 0; u < HOP_CHUNK; ++u) e[u] = t.ell_in[(int64_t)(k0 + u) * s.dimup + tb0 + p];
 #pragma unroll
       for (int u = 0; u < HOP_CHUNK; ++u) {
         if (k0 + u < kin) {  // wave-uniform: all 8 words are loaded at once, only the live slots are computed
@@ -286,8 +287,9 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_dw(DevSector s, DevTiles t, 
     if (tid < n) {
       const uint32_t packed = __builtin_amdgcn_readfirstlane(t.gmax[t.gstart[kb] + (tid >> 6)]);
       const int kin = (t.debug & 2) ? 0 : (int)(packed & 0xFFFFu);
-      col1 = (int)t.perm[cb0 + tid] - cb0;
-      const uint32_t* __restrict__ ellp = t.ell_in + cb0 + tid;
+      const int tb0 = (int)t.tstart[kb];  // the block whose in-block tables this one shares
+      col1 = (int)t.perm[tb0 + tid] - tb0;
+      const uint32_t* __restrict__ ellp = t.ell_in + tb0 + tid;
 #pragma unroll
       for (int rr = 0; rr < R; ++rr) acc[rr] = vzero<VT>();
       for (int k0 = 0; k0 < kin; k0 += HOP_CHUNK) {
@@ -440,7 +442,7 @@ int choose_lowbits(int ns, int npart, int width, int budget_bytes, int max_block
 }
 
 struct HostTiles {
-  std::vector<uint32_t> start, perm, gstart, gmax, ell_in;
+  std::vector<uint32_t> start, perm, gstart, gmax, ell_in, tstart;
   std::vector<uint32_t> bh_ptr, bh, rs_ptr, rs_off, rs_tab, order;
 };
 
@@ -532,6 +534,33 @@ void build_spin_tiles(const SpinOp& op, const std::vector<uint32_t>& map, int lo
       else
         ++b;  // out-of-block entry: handled by the structured part below
     }
+  }
+  // Blocks whose high orbitals hold the same NUMBER of particles contain the same low-orbital patterns, and hops among the
+  // low orbitals see nothing else: their in-block tables (words, visiting order, loop bounds) are identical.  Every block
+  // reads the tables of the first block that equals it (compared, not assumed), so the hot table set shrinks from one
+  // slice per block to one per class (C3: 5 instead of 16) and stays in L2 between the workgroups that use it.
+  h.tstart.assign(t.nblocks, 0);
+  t.table_classes = 0;
+  for (int k = 0; k < t.nblocks; ++k) {
+    h.tstart[k] = h.start[k];
+    const uint32_t nk = h.start[k + 1] - h.start[k];
+    bool found = false;
+    for (int c = 0; c < k && !found; ++c) {
+      if (h.tstart[c] != h.start[c] || h.start[c + 1] - h.start[c] != nk) continue;  // (only first-of-class blocks are candidates)
+      bool same = true;
+      for (uint32_t q = 0; q < nk && same; ++q) same = h.perm[h.start[k] + q] - h.start[k] == h.perm[h.start[c] + q] - h.start[c];
+      const uint32_t ng = (nk + 63) / 64;
+      for (uint32_t q = 0; q < ng && same; ++q) same = (h.gmax[h.gstart[k] + q] & 0xFFFFu) == (h.gmax[h.gstart[c] + q] & 0xFFFFu);  // (the kernels read the in-block bound only)
+      for (int a = 0; a < t.k_in && same; ++a)
+        same = std::equal(h.ell_in.begin() + (size_t)a * dim + h.start[k], h.ell_in.begin() + (size_t)a * dim + h.start[k] + nk,
+                          h.ell_in.begin() + (size_t)a * dim + h.start[c]);
+      if (same) {
+        h.tstart[k] = h.start[c];
+        h.gstart[k] = h.gstart[c];
+        found = true;
+      }
+    }
+    if (!found) ++t.table_classes;
   }
   // ---- structured out-of-block part: group by (block, source block)
   h.bh_ptr.assign(t.nblocks + 1, 0);
@@ -730,7 +759,7 @@ std::string make_tile_plan(const SectorHost& s, TilePlan& plan, const PlanUpload
     if (t.max_block > max_block) return "block larger than the workgroup (one thread per block row/column)";
     if (up.u32(h.start, &t.d_start) != hipSuccess || up.u32(h.perm, &t.d_perm) != hipSuccess ||
         up.u32(h.gstart, &t.d_gstart) != hipSuccess || up.u32(h.gmax, &t.d_gmax) != hipSuccess ||
-        up.u32(h.ell_in, &t.d_ell_in) != hipSuccess ||
+        up.u32(h.ell_in, &t.d_ell_in) != hipSuccess || up.u32(h.tstart, &t.d_tstart) != hipSuccess ||
         up.u32(h.bh_ptr, &t.d_bh_ptr) != hipSuccess || up.u32(h.bh, &t.d_bh) != hipSuccess ||
         up.u32(h.rs_ptr, &t.d_rs_ptr) != hipSuccess || up.u32(h.rs_off, &t.d_rs_off) != hipSuccess ||
         up.u32(h.rs_tab, &t.d_rs_tab) != hipSuccess || up.u32(h.order, &t.d_order) != hipSuccess)
@@ -785,10 +814,10 @@ template <typename VT>
 static hipError_t launch_tiled_vt(const DevSector& s, const TilePlan& plan, const VT* v, VT* wt, VT* hv, hipStream_t st, const LzEpilogue* lz,
                                   int only_pass, bool wt_natural) {
   constexpr bool RV = std::is_same<VT, double>::value;
-  DevTiles tu{plan.up.d_start, plan.up.d_perm, plan.up.d_gstart, plan.up.d_gmax, plan.up.d_ell_in,
+  DevTiles tu{plan.up.d_start, plan.up.d_tstart, plan.up.d_perm, plan.up.d_gstart, plan.up.d_gmax, plan.up.d_ell_in,
               plan.d_scoef_up, plan.up.d_bh_ptr, plan.up.d_bh, plan.up.d_rs_ptr, plan.up.d_rs_off, plan.up.d_rs_tab,
               plan.up.nblocks, 2 * plan.ncoef_up + 1, plan.opt.debug, 0};
-  DevTiles td{plan.dw.d_start, plan.dw.d_perm, plan.dw.d_gstart, plan.dw.d_gmax, plan.dw.d_ell_in,
+  DevTiles td{plan.dw.d_start, plan.dw.d_tstart, plan.dw.d_perm, plan.dw.d_gstart, plan.dw.d_gmax, plan.dw.d_ell_in,
               plan.d_scoef_dw, plan.dw.d_bh_ptr, plan.dw.d_bh, plan.dw.d_rs_ptr, plan.dw.d_rs_off, plan.dw.d_rs_tab,
               plan.dw.nblocks, 2 * plan.ncoef_dw + 1, plan.opt.debug, 0};
   // (decided below, once the tile's row count R is known)

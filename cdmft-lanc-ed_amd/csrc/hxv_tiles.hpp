@@ -29,6 +29,8 @@ struct SpinTiles {
   double slots_in = 0, slots_out = 0;  // processed slots per row after sorting (statistics)
   std::vector<uint32_t> start;       // [nblocks+1]
   uint32_t* d_start = nullptr;
+  uint32_t* d_tstart = nullptr;      // [nblocks] start of the first block with identical in-block tables (they are read from there)
+  int table_classes = 0;             // distinct in-block tables among the blocks
   uint32_t* d_perm = nullptr;        // [dim] sorted position -> index
   uint32_t* d_gstart = nullptr;      // [nblocks+1] first 64-lane group of each block
   uint32_t* d_gmax = nullptr;        // [ngroups] k_in max | k_out max << 16 of each 64-position group
