@@ -465,7 +465,7 @@ int hxv_set_option(hxv_handle* h, const char* name, int64_t value) {
   else if (!strcmp(name, "sort_mode")) o.sort_mode = (int)value;
   else if (!strcmp(name, "wt_cols")) o.wt_cols = (int)value;
   else if (!strcmp(name, "sort_mode_dw")) o.sort_mode_dw = (int)value;
-  else if (!strcmp(name, "job_up")) o.job_up = value ? 1 : 0;
+  else if (!strcmp(name, "job_up")) o.job_up = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
   else if (!strcmp(name, "job_cols")) o.job_cols = (int)value;
   else if (!strcmp(name, "job_groups")) o.job_groups = (int)value;
   else if (!strcmp(name, "job_stages")) o.job_stages = (int)value;
@@ -521,7 +521,7 @@ int64_t hxv_get_option(const hxv_handle* h, const char* name) {
   if (!strcmp(name, "nblocks_dw")) return h->plan.dw.nblocks;
   if (!strcmp(name, "job_up")) return h->plan.opt.job_up;
   if (!strcmp(name, "job_up_active"))
-    return (h->plan.opt.job_up && h->plan.opt.sort_mode == 0 && job_up_usable(h->dev, h->plan) &&
+    return (h->plan.opt.job_up == 1 && h->plan.opt.sort_mode == 0 && job_up_usable(h->dev, h->plan) &&
             job_up_fits(h->dev, h->plan, false, std::max(h->plan.opt.job_cols, h->plan.opt.wt_cols)))
                ? 1
                : 0;

@@ -21,6 +21,7 @@ struct DevTiles {
   int nblocks, nscoef;
   int debug;  // timing experiments only: 1 skip out-of-block hops, 2 skip in-block hops, 4 skip the hv read-modify-write (pass B)
   int pair_rows;  // pass B: the two row groups that share 128-byte lines run back to back, block by block (large sectors)
+  const uint32_t* order;  // [nblocks] blocks by decreasing size (= grouped by table class), or null: pass B visits a row group's blocks in this order
 };
 
 constexpr int HOP_CHUNK = 8;

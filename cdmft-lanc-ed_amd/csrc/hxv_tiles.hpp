@@ -64,7 +64,8 @@ struct TileOptions {
   int job_max_blocks = 32;  // pass A runs as jobs only up to this many blocks per spin (beyond, one chunk's jobs no longer fit an XCD's CUs)
   int wt_cols = 4;  // columns per group of the blocked dw-hop scratch (>= cols_per_tile): R*wt_cols*16-byte write runs in pass B
   // pipelined job kernels (hxv_jobs.hip)
-  int job_up = 1;      // pass A as jobs (block x run of column groups) with an LDS-DMA tile ring; 0 = one tile per workgroup
+  int job_up = 2;      // pass A as jobs (block x run of column groups) with an LDS-DMA tile ring: 2 = for the fused Lanczos product only
+                       // [default], 1 = always, 0 = never (one tile per workgroup)
   int job_cols = 1;    // columns per tile of a pass-A job (1 or 2)
   int job_groups = 100; // column groups per job (about: an XCD's groups are cut into equal runs)
   int job_stages = 4;  // depth of the LDS tile ring (clamped to what fits 160 KB)
