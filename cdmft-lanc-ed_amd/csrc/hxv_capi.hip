@@ -518,6 +518,8 @@ int64_t hxv_get_option(const hxv_handle* h, const char* name) {
   if (!strcmp(name, "nblocks_up")) return h->plan.up.nblocks;
   if (!strcmp(name, "table_classes_up")) return h->plan.up.table_classes;
   if (!strcmp(name, "table_classes_dw")) return h->plan.dw.table_classes;
+  if (!strcmp(name, "rs_tables_up")) return h->plan.up.rs_tables;
+  if (!strcmp(name, "rs_tables_dw")) return h->plan.dw.rs_tables;
   if (!strcmp(name, "nblocks_dw")) return h->plan.dw.nblocks;
   if (!strcmp(name, "job_up")) return h->plan.opt.job_up;
   if (!strcmp(name, "job_up_active"))

@@ -224,6 +224,7 @@ __global__ void __launch_bounds__(1024) hxv_up_job(DevSector s, DevTiles t, JobU
       uint32_t e = EMPTY;
       if (i < nrs) {
         e = t.rs_tab[t.rs_off[rs0 + i] + pr];
+        if (e != EMPTY) e = ((e ^ (t.rs_neg[rs0 + i] << TILE_COEF_SHIFT)) & ~OFFM) | ((e & OFFM) + t.rs_base[rs0 + i]);  // shared table: sign, base
       } else if (i < nrs + nbh) {
         const int h = bh0 + i - nrs;
         e = (t.bh[2 * h + 1] << TILE_COEF_SHIFT) | (t.bh[2 * h] + (uint32_t)pr);
@@ -438,7 +439,7 @@ bool job_up_usable(const DevSector& s, const TilePlan& plan) {
   const SpinTiles& u = plan.up;
   return plan.usable && s.diag.mode == 0 && u.max_block <= 64 * JOB_LOADER && u.k_in <= JOB_KIN && u.max_outer <= JOB_KO &&
          u.d_order != nullptr && s.dimup < 65536 &&  // (packed out-of-block words: hxv_up_job)
-         u.nblocks <= plan.opt.job_max_blocks;
+         u.nblocks <= plan.opt.job_max_blocks && plan.opt.job_cols == 1;
 }
 
 static void job_up_geometry(const DevSector& s, const TilePlan& plan, bool lz_xm, int wc, JobUp& jb, int& lds_bytes, int64_t& nwg) {
@@ -490,9 +491,9 @@ hipError_t launch_up_job(const DevSector& s, const TilePlan& plan, const DevTile
   jb.wt = wt;
   jb.hv = hv;
   jb.wc = wc;
-  if (plan.opt.job_cols == 1)
-    return lz ? launch_up_job_c<1, true>(s, tu, jb, lds_bytes, nwg, *lz, st) : launch_up_job_c<1, false>(s, tu, jb, lds_bytes, nwg, LzEpilogue(), st);
-  return lz ? launch_up_job_c<2, true>(s, tu, jb, lds_bytes, nwg, *lz, st) : launch_up_job_c<2, false>(s, tu, jb, lds_bytes, nwg, LzEpilogue(), st);
+  // (two columns per tile were measured slower, and every such kernel spills vector and scalar registers: not built any more)
+  if (plan.opt.job_cols != 1) return hipErrorInvalidValue;
+  return lz ? launch_up_job_c<1, true>(s, tu, jb, lds_bytes, nwg, *lz, st) : launch_up_job_c<1, false>(s, tu, jb, lds_bytes, nwg, LzEpilogue(), st);
 }
 
 }  // namespace hxv

@@ -18,6 +18,8 @@ struct DevTiles {
   const uint32_t* rs_ptr;
   const uint32_t* rs_off;
   const uint32_t* rs_tab;
+  const uint32_t* rs_base; // [nslots] first gather slot of the slot's source block (table words are relative to it; 0: absolute words)
+  const uint32_t* rs_neg;  // [nslots] 1: the (shared) table holds this slot's coefficients with the opposite sign
   int nblocks, nscoef;
   int debug;  // timing experiments only: 1 skip out-of-block hops, 2 skip in-block hops, 4 skip the hv read-modify-write (pass B)
   int pair_rows;  // pass B: the two row groups that share 128-byte lines run back to back, block by block (large sectors)
@@ -97,12 +99,14 @@ struct Coef<true> {
   }
   static __device__ __forceinline__ void fma(double& acc, double c, double x) { acc = ::fma(c, x, acc); }
   static __device__ __forceinline__ double from(double2 c) { return c.x; }
+  static __device__ __forceinline__ double neg(double c) { return -c; }
 };
 template <>
 struct Coef<false> {
   using type = double2;
   static __device__ __forceinline__ void fma(double2& acc, double2 c, double2 x) { cfma(acc, c, x); }
   static __device__ __forceinline__ double2 from(double2 c) { return c; }
+  static __device__ __forceinline__ double2 neg(double2 c) { return make_double2(-c.x, -c.y); }
 };
 
 template <bool NORB1>

@@ -120,8 +120,9 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
       for (uint32_t sl = t.rs_ptr[kb]; sl < t.rs_ptr[kb + 1]; ++sl) {
         const uint32_t e = t.rs_tab[t.rs_off[sl] + r];
         if (__all(e == emptyz)) continue;
-        const CT cf = lcoef[e >> TILE_COEF_SHIFT];
-        const VT* __restrict__ src = vcol0 + (e & TILE_OFF_MASK);
+        CT cf = lcoef[e >> TILE_COEF_SHIFT];
+        if (t.rs_neg[sl]) cf = Coef<REAL>::neg(cf);  // (uniform: the shared table holds the other overall sign)
+        const VT* __restrict__ src = vcol0 + t.rs_base[sl] + (e & TILE_OFF_MASK);
 #pragma unroll
         for (int cc = 0; cc < C; ++cc) Coef<REAL>::fma(acc[cc], cf, src[(int64_t)min(cc, nc - 1) * s.pitch]);
       }
@@ -360,11 +361,17 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_dw(DevSector s, DevTiles t, 
             for (int it = 0; it < HB; ++it) none = none && (e[jj][it] == emptyz);
             if (__all(none)) continue;
             VT x[HB];
+            const char* __restrict__ vslot = vrow64 + (uint64_t)t.rs_base[sl0 + jj] * pitchb;  // (the slot's source block)
+            const bool neg = t.rs_neg[sl0 + jj] != 0;  // (uniform: the shared table holds the other overall sign)
 #pragma unroll
             for (int it = 0; it < HB; ++it)
-              x[it] = *reinterpret_cast<const VT*>(vrow64 + (uint64_t)(e[jj][it] & TILE_OFF_MASK) * pitchb);
+              x[it] = *reinterpret_cast<const VT*>(vslot + (uint64_t)(e[jj][it] & TILE_OFF_MASK) * pitchb);
 #pragma unroll
-            for (int it = 0; it < HB; ++it) Coef<REAL>::fma(osum[it], lds_ld<CT>((e[jj][it] >> TILE_COEF_SHIFT) << LCB), x[it]);
+            for (int it = 0; it < HB; ++it) {
+              CT cf = lds_ld<CT>((e[jj][it] >> TILE_COEF_SHIFT) << LCB);
+              if (neg) cf = Coef<REAL>::neg(cf);
+              Coef<REAL>::fma(osum[it], cf, x[it]);
+            }
           }
         }
       }
@@ -445,7 +452,7 @@ int choose_lowbits(int ns, int npart, int width, int budget_bytes, int max_block
 
 struct HostTiles {
   std::vector<uint32_t> start, perm, gstart, gmax, ell_in, tstart;
-  std::vector<uint32_t> bh_ptr, bh, rs_ptr, rs_off, rs_tab, order;
+  std::vector<uint32_t> bh_ptr, bh, rs_ptr, rs_off, rs_tab, rs_base, rs_neg, order;
 };
 
 // sorted_out: outer table indexed by sorted position (pass A) or by natural index (pass B)
@@ -570,6 +577,8 @@ void build_spin_tiles(const SpinOp& op, const std::vector<uint32_t>& map, int lo
   h.bh.clear();
   h.rs_off.clear();
   h.rs_tab.clear();
+  h.rs_base.clear();
+  h.rs_neg.clear();
   double bh_rows = 0, rs_rows = 0;
   struct Ent {
     uint32_t off, src, ci;
@@ -619,14 +628,25 @@ void build_spin_tiles(const SpinOp& op, const std::vector<uint32_t>& map, int lo
         std::vector<int> mult(nb, 0);
         int nsl = 0;
         for (const Ent& en : ents) nsl = std::max(nsl, ++mult[en.off]);
+        // Table words hold the source RELATIVE to its block when the block's slots are contiguous in the gather layout
+        // (always on an unsplit sector); the slot's base is a per-slot constant.  Relative tables repeat between blocks of
+        // the same class up to one overall sign, and are shared below.
+        bool contig = true;
+        if (vcol)
+          for (uint32_t q = 0; q < ns && contig; ++q) contig = (*vcol)[s0 + q] == (*vcol)[s0] + q;
         const size_t base = h.rs_tab.size();
         h.rs_tab.resize(base + (size_t)nsl * nb, emptyz);
         std::fill(mult.begin(), mult.end(), 0);
         for (const Ent& en : ents) {
           const int sl = mult[en.off]++;
-          h.rs_tab[base + (size_t)sl * nb + en.off] = (en.ci << TILE_COEF_SHIFT) | (vcol ? (*vcol)[en.src] : en.src);
+          const uint32_t where = contig ? en.src - s0 : (vcol ? (*vcol)[en.src] : en.src);
+          h.rs_tab[base + (size_t)sl * nb + en.off] = (en.ci << TILE_COEF_SHIFT) | where;
         }
-        for (int sl = 0; sl < nsl; ++sl) h.rs_off.push_back((uint32_t)(base + (size_t)sl * nb));
+        for (int sl = 0; sl < nsl; ++sl) {
+          h.rs_off.push_back((uint32_t)(base + (size_t)sl * nb));
+          h.rs_base.push_back(contig ? (vcol ? (*vcol)[s0] : s0) : 0u);
+          h.rs_neg.push_back(0u);
+        }
         rs_rows += (double)nsl * nb;
       }
       ents.clear();
@@ -634,8 +654,42 @@ void build_spin_tiles(const SpinOp& op, const std::vector<uint32_t>& map, int lo
   }
   h.bh_ptr[t.nblocks] = (uint32_t)(h.bh.size() / 2);
   h.rs_ptr[t.nblocks] = (uint32_t)h.rs_off.size();
+  // share row-slot tables that are equal up to an overall sign (a coefficient index is 2*amplitude + sign): a slot reads
+  // the first table that equals its own after normalising the sign of its first entry, and negates if it had to flip
+  {
+    std::map<std::vector<uint32_t>, uint32_t> seen;  // normalised table -> offset of its first copy
+    t.rs_tables = 0;
+    for (int k = 0; k < t.nblocks; ++k) {
+      const uint32_t nb = h.start[k + 1] - h.start[k];
+      for (uint32_t sl = h.rs_ptr[k]; sl < h.rs_ptr[k + 1]; ++sl) {
+        std::vector<uint32_t> tab(h.rs_tab.begin() + h.rs_off[sl], h.rs_tab.begin() + h.rs_off[sl] + nb);
+        uint32_t flip = 0;
+        for (uint32_t w : tab)
+          if (w != emptyz) {
+            flip = (w >> TILE_COEF_SHIFT) & 1u;
+            break;
+          }
+        if (flip)
+          for (uint32_t& w : tab)
+            if (w != emptyz) w ^= 1u << TILE_COEF_SHIFT;
+        auto it = seen.find(tab);
+        if (it == seen.end()) {
+          std::copy(tab.begin(), tab.end(), h.rs_tab.begin() + h.rs_off[sl]);  // stored normalised
+          seen.emplace(std::move(tab), h.rs_off[sl]);
+          ++t.rs_tables;
+        } else {
+          h.rs_off[sl] = it->second;
+        }
+        h.rs_neg[sl] = flip;
+      }
+    }
+  }
   if (h.bh.empty()) h.bh.assign(2, 0);
-  if (h.rs_off.empty()) h.rs_off.assign(1, 0);
+  if (h.rs_off.empty()) {
+    h.rs_off.assign(1, 0);
+    h.rs_base.assign(1, 0);
+    h.rs_neg.assign(1, 0);
+  }
   if (h.rs_tab.empty()) h.rs_tab.assign(1, emptyz);
   t.bh_per_row = bh_rows / dim;
   t.rs_per_row = rs_rows / dim;
@@ -764,7 +818,8 @@ std::string make_tile_plan(const SectorHost& s, TilePlan& plan, const PlanUpload
         up.u32(h.ell_in, &t.d_ell_in) != hipSuccess || up.u32(h.tstart, &t.d_tstart) != hipSuccess ||
         up.u32(h.bh_ptr, &t.d_bh_ptr) != hipSuccess || up.u32(h.bh, &t.d_bh) != hipSuccess ||
         up.u32(h.rs_ptr, &t.d_rs_ptr) != hipSuccess || up.u32(h.rs_off, &t.d_rs_off) != hipSuccess ||
-        up.u32(h.rs_tab, &t.d_rs_tab) != hipSuccess || up.u32(h.order, &t.d_order) != hipSuccess)
+        up.u32(h.rs_tab, &t.d_rs_tab) != hipSuccess || up.u32(h.order, &t.d_order) != hipSuccess ||
+        up.u32(h.rs_base, &t.d_rs_base) != hipSuccess || up.u32(h.rs_neg, &t.d_rs_neg) != hipSuccess)
       return "upload of tile tables failed";
     return "";
   };
@@ -788,6 +843,11 @@ int64_t tiled_wt_elems(const DevSector& s, const TilePlan& plan) {
 
 // Real-vector mode runs the same plans with twice the columns (pass A) / rows (pass B) per tile: the same tile bytes.
 static int real_cols(const TilePlan& plan) { return std::min(8, 2 * plan.opt.cols_per_tile); }
+// Complex vectors: at most four columns per pass-A tile.  The eight-column kernels need far more than the 64 registers two
+// workgroups per CU leave (they spill 30 - 140 of them, scalar registers as well), were 35 % slower when they were measured, and
+// one of them (complex H, Lanczos epilogue) came out of hipcc computing wrong sums after an unrelated two-pointer growth of
+// the kernel arguments: "cols_per_tile" = 8 keeps its meaning for the plan (block size) and for real vectors only.
+static int cplx_cols(const TilePlan& plan) { return std::min(4, plan.opt.cols_per_tile); }
 static int real_rows(const TilePlan& plan) { return std::min(8, 2 * plan.opt.rows_per_tile); }
 static int real_wc(const TilePlan& plan) { return std::max(real_cols(plan), std::min(16, 2 * plan.opt.wt_cols)); }
 
@@ -811,7 +871,7 @@ static bool use_job_up(const DevSector& s, const TilePlan& plan, bool real_vec, 
 
 int64_t tiled_pass_up_workgroups(const DevSector& s, const TilePlan& plan, bool real_vec) {
   if (use_job_up(s, plan, real_vec, true, false)) return job_up_workgroups(s, plan);
-  const int C = real_vec ? real_cols(plan) : plan.opt.cols_per_tile;
+  const int C = real_vec ? real_cols(plan) : cplx_cols(plan);
   const int ngroups = (s.qdw + C - 1) / C;
   return (int64_t)((ngroups + 7) / 8) * 8 * plan.up.nblocks;
 }
@@ -821,14 +881,14 @@ static hipError_t launch_tiled_vt(const DevSector& s, const TilePlan& plan, cons
                                   int only_pass, bool wt_natural) {
   constexpr bool RV = std::is_same<VT, double>::value;
   DevTiles tu{plan.up.d_start, plan.up.d_tstart, plan.up.d_perm, plan.up.d_gstart, plan.up.d_gmax, plan.up.d_ell_in,
-              plan.d_scoef_up, plan.up.d_bh_ptr, plan.up.d_bh, plan.up.d_rs_ptr, plan.up.d_rs_off, plan.up.d_rs_tab,
+              plan.d_scoef_up, plan.up.d_bh_ptr, plan.up.d_bh, plan.up.d_rs_ptr, plan.up.d_rs_off, plan.up.d_rs_tab, plan.up.d_rs_base, plan.up.d_rs_neg,
               plan.up.nblocks, 2 * plan.ncoef_up + 1, plan.opt.debug, 0, (2 * plan.up.table_classes <= plan.up.nblocks && !(plan.opt.debug & 32)) ? plan.up.d_order : nullptr};
   DevTiles td{plan.dw.d_start, plan.dw.d_tstart, plan.dw.d_perm, plan.dw.d_gstart, plan.dw.d_gmax, plan.dw.d_ell_in,
-              plan.d_scoef_dw, plan.dw.d_bh_ptr, plan.dw.d_bh, plan.dw.d_rs_ptr, plan.dw.d_rs_off, plan.dw.d_rs_tab,
+              plan.d_scoef_dw, plan.dw.d_bh_ptr, plan.dw.d_bh, plan.dw.d_rs_ptr, plan.dw.d_rs_off, plan.dw.d_rs_tab, plan.dw.d_rs_base, plan.dw.d_rs_neg,
               plan.dw.nblocks, 2 * plan.ncoef_dw + 1, plan.opt.debug, 0, (2 * plan.dw.table_classes <= plan.dw.nblocks && !(plan.opt.debug & 32)) ? plan.dw.d_order : nullptr};
   // (class order only where classes are few: with 11 table sets for 16 blocks (C4) the natural order measured 2.6 % faster)
   // (decided below, once the tile's row count R is known)
-  const int C = RV ? real_cols(plan) : plan.opt.cols_per_tile, R = RV ? real_rows(plan) : plan.opt.rows_per_tile;
+  const int C = RV ? real_cols(plan) : cplx_cols(plan), R = RV ? real_rows(plan) : plan.opt.rows_per_tile;
   // columns per group of the wt scratch; 0 = natural layout
   const int passes = only_pass ? only_pass : plan.opt.passes;
   {
@@ -858,7 +918,12 @@ static hipError_t launch_tiled_vt(const DevSector& s, const TilePlan& plan, cons
   if (passes & 1) switch (C) {
       case 2: e = launch_up<2, VT>(s, tu, lds_a, ta, norb1, wc, v, wta, hv, lz, st); break;
       case 4: e = launch_up<4, VT>(s, tu, lds_a, ta, norb1, wc, v, wta, hv, lz, st); break;
-      default: e = launch_up<8, VT>(s, tu, lds_a, ta, norb1, wc, v, wta, hv, lz, st); break;
+      default:
+        if constexpr (RV)
+          e = launch_up<8, VT>(s, tu, lds_a, ta, norb1, wc, v, wta, hv, lz, st);
+        else
+          e = hipErrorInvalidValue;  // (cplx_cols)
+        break;
     }
   return e;
 }

@@ -43,7 +43,10 @@ struct SpinTiles {
   uint32_t* d_bh = nullptr;          // [2*nbh] (source start, signed-coefficient index)
   uint32_t* d_rs_ptr = nullptr;      // [nblocks+1] -> d_rs_off
   uint32_t* d_rs_off = nullptr;      // [nslots] offset of each slot's table in d_rs_tab
-  uint32_t* d_rs_tab = nullptr;      // flat tables, |block| words per slot
+  uint32_t* d_rs_tab = nullptr;      // flat tables, |block| words per slot (source relative to the slot's base)
+  uint32_t* d_rs_base = nullptr;     // [nslots] first gather slot of the source block (0: the words are absolute)
+  uint32_t* d_rs_neg = nullptr;      // [nslots] 1: the shared table holds the opposite overall sign
+  int rs_tables = 0;                 // distinct row-slot tables after sharing
   double bh_per_row = 0, rs_per_row = 0;  // statistics: block hops / row slots visited per row
   int max_outer = 0;                 // most (row slots + block hops) of any block (register tables of the job kernels)
   uint32_t* d_order = nullptr;       // [nblocks] block indices, largest block first (job order inside a chunk)
@@ -66,7 +69,7 @@ struct TileOptions {
   // pipelined job kernels (hxv_jobs.hip)
   int job_up = 2;      // pass A as jobs (block x run of column groups) with an LDS-DMA tile ring: 2 = for the fused Lanczos product only
                        // [default], 1 = always, 0 = never (one tile per workgroup)
-  int job_cols = 1;    // columns per tile of a pass-A job (1 or 2)
+  int job_cols = 1;    // columns per tile of a pass-A job: 1 (with 2 pass A does not run as jobs: those kernels were slower and spilled)
   int job_groups = 100; // column groups per job (about: an XCD's groups are cut into equal runs)
   int job_stages = 4;  // depth of the LDS tile ring (clamped to what fits 160 KB)
   int job_debug = 0;   // timing experiments only (JobUp::debug); results are wrong when non-zero

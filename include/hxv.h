@@ -257,7 +257,7 @@ int hxv_get_diag(const hxv_handle *h, double *diag);
  *   "eigh_measure_all" 0 [default] = partial re-orthogonalisation (loss of orthogonality estimated by the omega recurrence, whole-basis
  *                     Gram-Schmidt only when needed); 1 = every projection measured at every step (round-1 behaviour)
  * Pass A as pipelined jobs (LDS-DMA tile ring, one workgroup per CU): "job_up" 2 [default: for the fused Lanczos product only] | 1 (always) | 0 (one tile per
- *   workgroup), "job_groups" columns per job [about 100: equal runs per XCD], "job_cols" 1|2 columns per tile [1], "job_stages" ring depth 2..8 [4, clamped
+ *   workgroup), "job_groups" columns per job [about 100: equal runs per XCD], "job_cols" 1 (2: no jobs; the two-column kernels were slower and are not built), "job_stages" ring depth 2..8 [4, clamped
  *   to what fits the LDS].  The engine falls back to the one-tile kernels by itself where jobs do not apply (real vectors,
  *   stored diagonal, more than 24 in-block / 16 out-of-block entries per row, blocks over 960 rows).
  * Tile shape (changing one rebuilds the plan; invalid combinations are refused with a message):
