@@ -261,7 +261,7 @@ int hxv_get_diag(const hxv_handle *h, double *diag);
  *   to what fits the LDS].  The engine falls back to the one-tile kernels by itself where jobs do not apply (real vectors,
  *   stored diagonal, more than 24 in-block / 16 out-of-block entries per row, blocks over 960 rows).
  * Tile shape (changing one rebuilds the plan; invalid combinations are refused with a message):
- *   "cols_per_tile" 2|4|8 [4], "rows_per_tile" 2|4|8 [4], "lds_budget_kb[_up|_dw]" 8..144 [64], "threads_up|_dw"
+ *   "cols_per_tile" 2|4|8 [4; complex vectors use at most 4 per tile], "rows_per_tile" 0|2|4|8 [0 = 4, or 8 for sectors whose row panels exceed the L2], "lds_budget_kb[_up|_dw]" 8..144 [64], "threads_up|_dw"
  *   256|512|1024 [1024], "sort_mode" 0..2 [0], "sort_mode_dw" 0|1 [1], "wt_cols" 2|4|8|16 [4], "tile_bits_up|_dw" (force the block bits),
  *   "lds_min_kb_up|_dw".
  * Timing experiments (results are wrong or partial when set; refused unless HXV_EXPERIMENTS=1 is in the environment):
