@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_dw(DevSector s, DevTiles t, 
   // column of pair `it` within the block (clamped) and its byte offset relative to (first column of a block, row i0);
   // the offsets are kept in registers when a thread has few pairs and recomputed (two instructions) when it has eight
   auto ccol = [&](int it) -> uint32_t { return (uint32_t)min((tid >> LR) + it * cstep, n - 1); };
-  constexpr bool KEEP = NP <= 4;
+  constexpr bool KEEP = NP <= 4 && R < 8;  // (eight-row tiles need the registers for their accumulators)
   uint32_t voff_keep[KEEP ? NP : 1];
   if constexpr (KEEP) {
 #pragma unroll
