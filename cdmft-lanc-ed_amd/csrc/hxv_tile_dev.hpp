@@ -12,6 +12,7 @@ struct DevTiles {
   const uint32_t* gstart;  // [nblocks+1] first 64-position group of each block
   const uint32_t* gmax;    // [groups] longest in-block list of each 64-position group (low 16 bits)
   const uint32_t* ell_in;  // [k_in][dim]
+  const uint32_t* ell16;   // [k_in/2][dim] the same table, two hops per word ((coefficient index << 10) | offset each), or null
   const double2* scoef;    // [nscoef] signed coefficients, last = 0
   const uint32_t* bh_ptr;  // block hops / row slots of the out-of-block part (hxv_tiles.hpp)
   const uint32_t* bh;

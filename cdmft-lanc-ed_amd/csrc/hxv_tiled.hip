@@ -21,7 +21,7 @@ namespace hxv {
 // ---------------------------------------------------------------------------------------
 // pass A
 // ---------------------------------------------------------------------------------------
-template <int C, bool REAL, bool NORB1, bool LZ, typename VT>
+template <int C, bool REAL, bool NORB1, bool LZ, bool P16, typename VT>
 __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, const VT* __restrict__ v,
                                                       const VT* __restrict__ wt, VT* __restrict__ hv, int ngroups,
                                                       int groups_per_xcd, int wc, LzEpilogue lz) {
@@ -129,14 +129,28 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
     }
     // hops inside the block: gathers from the LDS tile
     for (int k0 = 0; k0 < ((t.debug & 2) ? 0 : kin); k0 += HOP_CHUNK) {
-      uint32_t e[HOP_CHUNK];
+      uint32_t e[P16 ? HOP_CHUNK / 2 : HOP_CHUNK];
+      if constexpr (P16) {  // half-size table: two hops per word
 #pragma unroll
-      for (int u = 0; u < HOP_CHUNK; ++u) e[u] = t.ell_in[(int64_t)(k0 + u) * s.dimup + tb0 + p];
+        for (int u = 0; u < HOP_CHUNK / 2; ++u) e[u] = t.ell16[(int64_t)(k0 / 2 + u) * s.dimup + tb0 + p];
+      } else {
+#pragma unroll
+        for (int u = 0; u < HOP_CHUNK; ++u) e[u] = t.ell_in[(int64_t)(k0 + u) * s.dimup + tb0 + p];
+      }
 #pragma unroll
       for (int u = 0; u < HOP_CHUNK; ++u) {
         if (k0 + u < kin) {  // wave-uniform: all 8 words are loaded at once, only the live slots are computed
-          const CT cf = lcoef[e[u] >> TILE_COEF_SHIFT];
-          const int off = (int)(e[u] & TILE_OFF_MASK);
+          uint32_t ci;
+          int off;
+          if constexpr (P16) {
+            const uint32_t hw = (u & 1) ? e[u >> 1] >> 16 : e[u >> 1] & 0xFFFFu;
+            ci = hw >> 10;
+            off = (int)(hw & 0x3FFu);
+          } else {
+            ci = e[u] >> TILE_COEF_SHIFT;
+            off = (int)(e[u] & TILE_OFF_MASK);
+          }
+          const CT cf = lcoef[ci];
 #pragma unroll
           for (int cc = 0; cc < C; ++cc) Coef<REAL>::fma(acc[cc], cf, lds[cc * n + off]);
         }
@@ -192,7 +206,7 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
 // multiple of R, so a thread's pairs all have the same row; every global access is a uniform 64-bit base plus a per-thread
 // 32-bit byte offset that is computed once (tile load, block hops, scratch store), or one 64-bit multiply-add (row slots).
 // ---------------------------------------------------------------------------------------
-template <int R, int NP, bool REAL, typename VT>
+template <int R, int NP, bool REAL, bool P16, typename VT>
 __global__ void __launch_bounds__(1024, 8) hxv_pass_dw(DevSector s, DevTiles t, const VT* __restrict__ v, VT* __restrict__ wt,
                                                       int ngroups, int groups_per_xcd, int wc) {
   // NP = (row,column) pairs of the tile per thread (plan: max_block*R <= NP*blockDim.x); all their global
@@ -292,18 +306,31 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_dw(DevSector s, DevTiles t, 
       const int kin = (t.debug & 2) ? 0 : (int)(packed & 0xFFFFu);
       const int tb0 = (int)t.tstart[kb];  // the block whose in-block tables this one shares
       col1 = (int)t.perm[tb0 + tid] - tb0;
-      const uint32_t* __restrict__ ellp = t.ell_in + tb0 + tid;
+      const uint32_t* __restrict__ ellp = (P16 ? t.ell16 : t.ell_in) + tb0 + tid;
 #pragma unroll
       for (int rr = 0; rr < R; ++rr) acc[rr] = vzero<VT>();
       for (int k0 = 0; k0 < kin; k0 += HOP_CHUNK) {
-        uint32_t e[HOP_CHUNK];
+        uint32_t e[P16 ? HOP_CHUNK / 2 : HOP_CHUNK];
+        if constexpr (P16) {
 #pragma unroll
-        for (int u = 0; u < HOP_CHUNK; ++u) e[u] = ellp[(int64_t)(k0 + u) * s.dimdw];
+          for (int u = 0; u < HOP_CHUNK / 2; ++u) e[u] = ellp[(int64_t)(k0 / 2 + u) * s.dimdw];
+        } else {
+#pragma unroll
+          for (int u = 0; u < HOP_CHUNK; ++u) e[u] = ellp[(int64_t)(k0 + u) * s.dimdw];
+        }
 #pragma unroll
         for (int u = 0; u < HOP_CHUNK; ++u) {
           if (k0 + u < kin) {  // wave-uniform
-            const CT cf = lds_ld<CT>(e[u] >> (TILE_COEF_SHIFT - LCB));
-            const uint32_t col = e[u] & TILE_OFF_MASK;
+            uint32_t cfa, col;  // coefficient's LDS address, source column within the block
+            if constexpr (P16) {
+              const uint32_t hw = (u & 1) ? e[u >> 1] >> 16 : e[u >> 1] & 0xFFFFu;
+              cfa = (hw >> 10) << LCB;
+              col = hw & 0x3FFu;
+            } else {
+              cfa = e[u] >> (TILE_COEF_SHIFT - LCB);
+              col = e[u] & TILE_OFF_MASK;
+            }
+            const CT cf = lds_ld<CT>(cfa);
             const uint32_t src = shl_add<LTB>(col, ltile), sw = swz_of(col);
 #pragma unroll
             for (int rr = 0; rr < R; ++rr) Coef<REAL>::fma(acc[rr], cf, lds_ld<VT>(src + ((uint32_t)(rr * VB) ^ sw)));
@@ -451,7 +478,7 @@ int choose_lowbits(int ns, int npart, int width, int budget_bytes, int max_block
 }
 
 struct HostTiles {
-  std::vector<uint32_t> start, perm, gstart, gmax, ell_in, tstart;
+  std::vector<uint32_t> start, perm, gstart, gmax, ell_in, ell16, tstart;
   std::vector<uint32_t> bh_ptr, bh, rs_ptr, rs_off, rs_tab, rs_base, rs_neg, order;
 };
 
@@ -543,6 +570,19 @@ void build_spin_tiles(const SpinOp& op, const std::vector<uint32_t>& map, int lo
       else
         ++b;  // out-of-block entry: handled by the structured part below
     }
+  }
+  // Half-size copy of the in-block table for the kernels that gather from LDS tiles of at most 1024 rows/columns with at
+  // most 64 signed coefficients: two hops per word, each (coefficient index << 10) | offset.  Half the table bytes to keep in
+  // L2 and half the loads; the 32-bit table stays for the job kernel, which packs its words once per job.
+  h.ell16.clear();
+  if (t.max_block <= 1024 && 2 * op.coef.size() + 1 <= 64 && t.k_in % 2 == 0) {
+    h.ell16.assign((size_t)(t.k_in / 2) * dim, 0u);
+    for (int a = 0; a < t.k_in; ++a)
+      for (int q = 0; q < dim; ++q) {
+        const uint32_t e = h.ell_in[(size_t)a * dim + q];
+        const uint32_t half = ((e >> TILE_COEF_SHIFT) << 10) | (e & 0x3FFu);
+        h.ell16[(size_t)(a / 2) * dim + q] |= half << (16 * (a & 1));
+      }
   }
   // Blocks whose high orbitals hold the same NUMBER of particles contain the same low-orbital patterns, and hops among the
   // low orbitals see nothing else: their in-block tables (words, visiting order, loop bounds) are identical.  Every block
@@ -722,13 +762,22 @@ hipError_t launch_up_lz(const DevSector& s, const DevTiles& t, int lds_bytes, in
   const int gpx = (ngroups + 7) / 8;
   const int64_t nwg = (int64_t)gpx * 8 * t.nblocks;
   void (*kern)(DevSector, DevTiles, const VT*, const VT*, VT*, int, int, int, LzEpilogue);
+  const bool p16 = t.ell16 != nullptr;  // (the half-size in-block table exists)
   if constexpr (std::is_same<VT, double>::value) {  // real vectors exist for real H only
-    kern = norb1 ? hxv_pass_up<C, true, true, LZ, double> : hxv_pass_up<C, true, false, LZ, double>;
-  } else {
-    if (s.real_h)
-      kern = norb1 ? hxv_pass_up<C, true, true, LZ, double2> : hxv_pass_up<C, true, false, LZ, double2>;
+    if (p16)
+      kern = norb1 ? hxv_pass_up<C, true, true, LZ, true, double> : hxv_pass_up<C, true, false, LZ, true, double>;
     else
-      kern = norb1 ? hxv_pass_up<C, false, true, LZ, double2> : hxv_pass_up<C, false, false, LZ, double2>;
+      kern = norb1 ? hxv_pass_up<C, true, true, LZ, false, double> : hxv_pass_up<C, true, false, LZ, false, double>;
+  } else if (s.real_h) {
+    if (p16)
+      kern = norb1 ? hxv_pass_up<C, true, true, LZ, true, double2> : hxv_pass_up<C, true, false, LZ, true, double2>;
+    else
+      kern = norb1 ? hxv_pass_up<C, true, true, LZ, false, double2> : hxv_pass_up<C, true, false, LZ, false, double2>;
+  } else {
+    if (p16)
+      kern = norb1 ? hxv_pass_up<C, false, true, LZ, true, double2> : hxv_pass_up<C, false, false, LZ, true, double2>;
+    else
+      kern = norb1 ? hxv_pass_up<C, false, true, LZ, false, double2> : hxv_pass_up<C, false, false, LZ, false, double2>;
   }
   lds_bytes = std::max(lds_bytes, threads * 8);  // the epilogue reduces through LDS
   hipError_t e = allow_dynamic_lds((const void*)kern, lds_bytes);
@@ -751,10 +800,13 @@ hipError_t launch_dw_np(const DevSector& s, const DevTiles& t, int lds_bytes, in
   const int gpx = (ngroups + 7) / 8;
   const int64_t nwg = (int64_t)((gpx + 1) & ~1) * 8 * t.nblocks;  // (an even number of row groups per XCD: DevTiles::pair_rows)
   void (*kern)(DevSector, DevTiles, const VT*, VT*, int, int, int);
+  const bool p16 = t.ell16 != nullptr;  // (the half-size in-block table exists: blocks <= 1024 columns, <= 64 signed coefficients)
   if constexpr (std::is_same<VT, double>::value)
-    kern = hxv_pass_dw<R, NP, true, double>;
+    kern = p16 ? hxv_pass_dw<R, NP, true, true, double> : hxv_pass_dw<R, NP, true, false, double>;
+  else if (s.real_h)
+    kern = p16 ? hxv_pass_dw<R, NP, true, true, double2> : hxv_pass_dw<R, NP, true, false, double2>;
   else
-    kern = s.real_h ? hxv_pass_dw<R, NP, true, double2> : hxv_pass_dw<R, NP, false, double2>;
+    kern = p16 ? hxv_pass_dw<R, NP, false, true, double2> : hxv_pass_dw<R, NP, false, false, double2>;
   hipError_t e = allow_dynamic_lds((const void*)kern, lds_bytes);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(threads), (size_t)lds_bytes, st, s, t, v, hv, ngroups, gpx, wc);
@@ -816,6 +868,7 @@ std::string make_tile_plan(const SectorHost& s, TilePlan& plan, const PlanUpload
     if (up.u32(h.start, &t.d_start) != hipSuccess || up.u32(h.perm, &t.d_perm) != hipSuccess ||
         up.u32(h.gstart, &t.d_gstart) != hipSuccess || up.u32(h.gmax, &t.d_gmax) != hipSuccess ||
         up.u32(h.ell_in, &t.d_ell_in) != hipSuccess || up.u32(h.tstart, &t.d_tstart) != hipSuccess ||
+        (!h.ell16.empty() && up.u32(h.ell16, &t.d_ell16) != hipSuccess) ||
         up.u32(h.bh_ptr, &t.d_bh_ptr) != hipSuccess || up.u32(h.bh, &t.d_bh) != hipSuccess ||
         up.u32(h.rs_ptr, &t.d_rs_ptr) != hipSuccess || up.u32(h.rs_off, &t.d_rs_off) != hipSuccess ||
         up.u32(h.rs_tab, &t.d_rs_tab) != hipSuccess || up.u32(h.order, &t.d_order) != hipSuccess ||
@@ -880,10 +933,10 @@ template <typename VT>
 static hipError_t launch_tiled_vt(const DevSector& s, const TilePlan& plan, const VT* v, VT* wt, VT* hv, hipStream_t st, const LzEpilogue* lz,
                                   int only_pass, bool wt_natural) {
   constexpr bool RV = std::is_same<VT, double>::value;
-  DevTiles tu{plan.up.d_start, plan.up.d_tstart, plan.up.d_perm, plan.up.d_gstart, plan.up.d_gmax, plan.up.d_ell_in,
+  DevTiles tu{plan.up.d_start, plan.up.d_tstart, plan.up.d_perm, plan.up.d_gstart, plan.up.d_gmax, plan.up.d_ell_in, plan.up.d_ell16,
               plan.d_scoef_up, plan.up.d_bh_ptr, plan.up.d_bh, plan.up.d_rs_ptr, plan.up.d_rs_off, plan.up.d_rs_tab, plan.up.d_rs_base, plan.up.d_rs_neg,
               plan.up.nblocks, 2 * plan.ncoef_up + 1, plan.opt.debug, 0, (2 * plan.up.table_classes <= plan.up.nblocks && !(plan.opt.debug & 32)) ? plan.up.d_order : nullptr};
-  DevTiles td{plan.dw.d_start, plan.dw.d_tstart, plan.dw.d_perm, plan.dw.d_gstart, plan.dw.d_gmax, plan.dw.d_ell_in,
+  DevTiles td{plan.dw.d_start, plan.dw.d_tstart, plan.dw.d_perm, plan.dw.d_gstart, plan.dw.d_gmax, plan.dw.d_ell_in, plan.dw.d_ell16,
               plan.d_scoef_dw, plan.dw.d_bh_ptr, plan.dw.d_bh, plan.dw.d_rs_ptr, plan.dw.d_rs_off, plan.dw.d_rs_tab, plan.dw.d_rs_base, plan.dw.d_rs_neg,
               plan.dw.nblocks, 2 * plan.ncoef_dw + 1, plan.opt.debug, 0, (2 * plan.dw.table_classes <= plan.dw.nblocks && !(plan.opt.debug & 32)) ? plan.dw.d_order : nullptr};
   // (class order only where classes are few: with 11 table sets for 16 blocks (C4) the natural order measured 2.6 % faster)

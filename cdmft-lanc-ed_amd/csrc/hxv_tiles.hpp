@@ -35,6 +35,7 @@ struct SpinTiles {
   uint32_t* d_gstart = nullptr;      // [nblocks+1] first 64-lane group of each block
   uint32_t* d_gmax = nullptr;        // [ngroups] k_in max | k_out max << 16 of each 64-position group
   uint32_t* d_ell_in = nullptr;      // [k_in][dim], indexed by sorted position
+  uint32_t* d_ell16 = nullptr;       // [k_in/2][dim] half-size copy (two hops per word), null when the fields do not fit 16 bits
   // Out-of-block hops, grouped by (block, source block).  A pair whose hop maps the whole source block onto
   // the block with the identity on the low orbitals and one signed coefficient is a BLOCK hop: no per-row
   // data at all, the partner block is read as one contiguous, coalesced run.  Everything else is a ROW slot:
