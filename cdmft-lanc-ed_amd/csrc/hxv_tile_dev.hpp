@@ -12,7 +12,7 @@ struct DevTiles {
   const uint32_t* gstart;  // [nblocks+1] first 64-position group of each block
   const uint32_t* gmax;    // [groups] longest in-block list of each 64-position group (low 16 bits)
   const uint32_t* ell_in;  // [k_in][dim]
-  const uint32_t* ell16;   // [k_in/2][dim] the same table, two hops per word ((coefficient index << 10) | offset each), or null
+  const uint32_t* ell16;   // [k_in/2][dim] the same table, two hops per word ((coefficient index << p16_bits) | offset each), or null
   const double2* scoef;    // [nscoef] signed coefficients, last = 0
   const uint32_t* bh_ptr;  // block hops / row slots of the out-of-block part (hxv_tiles.hpp)
   const uint32_t* bh;
@@ -25,6 +25,9 @@ struct DevTiles {
   int debug;  // timing experiments only: 1 skip out-of-block hops, 2 skip in-block hops, 4 skip the hv read-modify-write (pass B)
   int pair_rows;  // pass B: the two row groups that share 128-byte lines run back to back, block by block (large sectors)
   const uint32_t* order;  // [nblocks] blocks by decreasing size (= grouped by table class), or null: pass B visits a row group's blocks in this order
+  int p16_bits;           // ell16 words: (coefficient index << p16_bits) | offset, two per 32-bit word
+  const uint32_t* rs16;     // half-size row-slot tables: slots sl, sl+1 of a block in one word (same split), or null
+  const uint32_t* rs16_off; // [nslots] offset of the packed table of the pair that STARTS at this slot
 };
 
 constexpr int HOP_CHUNK = 8;

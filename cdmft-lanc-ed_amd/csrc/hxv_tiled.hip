@@ -21,7 +21,10 @@ namespace hxv {
 // ---------------------------------------------------------------------------------------
 // pass A
 // ---------------------------------------------------------------------------------------
-template <int C, bool REAL, bool NORB1, bool LZ, bool P16, typename VT>
+// MR (multi-row): a block may hold more rows than the workgroup has threads (large prefix blocks: 13-14 low orbitals, or
+// 512-thread workgroups on 12); a thread then walks rows p, p+T, p+2T, ... of the tile one after the other.  Rows are
+// independent once the tile is in LDS, so the registers do not grow with the row count.
+template <int C, bool REAL, bool NORB1, bool LZ, bool P16, bool MR, typename VT>
 __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, const VT* __restrict__ v,
                                                       const VT* __restrict__ wt, VT* __restrict__ hv, int ngroups,
                                                       int groups_per_xcd, int wc, LzEpilogue lz) {
@@ -54,36 +57,41 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
     for (int r = threadIdx.x; r < n; r += T) lds[cc * n + r] = src[r];
   }
   for (int q = threadIdx.x; q < t.nscoef; q += T) lcoef[q] = Coef<REAL>::from(t.scoef[q]);
-  // one row per thread (plan guarantees n <= blockDim.x)
-  const int p = threadIdx.x;
+  const uint32_t p16m = (1u << t.p16_bits) - 1u;  // half-size table words: (coefficient index << p16_bits) | offset
+  double asum = 0.0;
+  // one row per thread and trip (the plan guarantees n <= blockDim.x unless MR)
+  int p = threadIdx.x;
   VT acc[C];
-  VT xq[LZ ? C : 1];  // the thread's own input elements, kept for the Lanczos epilogue
-  int r = 0;
+  double au = 0.0;
+  uint32_t mu = 0;
   // Issued BEFORE the barrier so their latency hides behind the tile load: the dw-hop part that pass B left in the
   // column-group-blocked scratch wt[group][row][wc] (C*16 contiguous bytes per row, rows consecutive: a plain
   // streaming read) becomes the initial value of the accumulators; the diagonal's per-row inputs come along.
-  double au = 0.0;
-  uint32_t mu = 0;
-  if (p < n) {
-    if (wt && wc == 0) {
-      // natural layout [local column][pitch] (all-to-all exchange: the dw part arrives assembled like hv)
-      const VT* __restrict__ wcol = wt + (int64_t)c0 * s.pitch + r0 + p;
+  auto row_inputs = [&]() {
+    if (p < n) {
+      if (wt && wc == 0) {
+        // natural layout [local column][pitch] (all-to-all exchange: the dw part arrives assembled like hv)
+        const VT* __restrict__ wcol = wt + (int64_t)c0 * s.pitch + r0 + p;
 #pragma unroll
-      for (int cc = 0; cc < C; ++cc) acc[cc] = wcol[(int64_t)min(cc, nc - 1) * s.pitch];
-    } else if (wt) {
-      const VT* __restrict__ wrow = wt + ((int64_t)(c0 / wc) * s.dimup + r0 + p) * wc + (c0 % wc);
+        for (int cc = 0; cc < C; ++cc) acc[cc] = wcol[(int64_t)min(cc, nc - 1) * s.pitch];
+      } else if (wt) {
+        const VT* __restrict__ wrow = wt + ((int64_t)(c0 / wc) * s.dimup + r0 + p) * wc + (c0 % wc);
 #pragma unroll
-      for (int cc = 0; cc < C; ++cc) acc[cc] = wrow[min(cc, nc - 1)];
-    } else {
+        for (int cc = 0; cc < C; ++cc) acc[cc] = wrow[min(cc, nc - 1)];
+      } else {
 #pragma unroll
-      for (int cc = 0; cc < C; ++cc) acc[cc] = vzero<VT>();
+        for (int cc = 0; cc < C; ++cc) acc[cc] = vzero<VT>();
+      }
+      if (s.diag.mode == 0) {
+        au = s.diag.a_up[r0 + p];
+        mu = s.diag.map_up[r0 + p];
+      }
     }
-    if (s.diag.mode == 0) {
-      au = s.diag.a_up[r0 + p];
-      mu = s.diag.map_up[r0 + p];
-    }
-  }
+  };
+  row_inputs();
   __syncthreads();
+  for (;;) {
+  VT xq[LZ ? C : 1];  // the thread's own input elements, kept for the Lanczos epilogue
   if (p < n) {
     const uint32_t packed = __builtin_amdgcn_readfirstlane(t.gmax[t.gstart[kb] + (p >> 6)]);
     const int kin = (int)(packed & 0xFFFFu);
@@ -92,7 +100,7 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
       for (int cc = 0; cc < C; ++cc) xq[LZ ? cc : 0] = lds[cc * n + p];
     }
     const int i = r0 + p;  // pass A visits the rows in natural order: every global access stays coalesced
-    r = p;
+    const int r = p;
     if (s.diag.mode == 0) {
 #pragma unroll
       for (int cc = 0; cc < C; ++cc) {
@@ -115,16 +123,36 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
 #pragma unroll
         for (int cc = 0; cc < C; ++cc) Coef<REAL>::fma(acc[cc], cf, src[(int64_t)min(cc, nc - 1) * s.pitch]);
       }
-      // row slots: one table word per row and (block, source block) pair
-      const uint32_t emptyz = (uint32_t)(t.nscoef - 1) << TILE_COEF_SHIFT;
-      for (uint32_t sl = t.rs_ptr[kb]; sl < t.rs_ptr[kb + 1]; ++sl) {
-        const uint32_t e = t.rs_tab[t.rs_off[sl] + r];
-        if (__all(e == emptyz)) continue;
-        CT cf = lcoef[e >> TILE_COEF_SHIFT];
-        if (t.rs_neg[sl]) cf = Coef<REAL>::neg(cf);  // (uniform: the shared table holds the other overall sign)
-        const VT* __restrict__ src = vcol0 + t.rs_base[sl] + (e & TILE_OFF_MASK);
+      // row slots: one table word per row and (block, source block) pair -- or, packed, per TWO such pairs (P16)
+      const uint32_t rs1 = t.rs_ptr[kb + 1];
+      if (P16 && t.rs16) {
+        const uint32_t empty16 = (uint32_t)(t.nscoef - 1) << t.p16_bits;
+        for (uint32_t sl = t.rs_ptr[kb]; sl < rs1; sl += 2) {
+          const uint32_t w = t.rs16[t.rs16_off[sl] + r];
 #pragma unroll
-        for (int cc = 0; cc < C; ++cc) Coef<REAL>::fma(acc[cc], cf, src[(int64_t)min(cc, nc - 1) * s.pitch]);
+          for (int hh = 0; hh < 2; ++hh) {
+            if (sl + hh < rs1) {  // (uniform)
+              const uint32_t e = hh ? w >> 16 : w & 0xFFFFu;
+              if (__all(e == empty16)) continue;
+              CT cf = lcoef[e >> t.p16_bits];
+              if (t.rs_neg[sl + hh]) cf = Coef<REAL>::neg(cf);  // (uniform: the shared table holds the other overall sign)
+              const VT* __restrict__ src = vcol0 + t.rs_base[sl + hh] + (e & p16m);
+#pragma unroll
+              for (int cc = 0; cc < C; ++cc) Coef<REAL>::fma(acc[cc], cf, src[(int64_t)min(cc, nc - 1) * s.pitch]);
+            }
+          }
+        }
+      } else {
+        const uint32_t emptyz = (uint32_t)(t.nscoef - 1) << TILE_COEF_SHIFT;
+        for (uint32_t sl = t.rs_ptr[kb]; sl < rs1; ++sl) {
+          const uint32_t e = t.rs_tab[t.rs_off[sl] + r];
+          if (__all(e == emptyz)) continue;
+          CT cf = lcoef[e >> TILE_COEF_SHIFT];
+          if (t.rs_neg[sl]) cf = Coef<REAL>::neg(cf);  // (uniform: the shared table holds the other overall sign)
+          const VT* __restrict__ src = vcol0 + t.rs_base[sl] + (e & TILE_OFF_MASK);
+#pragma unroll
+          for (int cc = 0; cc < C; ++cc) Coef<REAL>::fma(acc[cc], cf, src[(int64_t)min(cc, nc - 1) * s.pitch]);
+        }
       }
     }
     // hops inside the block: gathers from the LDS tile
@@ -144,8 +172,8 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
           int off;
           if constexpr (P16) {
             const uint32_t hw = (u & 1) ? e[u >> 1] >> 16 : e[u >> 1] & 0xFFFFu;
-            ci = hw >> 10;
-            off = (int)(hw & 0x3FFu);
+            ci = hw >> t.p16_bits;
+            off = (int)(hw & p16m);
           } else {
             ci = e[u] >> TILE_COEF_SHIFT;
             off = (int)(e[u] & TILE_OFF_MASK);
@@ -159,7 +187,6 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
   }
   // Epilogue, same thread <-> row mapping: store hv with lanes along the rows.
   // With LZ: w = s*(H x) - c*xm and the partial sums of Re(conj(s*x) w).
-  double asum = 0.0;
   if (p < n) {
     const double sc = LZ ? lz.scal[lz.i_s] : 1.0;
     const double cm = (LZ && lz.xm) ? lz.scal[lz.i_c] : 0.0;
@@ -179,6 +206,11 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
           store_stream(&hv[o], w);
       }
     }
+  }
+  if constexpr (!MR) break;
+  p += T;
+  if ((p & ~63) >= n) break;  // (wave-uniform: the lanes of a wave share p >> 6)
+  row_inputs();
   }
   if (LZ) {
     // wavefront partial sums first (shuffles), one LDS word per wave afterwards: two barriers instead of a tree of eleven
@@ -251,6 +283,7 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_dw(DevSector s, DevTiles t, 
   auto swz_of = [](uint32_t col) -> uint32_t { return ((col >> LSW) & (R - 1)) << LVB; };  // byte XOR of a column
   const uint32_t tq = ltile + (((uint32_t)tid << LVB) ^ swz_of((uint32_t)tid >> LR));  // this thread's pair 0 (pair it: + it*T*VB)
   const uint32_t emptyz = (uint32_t)(t.nscoef - 1) << TILE_COEF_SHIFT;
+  const uint32_t p16m = (1u << t.p16_bits) - 1u;  // half-size table words: (coefficient index << p16_bits) | column
   for (int q = tid; q < t.nscoef; q += T) lds_st<CT>(q << LCB, Coef<REAL>::from(t.scoef[q]));
   // per-thread constants
   const int r = tid & (R - 1);
@@ -324,8 +357,8 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_dw(DevSector s, DevTiles t, 
             uint32_t cfa, col;  // coefficient's LDS address, source column within the block
             if constexpr (P16) {
               const uint32_t hw = (u & 1) ? e[u >> 1] >> 16 : e[u >> 1] & 0xFFFFu;
-              cfa = (hw >> 10) << LCB;
-              col = hw & 0x3FFu;
+              cfa = (hw >> t.p16_bits) << LCB;
+              col = hw & p16m;
             } else {
               cfa = e[u] >> (TILE_COEF_SHIFT - LCB);
               col = e[u] & TILE_OFF_MASK;
@@ -370,14 +403,26 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_dw(DevSector s, DevTiles t, 
       // row slots: one table word per column of the block and (block, source block) pair; the words of SB slots
       // are fetched together so that the gathers that depend on them follow one table round trip, not SB
       constexpr int SB = 2;
+      const bool packed = P16 && t.rs16 != nullptr;  // (uniform) two slots per table word
       for (uint32_t sl0 = rs0; sl0 < rs_end; sl0 += SB) {
         uint32_t e[SB][HB];
+        if (packed) {
+          const uint32_t* __restrict__ tab = t.rs16 + t.rs16_off[sl0];
 #pragma unroll
-        for (int jj = 0; jj < SB; ++jj) {
-          if (sl0 + jj < rs_end) {  // uniform
-            const uint32_t* __restrict__ tab = t.rs_tab + t.rs_off[sl0 + jj];
+          for (int it = 0; it < HB; ++it) {
+            const uint32_t w = tab[ccol(base + it)];
+            // back to the 32-bit word format of the unpacked table
+            e[0][it] = ((w & 0xFFFFu) >> t.p16_bits << TILE_COEF_SHIFT) | (w & p16m);
+            e[1][it] = ((w >> 16) >> t.p16_bits << TILE_COEF_SHIFT) | ((w >> 16) & p16m);
+          }
+        } else {
 #pragma unroll
-            for (int it = 0; it < HB; ++it) e[jj][it] = tab[ccol(base + it)];
+          for (int jj = 0; jj < SB; ++jj) {
+            if (sl0 + jj < rs_end) {  // uniform
+              const uint32_t* __restrict__ tab = t.rs_tab + t.rs_off[sl0 + jj];
+#pragma unroll
+              for (int it = 0; it < HB; ++it) e[jj][it] = tab[ccol(base + it)];
+            }
           }
         }
 #pragma unroll
@@ -479,7 +524,7 @@ int choose_lowbits(int ns, int npart, int width, int budget_bytes, int max_block
 
 struct HostTiles {
   std::vector<uint32_t> start, perm, gstart, gmax, ell_in, ell16, tstart;
-  std::vector<uint32_t> bh_ptr, bh, rs_ptr, rs_off, rs_tab, rs_base, rs_neg, order;
+  std::vector<uint32_t> bh_ptr, bh, rs_ptr, rs_off, rs_tab, rs_base, rs_neg, order, rs16, rs16_off;
 };
 
 // sorted_out: outer table indexed by sorted position (pass A) or by natural index (pass B)
@@ -571,18 +616,27 @@ void build_spin_tiles(const SpinOp& op, const std::vector<uint32_t>& map, int lo
         ++b;  // out-of-block entry: handled by the structured part below
     }
   }
-  // Half-size copy of the in-block table for the kernels that gather from LDS tiles of at most 1024 rows/columns with at
-  // most 64 signed coefficients: two hops per word, each (coefficient index << 10) | offset.  Half the table bytes to keep in
-  // L2 and half the loads; the 32-bit table stays for the job kernel, which packs its words once per job.
+  // Half-size copy of the in-block table: two hops per word, each (coefficient index << p16_bits) | offset, whenever the
+  // block offsets and the signed-coefficient indices fit 16 bits together (C3: 10 + 3 bits; blocks of 14 low orbitals: 12 + 3).
+  // Half the table bytes to keep in L2 and half the loads; the 32-bit table stays for the job kernel, which packs its words once per job.
   h.ell16.clear();
-  if (t.max_block <= 1024 && 2 * op.coef.size() + 1 <= 64 && t.k_in % 2 == 0) {
-    h.ell16.assign((size_t)(t.k_in / 2) * dim, 0u);
-    for (int a = 0; a < t.k_in; ++a)
-      for (int q = 0; q < dim; ++q) {
-        const uint32_t e = h.ell_in[(size_t)a * dim + q];
-        const uint32_t half = ((e >> TILE_COEF_SHIFT) << 10) | (e & 0x3FFu);
-        h.ell16[(size_t)(a / 2) * dim + q] |= half << (16 * (a & 1));
-      }
+  t.p16_bits = 0;
+  {
+    int ob = 1, cb = 1;
+    while ((1 << ob) < t.max_block) ++ob;
+    while ((1u << cb) < 2 * op.coef.size() + 1) ++cb;
+    if (ob + cb <= 16 && t.k_in % 2 == 0) {
+      t.p16_bits = std::max(ob, 10);  // (10 when it fits: the split the kernels were tuned with)
+      if (t.p16_bits + cb > 16) t.p16_bits = ob;
+      const uint32_t om = (1u << t.p16_bits) - 1u;
+      h.ell16.assign((size_t)(t.k_in / 2) * dim, 0u);
+      for (int a = 0; a < t.k_in; ++a)
+        for (int q = 0; q < dim; ++q) {
+          const uint32_t e = h.ell_in[(size_t)a * dim + q];
+          const uint32_t half = ((e >> TILE_COEF_SHIFT) << t.p16_bits) | (e & om);
+          h.ell16[(size_t)(a / 2) * dim + q] |= half << (16 * (a & 1));
+        }
+    }
   }
   // Blocks whose high orbitals hold the same NUMBER of particles contain the same low-orbital patterns, and hops among the
   // low orbitals see nothing else: their in-block tables (words, visiting order, loop bounds) are identical.  Every block
@@ -724,6 +778,52 @@ void build_spin_tiles(const SpinOp& op, const std::vector<uint32_t>& map, int lo
       }
     }
   }
+  // Half-size row-slot tables, two slots of a block per 32-bit word ((coefficient index << p16_bits) | source offset relative to
+  // the slot's block, the split of the half-size in-block table): half the table loads and bytes of the out-of-block phases.
+  // Needs block-relative words (contiguous gather slots: always on an unsplit sector).  Pairs are shared like the single tables.
+  h.rs16.clear();
+  h.rs16_off.assign(h.rs_off.size(), 0u);
+  if (t.p16_bits > 0 && !h.rs_off.empty()) {
+    bool ok = true;
+    // (absolute words appear only with non-contiguous gather slots: their offsets do not fit the field)
+    const uint32_t om = (1u << t.p16_bits) - 1u;
+    for (int k = 0; k < t.nblocks && ok; ++k) {
+      const uint32_t nb = h.start[k + 1] - h.start[k];
+      for (uint32_t sl = h.rs_ptr[k]; sl < h.rs_ptr[k + 1] && ok; ++sl)
+        for (uint32_t q = 0; q < nb && ok; ++q) ok = (h.rs_tab[h.rs_off[sl] + q] & TILE_OFF_MASK) <= om;
+    }
+    if (ok) {
+      std::map<std::pair<uint32_t, uint32_t>, uint32_t> seen;  // (table of the first slot, table of the second slot or ~0) -> packed offset
+      const uint32_t e16 = (uint32_t)(2 * op.coef.size()) << t.p16_bits;  // empty slot: (offset 0, zero coefficient)
+      for (int k = 0; k < t.nblocks; ++k) {
+        const uint32_t nb = h.start[k + 1] - h.start[k];
+        for (uint32_t sl = h.rs_ptr[k]; sl < h.rs_ptr[k + 1]; sl += 2) {
+          const bool two = sl + 1 < h.rs_ptr[k + 1];
+          const auto key = std::make_pair(h.rs_off[sl], two ? h.rs_off[sl + 1] : 0xFFFFFFFFu);
+          auto it = seen.find(key);
+          if (it == seen.end()) {
+            const uint32_t base = (uint32_t)h.rs16.size();
+            h.rs16.resize(base + nb);
+            for (uint32_t q = 0; q < nb; ++q) {
+              const uint32_t a = h.rs_tab[h.rs_off[sl] + q];
+              const uint32_t lo = ((a >> TILE_COEF_SHIFT) << t.p16_bits) | (a & om);
+              uint32_t hi = e16;
+              if (two) {
+                const uint32_t bb = h.rs_tab[h.rs_off[sl + 1] + q];
+                hi = ((bb >> TILE_COEF_SHIFT) << t.p16_bits) | (bb & om);
+              }
+              h.rs16[base + q] = lo | (hi << 16);
+            }
+            it = seen.emplace(key, base).first;
+          }
+          h.rs16_off[sl] = it->second;
+        }
+      }
+    }
+  }
+  t.rs16_on = !h.rs16.empty();
+  if (h.rs16.empty()) h.rs16.assign(1, 0u);
+  if (h.rs16_off.empty()) h.rs16_off.assign(1, 0u);
   if (h.bh.empty()) h.bh.assign(2, 0);
   if (h.rs_off.empty()) {
     h.rs_off.assign(1, 0);
@@ -755,8 +855,8 @@ hipError_t allow_dynamic_lds(const void* kern, int bytes) {
   return e;
 }
 
-template <int C, bool LZ, typename VT>
-hipError_t launch_up_lz(const DevSector& s, const DevTiles& t, int lds_bytes, int threads, bool norb1, int wc, const VT* v,
+template <int C, bool LZ, bool MR, typename VT>
+hipError_t launch_up_mr(const DevSector& s, const DevTiles& t, int lds_bytes, int threads, bool norb1, int wc, const VT* v,
                         const VT* wt, VT* hv, const LzEpilogue& lz, hipStream_t st) {
   const int ngroups = (s.qdw + C - 1) / C;
   const int gpx = (ngroups + 7) / 8;
@@ -765,19 +865,19 @@ hipError_t launch_up_lz(const DevSector& s, const DevTiles& t, int lds_bytes, in
   const bool p16 = t.ell16 != nullptr;  // (the half-size in-block table exists)
   if constexpr (std::is_same<VT, double>::value) {  // real vectors exist for real H only
     if (p16)
-      kern = norb1 ? hxv_pass_up<C, true, true, LZ, true, double> : hxv_pass_up<C, true, false, LZ, true, double>;
+      kern = norb1 ? hxv_pass_up<C, true, true, LZ, true, MR, double> : hxv_pass_up<C, true, false, LZ, true, MR, double>;
     else
-      kern = norb1 ? hxv_pass_up<C, true, true, LZ, false, double> : hxv_pass_up<C, true, false, LZ, false, double>;
+      kern = norb1 ? hxv_pass_up<C, true, true, LZ, false, MR, double> : hxv_pass_up<C, true, false, LZ, false, MR, double>;
   } else if (s.real_h) {
     if (p16)
-      kern = norb1 ? hxv_pass_up<C, true, true, LZ, true, double2> : hxv_pass_up<C, true, false, LZ, true, double2>;
+      kern = norb1 ? hxv_pass_up<C, true, true, LZ, true, MR, double2> : hxv_pass_up<C, true, false, LZ, true, MR, double2>;
     else
-      kern = norb1 ? hxv_pass_up<C, true, true, LZ, false, double2> : hxv_pass_up<C, true, false, LZ, false, double2>;
+      kern = norb1 ? hxv_pass_up<C, true, true, LZ, false, MR, double2> : hxv_pass_up<C, true, false, LZ, false, MR, double2>;
   } else {
     if (p16)
-      kern = norb1 ? hxv_pass_up<C, false, true, LZ, true, double2> : hxv_pass_up<C, false, false, LZ, true, double2>;
+      kern = norb1 ? hxv_pass_up<C, false, true, LZ, true, MR, double2> : hxv_pass_up<C, false, false, LZ, true, MR, double2>;
     else
-      kern = norb1 ? hxv_pass_up<C, false, true, LZ, false, double2> : hxv_pass_up<C, false, false, LZ, false, double2>;
+      kern = norb1 ? hxv_pass_up<C, false, true, LZ, false, MR, double2> : hxv_pass_up<C, false, false, LZ, false, MR, double2>;
   }
   lds_bytes = std::max(lds_bytes, threads * 8);  // the epilogue reduces through LDS
   hipError_t e = allow_dynamic_lds((const void*)kern, lds_bytes);
@@ -786,11 +886,19 @@ hipError_t launch_up_lz(const DevSector& s, const DevTiles& t, int lds_bytes, in
   return hipGetLastError();
 }
 
+template <int C, bool LZ, typename VT>
+hipError_t launch_up_lz(const DevSector& s, const DevTiles& t, int max_block, int lds_bytes, int threads, bool norb1, int wc, const VT* v,
+                        const VT* wt, VT* hv, const LzEpilogue& lz, hipStream_t st) {
+  // one row per thread when every block fits the workgroup, else the multi-row walk
+  if (max_block > threads) return launch_up_mr<C, LZ, true, VT>(s, t, lds_bytes, threads, norb1, wc, v, wt, hv, lz, st);
+  return launch_up_mr<C, LZ, false, VT>(s, t, lds_bytes, threads, norb1, wc, v, wt, hv, lz, st);
+}
+
 template <int C, typename VT>
-hipError_t launch_up(const DevSector& s, const DevTiles& t, int lds_bytes, int threads, bool norb1, int wc, const VT* v,
+hipError_t launch_up(const DevSector& s, const DevTiles& t, int max_block, int lds_bytes, int threads, bool norb1, int wc, const VT* v,
                      const VT* wt, VT* hv, const LzEpilogue* lz, hipStream_t st) {
-  if (lz) return launch_up_lz<C, true, VT>(s, t, lds_bytes, threads, norb1, wc, v, wt, hv, *lz, st);
-  return launch_up_lz<C, false, VT>(s, t, lds_bytes, threads, norb1, wc, v, wt, hv, LzEpilogue(), st);
+  if (lz) return launch_up_lz<C, true, VT>(s, t, max_block, lds_bytes, threads, norb1, wc, v, wt, hv, *lz, st);
+  return launch_up_lz<C, false, VT>(s, t, max_block, lds_bytes, threads, norb1, wc, v, wt, hv, LzEpilogue(), st);
 }
 
 template <int R, int NP, typename VT>
@@ -837,7 +945,7 @@ std::vector<double2> signed_coefs(const SpinOp& op) {
 
 std::string make_tile_plan(const SectorHost& s, TilePlan& plan, const PlanUploader& up) {
   TileOptions& o = plan.opt;
-  if (o.cols_per_tile != 2 && o.cols_per_tile != 4 && o.cols_per_tile != 8) return "cols_per_tile must be 2, 4 or 8";
+  if (o.cols_per_tile != 1 && o.cols_per_tile != 2 && o.cols_per_tile != 4 && o.cols_per_tile != 8) return "cols_per_tile must be 1, 2, 4 or 8";
   // Large sectors (Ns=18): two neighbouring 4-row panels of DimDw columns are 128 B x DimDw = 6 MB of lines, more than an XCD's
   // L2, and nearly every out-of-block gather of pass B then leaves the XCD: eight rows per tile (whole lines; smaller blocks
   // to stay within the LDS budget) measured 40.8 ms against 47.4 ms per pass B there (Ns=16: 2.25 against 2.22 ms).
@@ -872,13 +980,15 @@ std::string make_tile_plan(const SectorHost& s, TilePlan& plan, const PlanUpload
         up.u32(h.bh_ptr, &t.d_bh_ptr) != hipSuccess || up.u32(h.bh, &t.d_bh) != hipSuccess ||
         up.u32(h.rs_ptr, &t.d_rs_ptr) != hipSuccess || up.u32(h.rs_off, &t.d_rs_off) != hipSuccess ||
         up.u32(h.rs_tab, &t.d_rs_tab) != hipSuccess || up.u32(h.order, &t.d_order) != hipSuccess ||
-        up.u32(h.rs_base, &t.d_rs_base) != hipSuccess || up.u32(h.rs_neg, &t.d_rs_neg) != hipSuccess)
+        up.u32(h.rs_base, &t.d_rs_base) != hipSuccess || up.u32(h.rs_neg, &t.d_rs_neg) != hipSuccess ||
+        up.u32(h.rs16, &t.d_rs16) != hipSuccess || up.u32(h.rs16_off, &t.d_rs16_off) != hipSuccess)
       return "upload of tile tables failed";
     return "";
   };
   static const std::vector<uint32_t> no_map;  // panel handles have no up basis: plain index chunks (pass A never runs)
-  std::string e = one(s.up, s.panel_rows > 0 ? no_map : s.map_up, s.nup, o.cols_per_tile, o.force_bits_up, o.lds_budget_kb_up, o.threads_up, nullptr, true, 0,
-                      plan.up);
+  if (o.rows_per_thread_up < 1 || o.rows_per_thread_up > 8) return "rows_per_thread_up must be in [1,8]";
+  std::string e = one(s.up, s.panel_rows > 0 ? no_map : s.map_up, s.nup, o.cols_per_tile, o.force_bits_up, o.lds_budget_kb_up,
+                      o.threads_up * o.rows_per_thread_up, nullptr, true, 0, plan.up);
   if (!e.empty()) return e;
   // pass B sorts by the inner count only: its outer table is read in natural column order
   e = one(s.dw, s.map_dw, s.ndw, o.rows_per_tile, o.force_bits_dw, o.lds_budget_kb_dw, o.threads_dw, &s.vcol, false,
@@ -935,10 +1045,10 @@ static hipError_t launch_tiled_vt(const DevSector& s, const TilePlan& plan, cons
   constexpr bool RV = std::is_same<VT, double>::value;
   DevTiles tu{plan.up.d_start, plan.up.d_tstart, plan.up.d_perm, plan.up.d_gstart, plan.up.d_gmax, plan.up.d_ell_in, plan.up.d_ell16,
               plan.d_scoef_up, plan.up.d_bh_ptr, plan.up.d_bh, plan.up.d_rs_ptr, plan.up.d_rs_off, plan.up.d_rs_tab, plan.up.d_rs_base, plan.up.d_rs_neg,
-              plan.up.nblocks, 2 * plan.ncoef_up + 1, plan.opt.debug, 0, (2 * plan.up.table_classes <= plan.up.nblocks && !(plan.opt.debug & 32)) ? plan.up.d_order : nullptr};
+              plan.up.nblocks, 2 * plan.ncoef_up + 1, plan.opt.debug, 0, (2 * plan.up.table_classes <= plan.up.nblocks && !(plan.opt.debug & 32)) ? plan.up.d_order : nullptr, plan.up.p16_bits, (plan.up.rs16_on && !(plan.opt.debug & 64)) ? plan.up.d_rs16 : nullptr, plan.up.d_rs16_off};
   DevTiles td{plan.dw.d_start, plan.dw.d_tstart, plan.dw.d_perm, plan.dw.d_gstart, plan.dw.d_gmax, plan.dw.d_ell_in, plan.dw.d_ell16,
               plan.d_scoef_dw, plan.dw.d_bh_ptr, plan.dw.d_bh, plan.dw.d_rs_ptr, plan.dw.d_rs_off, plan.dw.d_rs_tab, plan.dw.d_rs_base, plan.dw.d_rs_neg,
-              plan.dw.nblocks, 2 * plan.ncoef_dw + 1, plan.opt.debug, 0, (2 * plan.dw.table_classes <= plan.dw.nblocks && !(plan.opt.debug & 32)) ? plan.dw.d_order : nullptr};
+              plan.dw.nblocks, 2 * plan.ncoef_dw + 1, plan.opt.debug, 0, (2 * plan.dw.table_classes <= plan.dw.nblocks && !(plan.opt.debug & 32)) ? plan.dw.d_order : nullptr, plan.dw.p16_bits, (plan.dw.rs16_on && !(plan.opt.debug & 64)) ? plan.dw.d_rs16 : nullptr, plan.dw.d_rs16_off};
   // (class order only where classes are few: with 11 table sets for 16 blocks (C4) the natural order measured 2.6 % faster)
   // (decided below, once the tile's row count R is known)
   const int C = RV ? real_cols(plan) : cplx_cols(plan), R = RV ? real_rows(plan) : plan.opt.rows_per_tile;
@@ -969,11 +1079,12 @@ static hipError_t launch_tiled_vt(const DevSector& s, const TilePlan& plan, cons
     if (job_a) return launch_up_job(s, plan, tu, wc, v, wta, hv, lz, st);
   }
   if (passes & 1) switch (C) {
-      case 2: e = launch_up<2, VT>(s, tu, lds_a, ta, norb1, wc, v, wta, hv, lz, st); break;
-      case 4: e = launch_up<4, VT>(s, tu, lds_a, ta, norb1, wc, v, wta, hv, lz, st); break;
+      case 1: e = launch_up<1, VT>(s, tu, plan.up.max_block, lds_a, ta, norb1, wc, v, wta, hv, lz, st); break;
+      case 2: e = launch_up<2, VT>(s, tu, plan.up.max_block, lds_a, ta, norb1, wc, v, wta, hv, lz, st); break;
+      case 4: e = launch_up<4, VT>(s, tu, plan.up.max_block, lds_a, ta, norb1, wc, v, wta, hv, lz, st); break;
       default:
         if constexpr (RV)
-          e = launch_up<8, VT>(s, tu, lds_a, ta, norb1, wc, v, wta, hv, lz, st);
+          e = launch_up<8, VT>(s, tu, plan.up.max_block, lds_a, ta, norb1, wc, v, wta, hv, lz, st);
         else
           e = hipErrorInvalidValue;  // (cplx_cols)
         break;

@@ -36,6 +36,7 @@ struct SpinTiles {
   uint32_t* d_gmax = nullptr;        // [ngroups] k_in max | k_out max << 16 of each 64-position group
   uint32_t* d_ell_in = nullptr;      // [k_in][dim], indexed by sorted position
   uint32_t* d_ell16 = nullptr;       // [k_in/2][dim] half-size copy (two hops per word), null when the fields do not fit 16 bits
+  int p16_bits = 0;                  // offset bits of a half-size word (the coefficient index sits above them)
   // Out-of-block hops, grouped by (block, source block).  A pair whose hop maps the whole source block onto
   // the block with the identity on the low orbitals and one signed coefficient is a BLOCK hop: no per-row
   // data at all, the partner block is read as one contiguous, coalesced run.  Everything else is a ROW slot:
@@ -48,6 +49,9 @@ struct SpinTiles {
   uint32_t* d_rs_base = nullptr;     // [nslots] first gather slot of the source block (0: the words are absolute)
   uint32_t* d_rs_neg = nullptr;      // [nslots] 1: the shared table holds the opposite overall sign
   int rs_tables = 0;                 // distinct row-slot tables after sharing
+  uint32_t* d_rs16 = nullptr;        // half-size row-slot tables, two slots per word (pairs of a block's slots), shared like the single ones
+  uint32_t* d_rs16_off = nullptr;    // [nslots] packed table of the pair starting at a slot
+  bool rs16_on = false;
   double bh_per_row = 0, rs_per_row = 0;  // statistics: block hops / row slots visited per row
   int max_outer = 0;                 // most (row slots + block hops) of any block (register tables of the job kernels)
   uint32_t* d_order = nullptr;       // [nblocks] block indices, largest block first (job order inside a chunk)
@@ -61,6 +65,8 @@ struct TileOptions {
   int lds_budget_kb_dw = 64;  // LDS per workgroup tile, pass B (two 1024-thread workgroups per CU)
   int force_bits_up = -1, force_bits_dw = -1;
   int threads_up = 1024, threads_dw = 1024;
+  int rows_per_thread_up = 1;  // pass A: a block may hold up to threads_up * rows_per_thread_up rows (1..8); > 1 = larger prefix blocks,
+                               // or the same blocks on smaller workgroups (more workgroups per CU)
   int sort_mode = 0;  // pass A visiting order: 0 natural (keeps global accesses coalesced), 1 by inner count, 2 by (outer, inner)
   int sort_mode_dw = 1;  // pass B inner phase (LDS only): 0 natural, 1 by inner count
   int lds_min_kb_up = 0, lds_min_kb_dw = 0;  // request at least this much LDS per workgroup (limits workgroups per CU)
