@@ -462,7 +462,6 @@ int hxv_set_option(hxv_handle* h, const char* name, int64_t value) {
   else if (!strcmp(name, "tile_bits_dw")) o.force_bits_dw = (int)value;
   else if (!strcmp(name, "threads_up")) o.threads_up = (int)value;
   else if (!strcmp(name, "threads_dw")) o.threads_dw = (int)value;
-  else if (!strcmp(name, "rows_per_thread_up")) o.rows_per_thread_up = (int)value;
 
   else if (!strcmp(name, "sort_mode")) o.sort_mode = (int)value;
   else if (!strcmp(name, "wt_cols")) o.wt_cols = (int)value;
@@ -498,7 +497,6 @@ int64_t hxv_get_option(const hxv_handle* h, const char* name) {
   if (!strcmp(name, "tile_bits_dw")) return h->plan.dw.lowbits;
   if (!strcmp(name, "cols_per_tile")) return h->plan.opt.cols_per_tile;
   if (!strcmp(name, "rows_per_tile")) return h->plan.opt.rows_per_tile;
-  if (!strcmp(name, "rows_per_thread_up")) return h->plan.opt.rows_per_thread_up;
   if (!strcmp(name, "p16_bits_up")) return h->plan.up.p16_bits;
   if (!strcmp(name, "p16_bits_dw")) return h->plan.dw.p16_bits;
   if (!strcmp(name, "lds_budget_kb_up")) return h->plan.opt.lds_budget_kb_up;

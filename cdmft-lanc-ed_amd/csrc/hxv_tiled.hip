@@ -21,10 +21,9 @@ namespace hxv {
 // ---------------------------------------------------------------------------------------
 // pass A
 // ---------------------------------------------------------------------------------------
-// MR (multi-row): a block may hold more rows than the workgroup has threads (large prefix blocks: 13-14 low orbitals, or
-// 512-thread workgroups on 12); a thread then walks rows p, p+T, p+2T, ... of the tile one after the other.  Rows are
-// independent once the tile is in LDS, so the registers do not grow with the row count.
-template <int C, bool REAL, bool NORB1, bool LZ, bool P16, bool MR, typename VT>
+// (Round 3 also ran this kernel with several rows per thread -- blocks of 13-14 low orbitals, or 512-thread workgroups on blocks of
+//  12 -- and every such plan was slower at C3, C4 and C5 (profiles/r03_ab_mr_*.log): one row per thread it stays.)
+template <int C, bool REAL, bool NORB1, bool LZ, bool P16, typename VT>
 __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, const VT* __restrict__ v,
                                                       const VT* __restrict__ wt, VT* __restrict__ hv, int ngroups,
                                                       int groups_per_xcd, int wc, LzEpilogue lz) {
@@ -59,8 +58,8 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
   for (int q = threadIdx.x; q < t.nscoef; q += T) lcoef[q] = Coef<REAL>::from(t.scoef[q]);
   const uint32_t p16m = (1u << t.p16_bits) - 1u;  // half-size table words: (coefficient index << p16_bits) | offset
   double asum = 0.0;
-  // one row per thread and trip (the plan guarantees n <= blockDim.x unless MR)
-  int p = threadIdx.x;
+  // one row per thread (the plan guarantees n <= blockDim.x)
+  const int p = threadIdx.x;
   VT acc[C];
   double au = 0.0;
   uint32_t mu = 0;
@@ -90,7 +89,6 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
   };
   row_inputs();
   __syncthreads();
-  for (;;) {
   VT xq[LZ ? C : 1];  // the thread's own input elements, kept for the Lanczos epilogue
   if (p < n) {
     const uint32_t packed = __builtin_amdgcn_readfirstlane(t.gmax[t.gstart[kb] + (p >> 6)]);
@@ -206,11 +204,6 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
           store_stream(&hv[o], w);
       }
     }
-  }
-  if constexpr (!MR) break;
-  p += T;
-  if ((p & ~63) >= n) break;  // (wave-uniform: the lanes of a wave share p >> 6)
-  row_inputs();
   }
   if (LZ) {
     // wavefront partial sums first (shuffles), one LDS word per wave afterwards: two barriers instead of a tree of eleven
@@ -402,27 +395,17 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_dw(DevSector s, DevTiles t, 
       }
       // row slots: one table word per column of the block and (block, source block) pair; the words of SB slots
       // are fetched together so that the gathers that depend on them follow one table round trip, not SB
+      // (the half-size, two-slots-per-word copy of these tables serves pass A only: here its decode costs the registers that
+      //  keep eight-pair tiles from spilling, for no measurable gain)
       constexpr int SB = 2;
-      const bool packed = P16 && t.rs16 != nullptr;  // (uniform) two slots per table word
       for (uint32_t sl0 = rs0; sl0 < rs_end; sl0 += SB) {
         uint32_t e[SB][HB];
-        if (packed) {
-          const uint32_t* __restrict__ tab = t.rs16 + t.rs16_off[sl0];
 #pragma unroll
-          for (int it = 0; it < HB; ++it) {
-            const uint32_t w = tab[ccol(base + it)];
-            // back to the 32-bit word format of the unpacked table
-            e[0][it] = ((w & 0xFFFFu) >> t.p16_bits << TILE_COEF_SHIFT) | (w & p16m);
-            e[1][it] = ((w >> 16) >> t.p16_bits << TILE_COEF_SHIFT) | ((w >> 16) & p16m);
-          }
-        } else {
+        for (int jj = 0; jj < SB; ++jj) {
+          if (sl0 + jj < rs_end) {  // uniform
+            const uint32_t* __restrict__ tab = t.rs_tab + t.rs_off[sl0 + jj];
 #pragma unroll
-          for (int jj = 0; jj < SB; ++jj) {
-            if (sl0 + jj < rs_end) {  // uniform
-              const uint32_t* __restrict__ tab = t.rs_tab + t.rs_off[sl0 + jj];
-#pragma unroll
-              for (int it = 0; it < HB; ++it) e[jj][it] = tab[ccol(base + it)];
-            }
+            for (int it = 0; it < HB; ++it) e[jj][it] = tab[ccol(base + it)];
           }
         }
 #pragma unroll
@@ -855,8 +838,8 @@ hipError_t allow_dynamic_lds(const void* kern, int bytes) {
   return e;
 }
 
-template <int C, bool LZ, bool MR, typename VT>
-hipError_t launch_up_mr(const DevSector& s, const DevTiles& t, int lds_bytes, int threads, bool norb1, int wc, const VT* v,
+template <int C, bool LZ, typename VT>
+hipError_t launch_up_lz(const DevSector& s, const DevTiles& t, int lds_bytes, int threads, bool norb1, int wc, const VT* v,
                         const VT* wt, VT* hv, const LzEpilogue& lz, hipStream_t st) {
   const int ngroups = (s.qdw + C - 1) / C;
   const int gpx = (ngroups + 7) / 8;
@@ -865,19 +848,19 @@ hipError_t launch_up_mr(const DevSector& s, const DevTiles& t, int lds_bytes, in
   const bool p16 = t.ell16 != nullptr;  // (the half-size in-block table exists)
   if constexpr (std::is_same<VT, double>::value) {  // real vectors exist for real H only
     if (p16)
-      kern = norb1 ? hxv_pass_up<C, true, true, LZ, true, MR, double> : hxv_pass_up<C, true, false, LZ, true, MR, double>;
+      kern = norb1 ? hxv_pass_up<C, true, true, LZ, true, double> : hxv_pass_up<C, true, false, LZ, true, double>;
     else
-      kern = norb1 ? hxv_pass_up<C, true, true, LZ, false, MR, double> : hxv_pass_up<C, true, false, LZ, false, MR, double>;
+      kern = norb1 ? hxv_pass_up<C, true, true, LZ, false, double> : hxv_pass_up<C, true, false, LZ, false, double>;
   } else if (s.real_h) {
     if (p16)
-      kern = norb1 ? hxv_pass_up<C, true, true, LZ, true, MR, double2> : hxv_pass_up<C, true, false, LZ, true, MR, double2>;
+      kern = norb1 ? hxv_pass_up<C, true, true, LZ, true, double2> : hxv_pass_up<C, true, false, LZ, true, double2>;
     else
-      kern = norb1 ? hxv_pass_up<C, true, true, LZ, false, MR, double2> : hxv_pass_up<C, true, false, LZ, false, MR, double2>;
+      kern = norb1 ? hxv_pass_up<C, true, true, LZ, false, double2> : hxv_pass_up<C, true, false, LZ, false, double2>;
   } else {
     if (p16)
-      kern = norb1 ? hxv_pass_up<C, false, true, LZ, true, MR, double2> : hxv_pass_up<C, false, false, LZ, true, MR, double2>;
+      kern = norb1 ? hxv_pass_up<C, false, true, LZ, true, double2> : hxv_pass_up<C, false, false, LZ, true, double2>;
     else
-      kern = norb1 ? hxv_pass_up<C, false, true, LZ, false, MR, double2> : hxv_pass_up<C, false, false, LZ, false, MR, double2>;
+      kern = norb1 ? hxv_pass_up<C, false, true, LZ, false, double2> : hxv_pass_up<C, false, false, LZ, false, double2>;
   }
   lds_bytes = std::max(lds_bytes, threads * 8);  // the epilogue reduces through LDS
   hipError_t e = allow_dynamic_lds((const void*)kern, lds_bytes);
@@ -886,19 +869,11 @@ hipError_t launch_up_mr(const DevSector& s, const DevTiles& t, int lds_bytes, in
   return hipGetLastError();
 }
 
-template <int C, bool LZ, typename VT>
-hipError_t launch_up_lz(const DevSector& s, const DevTiles& t, int max_block, int lds_bytes, int threads, bool norb1, int wc, const VT* v,
-                        const VT* wt, VT* hv, const LzEpilogue& lz, hipStream_t st) {
-  // one row per thread when every block fits the workgroup, else the multi-row walk
-  if (max_block > threads) return launch_up_mr<C, LZ, true, VT>(s, t, lds_bytes, threads, norb1, wc, v, wt, hv, lz, st);
-  return launch_up_mr<C, LZ, false, VT>(s, t, lds_bytes, threads, norb1, wc, v, wt, hv, lz, st);
-}
-
 template <int C, typename VT>
-hipError_t launch_up(const DevSector& s, const DevTiles& t, int max_block, int lds_bytes, int threads, bool norb1, int wc, const VT* v,
+hipError_t launch_up(const DevSector& s, const DevTiles& t, int lds_bytes, int threads, bool norb1, int wc, const VT* v,
                      const VT* wt, VT* hv, const LzEpilogue* lz, hipStream_t st) {
-  if (lz) return launch_up_lz<C, true, VT>(s, t, max_block, lds_bytes, threads, norb1, wc, v, wt, hv, *lz, st);
-  return launch_up_lz<C, false, VT>(s, t, max_block, lds_bytes, threads, norb1, wc, v, wt, hv, LzEpilogue(), st);
+  if (lz) return launch_up_lz<C, true, VT>(s, t, lds_bytes, threads, norb1, wc, v, wt, hv, *lz, st);
+  return launch_up_lz<C, false, VT>(s, t, lds_bytes, threads, norb1, wc, v, wt, hv, LzEpilogue(), st);
 }
 
 template <int R, int NP, typename VT>
@@ -945,7 +920,7 @@ std::vector<double2> signed_coefs(const SpinOp& op) {
 
 std::string make_tile_plan(const SectorHost& s, TilePlan& plan, const PlanUploader& up) {
   TileOptions& o = plan.opt;
-  if (o.cols_per_tile != 1 && o.cols_per_tile != 2 && o.cols_per_tile != 4 && o.cols_per_tile != 8) return "cols_per_tile must be 1, 2, 4 or 8";
+  if (o.cols_per_tile != 2 && o.cols_per_tile != 4 && o.cols_per_tile != 8) return "cols_per_tile must be 2, 4 or 8";
   // Large sectors (Ns=18): two neighbouring 4-row panels of DimDw columns are 128 B x DimDw = 6 MB of lines, more than an XCD's
   // L2, and nearly every out-of-block gather of pass B then leaves the XCD: eight rows per tile (whole lines; smaller blocks
   // to stay within the LDS budget) measured 40.8 ms against 47.4 ms per pass B there (Ns=16: 2.25 against 2.22 ms).
@@ -986,9 +961,8 @@ std::string make_tile_plan(const SectorHost& s, TilePlan& plan, const PlanUpload
     return "";
   };
   static const std::vector<uint32_t> no_map;  // panel handles have no up basis: plain index chunks (pass A never runs)
-  if (o.rows_per_thread_up < 1 || o.rows_per_thread_up > 8) return "rows_per_thread_up must be in [1,8]";
-  std::string e = one(s.up, s.panel_rows > 0 ? no_map : s.map_up, s.nup, o.cols_per_tile, o.force_bits_up, o.lds_budget_kb_up,
-                      o.threads_up * o.rows_per_thread_up, nullptr, true, 0, plan.up);
+  std::string e = one(s.up, s.panel_rows > 0 ? no_map : s.map_up, s.nup, o.cols_per_tile, o.force_bits_up, o.lds_budget_kb_up, o.threads_up, nullptr, true, 0,
+                      plan.up);
   if (!e.empty()) return e;
   // pass B sorts by the inner count only: its outer table is read in natural column order
   e = one(s.dw, s.map_dw, s.ndw, o.rows_per_tile, o.force_bits_dw, o.lds_budget_kb_dw, o.threads_dw, &s.vcol, false,
@@ -1079,12 +1053,11 @@ static hipError_t launch_tiled_vt(const DevSector& s, const TilePlan& plan, cons
     if (job_a) return launch_up_job(s, plan, tu, wc, v, wta, hv, lz, st);
   }
   if (passes & 1) switch (C) {
-      case 1: e = launch_up<1, VT>(s, tu, plan.up.max_block, lds_a, ta, norb1, wc, v, wta, hv, lz, st); break;
-      case 2: e = launch_up<2, VT>(s, tu, plan.up.max_block, lds_a, ta, norb1, wc, v, wta, hv, lz, st); break;
-      case 4: e = launch_up<4, VT>(s, tu, plan.up.max_block, lds_a, ta, norb1, wc, v, wta, hv, lz, st); break;
+      case 2: e = launch_up<2, VT>(s, tu, lds_a, ta, norb1, wc, v, wta, hv, lz, st); break;
+      case 4: e = launch_up<4, VT>(s, tu, lds_a, ta, norb1, wc, v, wta, hv, lz, st); break;
       default:
         if constexpr (RV)
-          e = launch_up<8, VT>(s, tu, plan.up.max_block, lds_a, ta, norb1, wc, v, wta, hv, lz, st);
+          e = launch_up<8, VT>(s, tu, lds_a, ta, norb1, wc, v, wta, hv, lz, st);
         else
           e = hipErrorInvalidValue;  // (cplx_cols)
         break;

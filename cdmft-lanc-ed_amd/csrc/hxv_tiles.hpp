@@ -65,8 +65,6 @@ struct TileOptions {
   int lds_budget_kb_dw = 64;  // LDS per workgroup tile, pass B (two 1024-thread workgroups per CU)
   int force_bits_up = -1, force_bits_dw = -1;
   int threads_up = 1024, threads_dw = 1024;
-  int rows_per_thread_up = 1;  // pass A: a block may hold up to threads_up * rows_per_thread_up rows (1..8); > 1 = larger prefix blocks,
-                               // or the same blocks on smaller workgroups (more workgroups per CU)
   int sort_mode = 0;  // pass A visiting order: 0 natural (keeps global accesses coalesced), 1 by inner count, 2 by (outer, inner)
   int sort_mode_dw = 1;  // pass B inner phase (LDS only): 0 natural, 1 by inner count
   int lds_min_kb_up = 0, lds_min_kb_dw = 0;  // request at least this much LDS per workgroup (limits workgroups per CU)
