@@ -7,8 +7,10 @@
 A "step" = one full product Hv = H v of the BASELINE C3 sector (cdn_hm_2dsquare: 2x2 cluster +
 3 replica baths, Ns=16, sector (8,8), Dim = 165 636 900, complex fp64), vectors resident in HBM.
 With N>1 ranks the sector is split along DimDw exactly like the reference (ED_HAMILTONIAN.f90:93-105):
-each step all-gathers the N slabs over RCCL and every rank computes its slab (strong scaling: the
-sector is fixed).  value = algorithmic GB/s of the whole job = 32 B x Dim / step time
+each step exchanges the slabs over RCCL THROUGH THE C-ABI (hxv_comm_unique_id -> broadcast -> hxv_comm_init ->
+hxv_apply_device_slab: what a Fortran rank of the reference would run; --exchange allgather [default] | halo) and every
+rank computes its slab (strong scaling: the sector is fixed).  --exchange alltoall and --backend gloo go through
+torch.distributed instead (hxv/distributed.py).  value = algorithmic GB/s of the whole job = 32 B x Dim / step time
 (read v once + write Hv once per basis state).
 
 Rank 0 prints ONE JSON line.  It also carries
@@ -28,7 +30,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT / "cdmft-lanc-ed_amd"))
 sys.path.insert(0, str(ROOT))
 
-KERNELS_STAMP = "r02-tileF"   # bumped whenever the product kernels change: profiles/traffic.json is quoted only for the same stamp
+KERNELS_STAMP = "r03-rs16"   # bumped whenever the product kernels change: profiles/traffic.json is quoted only for the same stamp
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
@@ -61,6 +63,51 @@ def cpu_baseline(model, nup, ndw, budget_s=25.0):
                       f"matrix build {build_s:.1f}s untimed)", "s_per_matvec": dt}
 
 
+def copy_rate_gbs(dev, nbytes=1 << 30, reps=5):
+    """Measured copy rate of this box (read + written bytes per second of a plain device copy): the yardstick of the two-pass
+    design's own floor (80 B per basis state)."""
+    import torch
+
+    x = torch.empty(nbytes // 8, dtype=torch.float64, device=dev).normal_()
+    y = torch.empty_like(x)
+    y.copy_(x)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        y.copy_(x)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+def time_other_workload(name, dev, reps):
+    """One of the other full-size BASELINE configs on this GPU: mean ms per product (HIP events on the launch stream)."""
+    import torch
+    import hxv
+    from hxv import models
+
+    model, (nup, ndw) = {"C4": (models.bhz_2d(Nbath=1), (8, 8)), "C5": (models.hm_ring(6, 2), (9, 9))}[name]
+    sec = hxv.HxvSector.from_model(model, nup, ndw, device=dev.index or 0)
+    n = sec.fullElems
+    v = torch.empty(n, dtype=torch.complex128, device=dev)
+    vr = torch.view_as_real(v).view(-1)
+    g = torch.Generator(device=dev).manual_seed(7)
+    for a in range(0, 2 * n, 1 << 28):   # (chunks: torch.randn on 75 GB at once would need a second buffer of that size)
+        b = min(a + (1 << 28), 2 * n)
+        vr[a:b] = torch.randn(b - a, dtype=torch.float64, device=dev, generator=g)
+    hv = torch.empty(sec.localElems, dtype=torch.complex128, device=dev)
+    sec.time_apply(v, hv, 1)
+    ms = sec.time_apply(v, hv, reps)
+    out = {"workload": f"{name}: {model.name} sector ({nup},{ndw}) Dim={sec.Dim}", "ms_per_product": round(ms, 4),
+           "achieved_GBs": round(32.0 * sec.Dim / (ms * 1e-3) / 1e9, 1), "frac": round(32.0 * sec.Dim / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    sec.close()
+    del v, hv, vr
+    torch.cuda.empty_cache()
+    hxv.pool_trim(dev.index or 0)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,6 +116,7 @@ def main():
     ap.add_argument("--workload", default="C3", choices=["C2", "C3", "C4", "C5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lanczos", action="store_true", help="skip the Lanczos-iteration timing (N=1; second half of BASELINE's metric)")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the C4 / C5 product timings reported in config.other_workloads (N=1)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 path on one GPU)")
     ap.add_argument("--exchange", default="allgather", choices=["allgather", "alltoall", "halo"],
                     help="N>1: allgather = one RCCL all-gather per product (BASELINE's mandated exchange, default); "
@@ -125,7 +173,20 @@ def main():
     v_local = torch.randn(Nloc, dtype=torch.float64, device=dev, generator=g) + 1j * torch.randn(Nloc, dtype=torch.float64, device=dev, generator=g)
     hv_local = torch.empty(Nloc, dtype=torch.complex128, device=dev)
     hxv.set_exchange_default("allgather")
+    if halo and sec.exchange_mode != "halo":
+        # (e.g. the spH0nd block keeps the all-gather layout): never feed halo-layout vectors to an all-gather handle
+        if rank == 0:
+            print("bench.py: the sector was opened in all-gather layout; --exchange halo falls back to allgather", file=sys.stderr)
+        halo = False
+        args.exchange = "allgather"
     sh = hxv.ShardedHxv(sec.DimUp, sec.DimDw, 0 if by_sector else rank, 1 if by_sector else world, sec.apply_device, pitch=sec.pitch)
+    # N>1 on RCCL: the exchange runs behind the C-ABI, exactly what a Fortran rank of the reference would call
+    # (hxv_comm_unique_id on rank 0 -> the host program's own broadcast -> hxv_comm_init -> hxv_apply_device_slab)
+    capi_exchange = world > 1 and not by_sector and args.backend == "nccl" and args.exchange in ("allgather", "halo")
+    if capi_exchange:
+        ident = [hxv.HxvSector.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ident, src=0)
+        sec.comm_init(ident[0])
     hx = None
     if halo:
         rp, cols, _ = sec.csr("dw")
@@ -138,7 +199,9 @@ def main():
                                pitch_panel=panel.pitch, stage_on_host=(args.backend != "nccl"))
 
     def step():
-        if world > 1 and args.exchange == "alltoall" and not by_sector:
+        if capi_exchange:
+            sec.apply_device_slab(v_local, hv_local)
+        elif world > 1 and args.exchange == "alltoall" and not by_sector:
             th(Nloc, v_local, hv_local)
         elif halo:
             hx(Nloc, v_local, hv_local)
@@ -193,7 +256,11 @@ def main():
                 traffic_src = f"profiles/traffic.json (rocprofv3 --pmc, kernels {KERNELS_STAMP})"
         except Exception:
             traffic = None
+    # the two-pass design's own floor: 80 B per basis state (pass B 32, pass A 48) at the copy rate this box measures
+    copy_gbs = copy_rate_gbs(dev)
+    floor_ms = 80.0 * sec.vecDim / (copy_gbs * 1e9) * 1e3
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "design_floor_ms": round(floor_ms, 4), "frac_of_design_floor": round(floor_ms / k_ms, 4), "copy_rate_GBs": round(copy_gbs, 1),
                 "traffic": traffic, "traffic_source": traffic_src, "kernel": ("hxv_up_job" if sec.get_option("job_up_active") else "hxv_pass_up") + " + hxv_pass_dw (one product)", "kernel_ms": round(k_ms, 4),
                 "algorithmic_bytes": 32 * sec.vecDim}
 
@@ -229,9 +296,37 @@ def main():
             lzr_ms = sec.time_lanczos(20)
             out["config"]["lanczos_real_vectors_ms_per_iter"] = round(lzr_ms, 4)
             out["config"]["lanczos_real_vectors_matvecs_per_s"] = round(1e3 / lzr_ms, 2)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        if sec.real_vectors_available:
+            # two real tridiagonalisations per complex product (hxv_lanczos_tridiag_pair: two Green's-function channels at once)
+            va = torch.zeros(sec.localElems, dtype=torch.complex128, device=dev)
+            vb = torch.zeros_like(va)
+            for w in (va, vb):
+                x = torch.randn(sec.DimDw, sec.DimUp, dtype=torch.float64, device=dev, generator=g)
+                torch.view_as_real(w).view(sec.DimDw, sec.pitch, 2)[:, : sec.DimUp, 0] = x / x.norm()
+            def wall(n):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                sec.lanczos_tridiag_pair(va, vb, n)
+                torch.cuda.synchronize()
+                return time.perf_counter() - t0
+            wall(3)
+            t_short, t_long = wall(4), wall(24)
+            pair_ms = (t_long - t_short) / 20 * 1e3
+            out["config"]["lanczos_paired_real_ms_per_iter"] = round(pair_ms, 4)           # one iteration of BOTH channels
+            out["config"]["lanczos_paired_real_ms_per_iter_per_channel"] = round(pair_ms / 2, 4)
+            out["config"]["lanczos_paired_real_matvecs_per_s"] = round(2e3 / pair_ms, 2)
+            del va, vb
+    if world == 1 and args.workload == "C3" and not args.no_other_workloads:
+        # the other full-size configs, driver-timed on the same GPU (parity-test sizes of BASELINE.json, not the headline)
         sec.close()
         del vfull, v_local, hv_local, sh
+        torch.cuda.empty_cache()
+        hxv.pool_trim(local_rank)
+        out["config"]["other_workloads"] = {w: time_other_workload(w, dev, 10 if w == "C4" else 3) for w in ("C4", "C5")}
+        vfull = v_local = hv_local = sh = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sec.close()
+        vfull = v_local = hv_local = sh = None
         torch.cuda.empty_cache()
         try:
             out["cpu_baseline"] = cpu_baseline(model, nup, ndw)

@@ -48,10 +48,16 @@ __global__ void __launch_bounds__(256) lz_sub_nrm(int64_t n, double2* __restrict
   double acc = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     double2 x = w[i], y = q[i];
-    x.x -= a * y.x;
-    x.y -= a * y.y;
+    // (written out -- one fused multiply-add per component, the squares rounded before they are added -- so that the paired
+    //  kernel below reproduces two runs of this one bit for bit)
+    x.x = fma(-a, y.x, x.x);
+    x.y = fma(-a, y.y, x.y);
     w[i] = x;
-    acc += x.x * x.x + x.y * x.y;
+    {
+#pragma clang fp contract(off)  // (the _rn intrinsics of HIP are plain operators, open to contraction)
+      const double t = x.x * x.x;
+      acc = acc + fma(x.y, x.y, t);
+    }
   }
   __shared__ double red[256];
   red[threadIdx.x] = acc;
@@ -63,12 +69,85 @@ __global__ void __launch_bounds__(256) lz_sub_nrm(int64_t n, double2* __restrict
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
+// PAIRED vectors (real part = vector a, imaginary part = vector b): w.re -= a_a*q.re, w.im -= a_b*q.im; partial sums of
+// |w.re|^2 and |w.im|^2 separately
+__global__ void __launch_bounds__(256) lz_sub_nrm_pair(int64_t n, double2* __restrict__ w, const double2* __restrict__ q,
+                                                       const double* __restrict__ scal, int ia, int ib, double* __restrict__ partial_a,
+                                                       double* __restrict__ partial_b) {
+  const double a = scal[ia], b = scal[ib];
+  double acc = 0.0, acc2 = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double2 x = w[i], y = q[i];
+    x.x = fma(-a, y.x, x.x);
+    x.y = fma(-b, y.y, x.y);
+    w[i] = x;
+    {
+#pragma clang fp contract(off)
+      const double t = x.x * x.x, t2 = x.y * x.y;
+      acc = acc + t;
+      acc2 = acc2 + t2;
+    }
+  }
+  __shared__ double red[256], red2[256];
+  red[threadIdx.x] = acc;
+  red2[threadIdx.x] = acc2;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      red[threadIdx.x] += red[threadIdx.x + s];
+      red2[threadIdx.x] += red2[threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    partial_a[blockIdx.x] = red[0];
+    partial_b[blockIdx.x] = red2[0];
+  }
+}
+
+// q = (Re a, Re b) from two complex vectors; partial sums of Im(a)^2 + Im(b)^2 (must be zero), |Re a|^2, |Re b|^2
+__global__ void __launch_bounds__(256) lz_pack_pair(int64_t n, const double2* __restrict__ a, const double2* __restrict__ b,
+                                                    double2* __restrict__ q, double* __restrict__ p_im, double* __restrict__ p_a,
+                                                    double* __restrict__ p_b) {
+  double im = 0.0, na = 0.0, nb = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double2 x = a[i], y = b[i];
+    q[i] = make_double2(x.x, y.x);
+    im += x.y * x.y + y.y * y.y;
+    {
+#pragma clang fp contract(off)
+      const double t = x.x * x.x, t2 = y.x * y.x;
+      na = na + t;
+      nb = nb + t2;
+    }
+  }
+  __shared__ double red[3][256];
+  red[0][threadIdx.x] = im;
+  red[1][threadIdx.x] = na;
+  red[2][threadIdx.x] = nb;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s)
+      for (int k = 0; k < 3; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    p_im[blockIdx.x] = red[0][0];
+    p_a[blockIdx.x] = red[1][0];
+    p_b[blockIdx.x] = red[2][0];
+  }
+}
+
 // partial sums of |x|^2
 __global__ void __launch_bounds__(256) lz_nrm(int64_t n, const double2* __restrict__ x, double* __restrict__ partial) {
   double acc = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     double2 a = x[i];
-    acc += a.x * a.x + a.y * a.y;
+    {
+#pragma clang fp contract(off)  // (written out: see lz_sub_nrm)
+      const double t = a.x * a.x;
+      acc = acc + fma(a.y, a.y, t);
+    }
   }
   __shared__ double red[256];
   red[threadIdx.x] = acc;
@@ -793,6 +872,126 @@ int hxv_lanczos_eigh(hxv_handle* h, int32_t nitermax, double threshold, double* 
   return HXV_OK;
 }
 
+// Two REAL Lanczos runs on one complex product (real H): the start vectors travel as real and imaginary part of one
+// complex vector -- H(x + i y) = H x + i H y -- and every scalar of the recurrence exists once per component.  The channels of
+// one Green's-function solve are independent (ED_GF_NORMAL.f90:123-306: one sp_lanc_tridiag per channel), so two of them share
+// the product's passes.  The arithmetic of each component is, operation for operation, that of hxv_lanczos_tridiag on (x, 0)
+// through the same kernels (options real_vectors = 0, job_up = 0): alanc/blanc are bit-identical to two such runs.
+int hxv_lanczos_tridiag_pair(hxv_handle* h, const void* d_vin_a, const void* d_vin_b, int32_t nlanc, double* alanc_a, double* blanc_a,
+                             double* alanc_b, double* blanc_b, double threshold, int32_t* nsteps_a, int32_t* nsteps_b) {
+  if (!h || !d_vin_a || !d_vin_b || nlanc < 1 || !alanc_a || !blanc_a || !alanc_b || !blanc_b)
+    return fail(HXV_ERR_ARG, "hxv_lanczos_tridiag_pair: bad argument");
+  if (const char* why = real_mode_blocker(h)) return fail(HXV_ERR_UNSUPPORTED, std::string("hxv_lanczos_tridiag_pair: unavailable: ") + why);
+  if (!h->lz_fused) return fail(HXV_ERR_UNSUPPORTED, "hxv_lanczos_tridiag_pair needs the fused recurrence (option lanczos_fused)");
+  if (std::min(4, h->plan.opt.cols_per_tile) > 4) return fail(HXV_ERR_UNSUPPORTED, "hxv_lanczos_tridiag_pair: tile shape");
+  HIPCHK(hipSetDevice(h->device));
+  int rc = ensure_lz(h, false);
+  if (rc) return rc;
+  rc = ensure_wt(h);
+  if (rc) return rc;
+  const int64_t n = (int64_t)h->host.pitch * h->host.qdw;
+  const int g = grid_for(n);
+  const int64_t nwg = tiled_pass_up_workgroups(h->dev, h->plan, false, true);
+  if (2 * nwg > h->lz_partial_n) {
+    if (h->d_lz_partial) (void)hipFree(h->d_lz_partial);
+    h->d_lz_partial = nullptr;
+    h->lz_partial_n = 0;
+    HIPCHK(hipMalloc((void**)&h->d_lz_partial, (size_t)2 * nwg * sizeof(double)));
+    h->lz_partial_n = 2 * nwg;
+  }
+  // scalars: [0] alpha_a [1] beta_a [2] s_a [3] c_a [4] alpha_a*s_a ; [8..12] the same for b ; block partials behind them
+  double* d_sc = nullptr;
+  HIPCHK(hipMalloc((void**)&d_sc, (size_t)(16 + 3 * RED_BLOCKS) * sizeof(double)));
+  struct Free {
+    double* p;
+    ~Free() { (void)hipFree(p); }
+  } guard{d_sc};
+  double* d_p0 = d_sc + 16;
+  double* d_p1 = d_p0 + RED_BLOCKS;
+  double* d_p2 = d_p1 + RED_BLOCKS;
+  HIPCHK(hipMemsetAsync(d_sc, 0, 16 * sizeof(double), h->stream));
+  double2 *q = h->d_lz[0], *qm = h->d_lz[1], *w = h->d_lz[2];
+  hipLaunchKernelGGL(lz_pack_pair, dim3(g), dim3(256), 0, h->stream, n, (const double2*)d_vin_a, (const double2*)d_vin_b, q, d_p0, d_p1, d_p2);
+  hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, d_p0, g, d_sc, 5, 0);
+  hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, d_p1, g, d_sc, 6, 1);
+  hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, d_p2, g, d_sc, 7, 1);
+  double head[3];
+  HIPCHK(hipMemcpyAsync(head, d_sc + 5, 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (head[0] != 0.0) return fail(HXV_ERR_ARG, "hxv_lanczos_tridiag_pair: the start vectors must be real (zero imaginary parts)");
+  for (int c = 0; c < 2; ++c)
+    if (!(head[1 + c] > 0.0) || !std::isfinite(head[1 + c])) return fail(HXV_ERR_ARG, "hxv_lanczos_tridiag_pair: a start vector is zero or not finite");
+  for (int k = 0; k < nlanc; ++k) alanc_a[k] = blanc_a[k] = alanc_b[k] = blanc_b[k] = 0.0;
+  // per component, exactly LzRunner's fused recurrence: q = s*X, s = 1/beta_k (the start vector's norm carried as beta_0)
+  double s_cur[2], beta_prev[2];
+  bool alive[2] = {true, true};
+  int done[2] = {0, 0};
+  for (int c = 0; c < 2; ++c) {
+    const double nrm = std::fabs(head[1 + c] - 1.0) <= 1e-14 ? 1.0 : head[1 + c];
+    s_cur[c] = 1.0 / nrm;
+    beta_prev[c] = nrm;
+  }
+  double* al[2] = {alanc_a, alanc_b};
+  double* bl[2] = {blanc_a, blanc_b};
+  bool first = true;
+  for (int k = 0; k < nlanc && (alive[0] || alive[1]); ++k) {
+    double sc[16] = {0};
+    for (int c = 0; c < 2; ++c) {
+      sc[8 * c + 2] = alive[c] ? s_cur[c] : 0.0;  // (a finished component is multiplied away: the other one goes on alone)
+      sc[8 * c + 3] = (first || !alive[c]) ? 0.0 : 1.0 / (s_cur[c] * beta_prev[c]);
+    }
+    HIPCHK(hipMemcpyAsync(d_sc + 2, sc + 2, 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(d_sc + 10, sc + 10, 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    LzEpilogue ep;
+    ep.xm = first ? nullptr : qm;
+    ep.scal = d_sc;
+    ep.i_s = 2;
+    ep.i_c = 3;
+    ep.pair = 1;
+    ep.i_s2 = 10;
+    ep.i_c2 = 11;
+    ep.partial = h->d_lz_partial;
+    ep.partial2 = h->d_lz_partial + nwg;
+    hipError_t e = launch_hxv_tiled(h->dev, h->plan, q, h->d_wt, w, h->stream, &ep);
+    if (e != hipSuccess) return fail(HXV_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    h->n_apply++;
+    hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_lz_partial, (int)nwg, d_sc, 0, 0);
+    hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_lz_partial + nwg, (int)nwg, d_sc, 8, 0);
+    hipLaunchKernelGGL(lz_mul, dim3(1), dim3(1), 0, h->stream, d_sc, 4, 0, 2);
+    hipLaunchKernelGGL(lz_mul, dim3(1), dim3(1), 0, h->stream, d_sc, 12, 8, 10);
+    hipLaunchKernelGGL(lz_sub_nrm_pair, dim3(g), dim3(256), 0, h->stream, n, w, q, d_sc, 4, 12, d_p0, d_p1);
+    hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, d_p0, g, d_sc, 1, 1);
+    hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, d_p1, g, d_sc, 9, 1);
+    double host[16];
+    HIPCHK(hipMemcpyAsync(host, d_sc, 16 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int c = 0; c < 2; ++c) {
+      if (!alive[c]) continue;
+      const double a = host[8 * c], bt = host[8 * c + 1];
+      al[c][k] = a;
+      if (k + 1 < nlanc) bl[c][k + 1] = bt;
+      done[c] = k + 1;
+      if (std::fabs(bt) < threshold || !std::isfinite(bt)) {
+        alive[c] = false;  // breakdown of this component's Krylov space (the early exit of hxv_lanczos_tridiag)
+        continue;
+      }
+      beta_prev[c] = 1.0 / s_cur[c];
+      s_cur[c] = 1.0 / bt;
+    }
+    // rotate: X_{k+1} = w (unnormalised residual), X_k = q, the old X_{k-1} becomes the next output
+    double2* old_m = qm;
+    qm = q;
+    q = w;
+    w = old_m;
+    first = false;
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->last_real = 2;
+  if (nsteps_a) *nsteps_a = done[0];
+  if (nsteps_b) *nsteps_b = done[1];
+  return HXV_OK;
+}
+
 namespace {
 int ensure_stage(hxv_handle* h) {
   const size_t bytes = (size_t)h->host.pitch * std::max(h->host.qdw, 1) * sizeof(double2);
@@ -818,6 +1017,21 @@ int hxv_lanczos_tridiag_host(hxv_handle* h, const void* vin_host, int32_t nlanc,
     HIPCHK(hipMemcpy2DAsync(h->d_stage_v, pit, vin_host, col, col, (size_t)h->host.qdw, hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return hxv_lanczos_tridiag(h, h->d_stage_v, nlanc, alanc, blanc, threshold, nsteps);
+}
+
+int hxv_lanczos_tridiag_pair_host(hxv_handle* h, const void* vin_a_host, const void* vin_b_host, int32_t nlanc, double* alanc_a,
+                                  double* blanc_a, double* alanc_b, double* blanc_b, double threshold, int32_t* nsteps_a, int32_t* nsteps_b) {
+  if (!h || !vin_a_host || !vin_b_host) return fail(HXV_ERR_ARG, "hxv_lanczos_tridiag_pair_host: NULL argument");
+  HIPCHK(hipSetDevice(h->device));
+  int rc = ensure_stage(h);
+  if (rc) return rc;
+  const size_t col = (size_t)h->host.dimup * sizeof(double2), pit = (size_t)h->host.pitch * sizeof(double2);
+  if (h->host.qdw > 0) {
+    HIPCHK(hipMemcpy2DAsync(h->d_stage_v, pit, vin_a_host, col, col, (size_t)h->host.qdw, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpy2DAsync(h->d_stage_hv, pit, vin_b_host, col, col, (size_t)h->host.qdw, hipMemcpyHostToDevice, h->stream));
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return hxv_lanczos_tridiag_pair(h, h->d_stage_v, h->d_stage_hv, nlanc, alanc_a, blanc_a, alanc_b, blanc_b, threshold, nsteps_a, nsteps_b);
 }
 
 int hxv_lanczos_eigh_host(hxv_handle* h, int32_t nitermax, double threshold, double* egs, void* vect_host, int32_t* niter) {

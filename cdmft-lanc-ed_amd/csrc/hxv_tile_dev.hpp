@@ -89,8 +89,27 @@ __device__ __forceinline__ void vadd(double2& a, double2 b) { a.x += b.x; a.y +=
 __device__ __forceinline__ void vadd(double& a, double b) { a += b; }
 __device__ __forceinline__ void vscale(double2& a, double c) { a.x *= c; a.y *= c; }
 __device__ __forceinline__ void vscale(double& a, double c) { a *= c; }
-__device__ __forceinline__ double vdot(double2 a, double2 b) { return a.x * b.x + a.y * b.y; }
-__device__ __forceinline__ double vdot(double a, double b) { return a * b; }
+// (written out: a.x*b.x rounded, then one fused multiply-add -- with a.y == 0 this is exactly the paired epilogue's a.x*b.x)
+__device__ __forceinline__ double mul_rounded(double a, double b) {
+#pragma clang fp contract(off)  // (never fused into a neighbouring add; the _rn intrinsics of HIP are plain operators)
+  const double t = a * b;
+  return t;
+}
+__device__ __forceinline__ double vdot(double2 a, double2 b) { return ::fma(a.y, b.y, mul_rounded(a.x, b.x)); }
+__device__ __forceinline__ double vdot(double a, double b) { return mul_rounded(a, b); }
+
+// paired Lanczos epilogue: the two components of a complex element are two independent real vectors
+__device__ __forceinline__ void pair_scale(double2& a, double c, double c2) { a.x *= c; a.y *= c2; }
+__device__ __forceinline__ void pair_scale(double&, double, double) {}
+__device__ __forceinline__ void pair_fma(double2& acc, double c, double c2, double2 x) {
+  acc.x = ::fma(c, x.x, acc.x);
+  acc.y = ::fma(c2, x.y, acc.y);
+}
+__device__ __forceinline__ void pair_fma(double&, double, double, double) {}
+__device__ __forceinline__ double pair_dot_re(double2 a, double2 b) { return mul_rounded(a.x, b.x); }
+__device__ __forceinline__ double pair_dot_im(double2 a, double2 b) { return mul_rounded(a.y, b.y); }
+__device__ __forceinline__ double pair_dot_re(double a, double b) { return mul_rounded(a, b); }
+__device__ __forceinline__ double pair_dot_im(double, double) { return 0.0; }
 
 template <bool REAL>
 struct Coef;

@@ -23,7 +23,9 @@ namespace hxv {
 // ---------------------------------------------------------------------------------------
 // (Round 3 also ran this kernel with several rows per thread -- blocks of 13-14 low orbitals, or 512-thread workgroups on blocks of
 //  12 -- and every such plan was slower at C3, C4 and C5 (profiles/r03_ab_mr_*.log): one row per thread it stays.)
-template <int C, bool REAL, bool NORB1, bool LZ, bool P16, typename VT>
+// LZ: 0 plain product, 1 Lanczos epilogue, 2 PAIRED Lanczos epilogue (real H, complex vectors): the real and the imaginary part
+// are two independent real Lanczos vectors (H(x + iy) = Hx + iHy), each with its own scalars and its own partial sums.
+template <int C, bool REAL, bool NORB1, int LZ, bool P16, typename VT>
 __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, const VT* __restrict__ v,
                                                       const VT* __restrict__ wt, VT* __restrict__ hv, int ngroups,
                                                       int groups_per_xcd, int wc, LzEpilogue lz) {
@@ -38,7 +40,10 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
   const int g = xcd * groups_per_xcd + gl;
   int kb = j - gl * t.nblocks;
   if (gl >= groups_per_xcd || g >= ngroups) {
-    if (LZ && threadIdx.x == 0) lz.partial[blockIdx.x] = 0.0;
+    if (LZ && threadIdx.x == 0) {
+      lz.partial[blockIdx.x] = 0.0;
+      if (LZ == 2) lz.partial2[blockIdx.x] = 0.0;
+    }
     return;
   }
   if (t.order) kb = (int)t.order[kb];  // blocks that share their in-block tables are dispatched next to each other
@@ -185,18 +190,28 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
   }
   // Epilogue, same thread <-> row mapping: store hv with lanes along the rows.
   // With LZ: w = s*(H x) - c*xm and the partial sums of Re(conj(s*x) w).
+  double asum2 = 0.0;  // (LZ == 2: the imaginary-part vector's sum)
   if (p < n) {
     const double sc = LZ ? lz.scal[lz.i_s] : 1.0;
     const double cm = (LZ && lz.xm) ? lz.scal[lz.i_c] : 0.0;
+    const double sc2 = LZ == 2 ? lz.scal[lz.i_s2] : 1.0;
+    const double cm2 = (LZ == 2 && lz.xm) ? lz.scal[lz.i_c2] : 0.0;
 #pragma unroll
     for (int cc = 0; cc < C; ++cc) {
       if (cc < nc) {
         const int64_t o = (int64_t)(c0 + cc) * s.pitch + r0 + p;
         VT w = acc[cc];
-        if (LZ) {
+        if constexpr (LZ == 2) {
+          // component-wise: the same operations, in the same order, as two LZ == 1 runs on (x, 0) and (y, 0)
+          const VT xo = xq[cc];
+          pair_scale(w, sc, sc2);
+          if (lz.xm) pair_fma(w, -cm, -cm2, reinterpret_cast<const VT*>(lz.xm)[o]);
+          asum = ::fma(sc, pair_dot_re(xo, w), asum);
+          asum2 = ::fma(sc2, pair_dot_im(xo, w), asum2);
+        } else if (LZ) {
           vscale(w, sc);
           if (lz.xm) Coef<true>::fma(w, -cm, reinterpret_cast<const VT*>(lz.xm)[o]);
-          asum += sc * vdot(xq[LZ ? cc : 0], w);
+          asum = ::fma(sc, vdot(xq[LZ ? cc : 0], w), asum);
         }
         if (t.debug & 8)
           hv[o] = w;
@@ -208,15 +223,25 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
   if (LZ) {
     // wavefront partial sums first (shuffles), one LDS word per wave afterwards: two barriers instead of a tree of eleven
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) asum += __shfl_down(asum, off, 64);
+    for (int off = 32; off > 0; off >>= 1) {
+      asum += __shfl_down(asum, off, 64);
+      if (LZ == 2) asum2 += __shfl_down(asum2, off, 64);
+    }
     __syncthreads();  // every gather from the tile is done
     double* red = reinterpret_cast<double*>(lds);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = asum;
+    if ((threadIdx.x & 63) == 0) {
+      red[threadIdx.x >> 6] = asum;
+      if (LZ == 2) red[16 + (threadIdx.x >> 6)] = asum2;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
-      double tot = 0.0;
-      for (int w = 0; w < (T >> 6); ++w) tot += red[w];
+      double tot = 0.0, tot2 = 0.0;
+      for (int w = 0; w < (T >> 6); ++w) {
+        tot += red[w];
+        if (LZ == 2) tot2 += red[16 + w];
+      }
       lz.partial[blockIdx.x] = tot;
+      if (LZ == 2) lz.partial2[blockIdx.x] = tot2;
     }
   }
 }
@@ -838,15 +863,26 @@ hipError_t allow_dynamic_lds(const void* kern, int bytes) {
   return e;
 }
 
-template <int C, bool LZ, typename VT>
+template <int C, int LZ, typename VT>
 hipError_t launch_up_lz(const DevSector& s, const DevTiles& t, int lds_bytes, int threads, bool norb1, int wc, const VT* v,
                         const VT* wt, VT* hv, const LzEpilogue& lz, hipStream_t st) {
   const int ngroups = (s.qdw + C - 1) / C;
   const int gpx = (ngroups + 7) / 8;
   const int64_t nwg = (int64_t)gpx * 8 * t.nblocks;
-  void (*kern)(DevSector, DevTiles, const VT*, const VT*, VT*, int, int, int, LzEpilogue);
+  void (*kern)(DevSector, DevTiles, const VT*, const VT*, VT*, int, int, int, LzEpilogue) = nullptr;
   const bool p16 = t.ell16 != nullptr;  // (the half-size in-block table exists)
-  if constexpr (std::is_same<VT, double>::value) {  // real vectors exist for real H only
+  if constexpr (LZ == 2) {
+    // paired epilogue: real H on complex vectors only
+    if constexpr (std::is_same<VT, double2>::value && C <= 4) {
+      if (!s.real_h) return hipErrorInvalidValue;
+      if (p16)
+        kern = norb1 ? hxv_pass_up<C, true, true, 2, true, double2> : hxv_pass_up<C, true, false, 2, true, double2>;
+      else
+        kern = norb1 ? hxv_pass_up<C, true, true, 2, false, double2> : hxv_pass_up<C, true, false, 2, false, double2>;
+    } else {
+      return hipErrorInvalidValue;
+    }
+  } else if constexpr (std::is_same<VT, double>::value) {  // real vectors exist for real H only
     if (p16)
       kern = norb1 ? hxv_pass_up<C, true, true, LZ, true, double> : hxv_pass_up<C, true, false, LZ, true, double>;
     else
@@ -862,7 +898,7 @@ hipError_t launch_up_lz(const DevSector& s, const DevTiles& t, int lds_bytes, in
     else
       kern = norb1 ? hxv_pass_up<C, false, true, LZ, false, double2> : hxv_pass_up<C, false, false, LZ, false, double2>;
   }
-  lds_bytes = std::max(lds_bytes, threads * 8);  // the epilogue reduces through LDS
+  lds_bytes = std::max(lds_bytes, 32 * 8);  // the epilogue reduces through LDS: 16 (+16 paired) doubles
   hipError_t e = allow_dynamic_lds((const void*)kern, lds_bytes);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(threads), (size_t)lds_bytes, st, s, t, v, wt, hv, ngroups, gpx, wc, lz);
@@ -872,8 +908,9 @@ hipError_t launch_up_lz(const DevSector& s, const DevTiles& t, int lds_bytes, in
 template <int C, typename VT>
 hipError_t launch_up(const DevSector& s, const DevTiles& t, int lds_bytes, int threads, bool norb1, int wc, const VT* v,
                      const VT* wt, VT* hv, const LzEpilogue* lz, hipStream_t st) {
-  if (lz) return launch_up_lz<C, true, VT>(s, t, lds_bytes, threads, norb1, wc, v, wt, hv, *lz, st);
-  return launch_up_lz<C, false, VT>(s, t, lds_bytes, threads, norb1, wc, v, wt, hv, LzEpilogue(), st);
+  if (lz && lz->pair) return launch_up_lz<C, 2, VT>(s, t, lds_bytes, threads, norb1, wc, v, wt, hv, *lz, st);
+  if (lz) return launch_up_lz<C, 1, VT>(s, t, lds_bytes, threads, norb1, wc, v, wt, hv, *lz, st);
+  return launch_up_lz<C, 0, VT>(s, t, lds_bytes, threads, norb1, wc, v, wt, hv, LzEpilogue(), st);
 }
 
 template <int R, int NP, typename VT>
@@ -1006,8 +1043,8 @@ static bool use_job_up(const DevSector& s, const TilePlan& plan, bool real_vec, 
   return true;
 }
 
-int64_t tiled_pass_up_workgroups(const DevSector& s, const TilePlan& plan, bool real_vec) {
-  if (use_job_up(s, plan, real_vec, true, false)) return job_up_workgroups(s, plan);
+int64_t tiled_pass_up_workgroups(const DevSector& s, const TilePlan& plan, bool real_vec, bool pair) {
+  if (!pair && use_job_up(s, plan, real_vec, true, false)) return job_up_workgroups(s, plan);  // (the paired epilogue runs on the tile kernel)
   const int C = real_vec ? real_cols(plan) : cplx_cols(plan);
   const int ngroups = (s.qdw + C - 1) / C;
   return (int64_t)((ngroups + 7) / 8) * 8 * plan.up.nblocks;
@@ -1036,7 +1073,7 @@ static hipError_t launch_tiled_vt(const DevSector& s, const TilePlan& plan, cons
   // (with the job kernels pass A's tile width no longer constrains the scratch layout)
   int wc = wt_natural ? 0 : (RV ? real_wc(plan) : std::max(C, plan.opt.wt_cols));
   bool job_a = false;
-  if constexpr (!RV) job_a = (passes & 1) && use_job_up(s, plan, false, lz != nullptr, wt_natural, &wc);
+  if constexpr (!RV) job_a = (passes & 1) && !(lz && lz->pair) && use_job_up(s, plan, false, lz != nullptr, wt_natural, &wc);
   const int lds_a = std::max(plan.up.max_block * C * (int)sizeof(VT) + tu.nscoef * 16, plan.opt.lds_min_kb_up * 1024);
   const int lds_b = std::max(plan.dw.max_block * R * (int)sizeof(VT) + ((td.nscoef * 16 + 255) & ~255), plan.opt.lds_min_kb_dw * 1024);
   const int ta = plan.opt.threads_up, tb = plan.opt.threads_dw;

@@ -99,9 +99,14 @@ struct LzEpilogue {
   const double* scal = nullptr;
   int i_s = 0, i_c = 0;
   double* partial = nullptr;    // one partial sum per workgroup of pass A
+  // PAIRED epilogue (real H, complex vectors): Re and Im are two independent real Lanczos vectors; the imaginary part has
+  // its own s = scal[i_s2], c = scal[i_c2] and its own partial sums
+  int pair = 0;
+  int i_s2 = 0, i_c2 = 0;
+  double* partial2 = nullptr;
 };
 // workgroups of pass A (= partial sums of the Lanczos epilogue) for the product launch_hxv_tiled would run with an epilogue
-int64_t tiled_pass_up_workgroups(const DevSector& s, const TilePlan& plan, bool real_vec = false);
+int64_t tiled_pass_up_workgroups(const DevSector& s, const TilePlan& plan, bool real_vec = false, bool pair = false);
 int64_t tiled_wt_elems(const DevSector& s, const TilePlan& plan);
 
 struct PlanUploader {

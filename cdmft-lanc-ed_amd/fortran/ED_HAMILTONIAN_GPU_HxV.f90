@@ -21,6 +21,7 @@ module ED_HAMILTONIAN_GPU_HXV
   public :: gpu_comm_init
   public :: gpu_lanc_tridiag_host
   public :: gpu_sp_lanc_tridiag
+  public :: gpu_sp_lanc_tridiag_pair
   public :: gpu_sp_lanc_eigh
   public :: gpu_sp_eigh
 
@@ -78,6 +79,16 @@ module ED_HAMILTONIAN_GPU_HXV
        real(c_double),value                 :: threshold
        integer(c_int32_t)                   :: nsteps
      end function hxv_lanczos_tridiag_host
+     integer(c_int) function hxv_lanczos_tridiag_pair_host(h,vin_a,vin_b,nlanc,alanc_a,blanc_a,alanc_b,blanc_b,threshold,nsteps_a,nsteps_b) &
+          bind(C,name="hxv_lanczos_tridiag_pair_host")
+       import :: c_int, c_int32_t, c_ptr, c_double, c_double_complex
+       type(c_ptr),value                    :: h
+       complex(c_double_complex),intent(in) :: vin_a(*),vin_b(*)
+       integer(c_int32_t),value             :: nlanc
+       real(c_double)                       :: alanc_a(*),blanc_a(*),alanc_b(*),blanc_b(*)
+       real(c_double),value                 :: threshold
+       integer(c_int32_t)                   :: nsteps_a,nsteps_b
+     end function hxv_lanczos_tridiag_pair_host
      integer(c_int) function hxv_lanczos_eigh_host(h,nitermax,threshold,egs,vect,niter) bind(C,name="hxv_lanczos_eigh_host")
        import :: c_int, c_int32_t, c_ptr, c_double, c_double_complex
        type(c_ptr),value                    :: h
@@ -270,6 +281,29 @@ contains
     ! split sector the norm is the global one)
     call check(hxv_lanczos_tridiag_host(handle,vin,int(size(alanc),c_int32_t),alanc,blanc,thr,nsteps),"gpu_sp_lanc_tridiag")
   end subroutine gpu_sp_lanc_tridiag_serial
+
+  !> TWO tridiagonalisations on one product (real H): two of the independent channels of lanc_build_gf_normal_*
+  !! (ED_GF_NORMAL.f90:123-306; one sp_lanc_tridiag each at :215,282,422,504,638,720,801,882) share the product's passes, their
+  !! real start vectors travelling as real and imaginary part of one complex Lanczos vector (H(x+iy) = Hx + iHy).  Same
+  !! argument meaning as sp_lanc_tridiag, once per channel; vin_a, vin_b must have zero imaginary parts.
+  subroutine gpu_sp_lanc_tridiag_pair(MatVec,vin_a,vin_b,alanc_a,blanc_a,alanc_b,blanc_b,threshold)
+    interface
+       subroutine MatVec(Nloc,v,Hv)
+         integer                    :: Nloc
+         complex(8),dimension(Nloc) :: v,Hv
+       end subroutine MatVec
+    end interface
+    complex(8),intent(inout)    :: vin_a(:),vin_b(:)
+    real(8),intent(inout)       :: alanc_a(:),blanc_a(:),alanc_b(:),blanc_b(:)
+    real(8),intent(in),optional :: threshold
+    real(8)                     :: thr
+    integer(c_int32_t)          :: na,nb
+    if(.not.c_associated(handle))stop "gpu_sp_lanc_tridiag_pair ERROR: Hsector NOT set"
+    if(size(alanc_a)/=size(alanc_b))stop "gpu_sp_lanc_tridiag_pair ERROR: the two channels need equally long alanc/blanc"
+    thr=1d-12; if(present(threshold))thr=threshold
+    call check(hxv_lanczos_tridiag_pair_host(handle,vin_a,vin_b,int(size(alanc_a),c_int32_t),alanc_a,blanc_a,alanc_b,blanc_b,thr,na,nb),&
+         "gpu_sp_lanc_tridiag_pair")
+  end subroutine gpu_sp_lanc_tridiag_pair
 
   subroutine gpu_sp_lanc_eigh_serial(MatVec,egs,vect,Nitermax,iverbose,threshold)
     interface

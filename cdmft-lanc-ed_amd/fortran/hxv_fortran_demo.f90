@@ -89,6 +89,19 @@ contains
     write(*,"(A,F16.10)")"C2 device tridiag E0=",lowest_tridiag(alanc,blanc)
     call gpu_sp_lanc_eigh(spHtimesV_p,e0,hv,512,threshold=1d-14)
     write(*,"(A,F16.10,A,ES12.4)")"C2 device eigh E0=",e0," |vec|^2-1=",dble(dot_product(hv,hv))-1d0
+    !two Green's-function-style channels on one product: real start vectors as Re / Im of one complex Lanczos vector
+    block
+      complex(8),allocatable :: va(:),vb(:)
+      real(8),allocatable    :: aa(:),ba(:),ab(:),bb(:)
+      allocate(va(dim),vb(dim),aa(size(alanc)),ba(size(alanc)),ab(size(alanc)),bb(size(alanc)))
+      va=cmplx(dble(v),0d0,8);   va=va/sqrt(dble(dot_product(va,va)))
+      vb=cmplx(aimag(v),0d0,8);  vb=vb/sqrt(dble(dot_product(vb,vb)))
+      call gpu_sp_lanc_tridiag_pair(spHtimesV_p,va,vb,aa,ba,ab,bb)
+      write(*,"(A,2F16.10)")"C2 device tridiag pair E0=",lowest_tridiag(aa,ba),lowest_tridiag(ab,bb)
+      call gpu_sp_lanc_tridiag(spHtimesV_p,va,alanc,blanc)
+      write(*,"(A,F16.10)")"C2 device tridiag channel a alone E0=",lowest_tridiag(alanc,blanc)
+      deallocate(va,vb,aa,ba,ab,bb)
+    end block
     !the default spectrum call of ED_DIAG.f90:152-160: sp_eigh(spHtimesV_p,eig_values,eig_basis,Nblock,Nitermax,tol=...)
     allocate(eig_values(2),eig_basis(dim,2))
     call gpu_sp_eigh(spHtimesV_p,eig_values,eig_basis,20,512,tol=1d-18)

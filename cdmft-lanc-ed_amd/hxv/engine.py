@@ -41,7 +41,7 @@ class _Stats(C.Structure):
 # every symbol include/hxv.h declares (tests check that the library exports all of them)
 EXPORTS = [
     "hxv_create_from_model", "hxv_create_from_csr", "hxv_create_dw_panel", "hxv_apply_dw_panel", "hxv_apply_up_add", "hxv_destroy", "hxv_vecdim", "hxv_dims", "hxv_apply_host",
-    "hxv_apply_device", "hxv_apply_device_real", "hxv_real_vectors_available", "hxv_pitch_real", "hxv_realvec_elems", "hxv_fullvec_elems", "hxv_localvec_elems", "hxv_pitch", "hxv_time_apply", "hxv_lanczos_tridiag", "hxv_lanczos_eigh", "hxv_lanczos_tridiag_host", "hxv_lanczos_eigh_host", "hxv_eigh_lowest", "hxv_eigh_lowest_host", "hxv_time_lanczos", "hxv_apply_ladder", "hxv_apply_ladder_axpy", "hxv_get_maps",
+    "hxv_apply_device", "hxv_apply_device_real", "hxv_real_vectors_available", "hxv_pitch_real", "hxv_realvec_elems", "hxv_fullvec_elems", "hxv_localvec_elems", "hxv_pitch", "hxv_time_apply", "hxv_lanczos_tridiag", "hxv_lanczos_eigh", "hxv_lanczos_tridiag_host", "hxv_lanczos_eigh_host", "hxv_lanczos_tridiag_pair", "hxv_lanczos_tridiag_pair_host", "hxv_eigh_lowest", "hxv_eigh_lowest_host", "hxv_time_lanczos", "hxv_apply_ladder", "hxv_apply_ladder_axpy", "hxv_get_maps",
     "hxv_nnz", "hxv_get_csr", "hxv_get_diag", "hxv_set_option", "hxv_get_option", "hxv_get_stats", "hxv_pool_trim", "hxv_pool_stats", "hxv_last_error",
     "hxv_version", "hxv_comm_unique_id", "hxv_comm_init", "hxv_comm_free", "hxv_apply_device_slab", "hxv_exchange_count",
     "hxv_set_exchange_default", "hxv_exchange_mode", "hxv_halo_counts", "hxv_halo_lists",
@@ -92,6 +92,8 @@ def load_library():
     L.hxv_lanczos_eigh.argtypes = [vp, i32, dbl, pd, vp, pi32]
     L.hxv_lanczos_tridiag_host.argtypes = [vp, vp, i32, pd, pd, dbl, pi32]
     L.hxv_lanczos_eigh_host.argtypes = [vp, i32, dbl, pd, vp, pi32]
+    L.hxv_lanczos_tridiag_pair.argtypes = [vp, vp, vp, i32, pd, pd, pd, pd, dbl, pi32, pi32]
+    L.hxv_lanczos_tridiag_pair_host.argtypes = [vp, vp, vp, i32, pd, pd, pd, pd, dbl, pi32, pi32]
     L.hxv_eigh_lowest.argtypes = [vp, i32, i32, i32, dbl, pd, vp, pi32, pi32]
     L.hxv_eigh_lowest_host.argtypes = [vp, i32, i32, i32, dbl, pd, vp, pi32, pi32]
     L.hxv_time_lanczos.argtypes = [vp, vp, i32, C.POINTER(C.c_float)]
@@ -440,6 +442,37 @@ class HxvSector:
         _chk(load_library().hxv_lanczos_tridiag(self._h, vin.data_ptr(), nlanc, _p(a, C.c_double), _p(b, C.c_double), threshold,
                                                 C.byref(n)), "hxv_lanczos_tridiag")
         return a, b, n.value
+
+    def lanczos_tridiag_pair(self, vin_a, vin_b, nlanc: int, threshold: float = 1e-12):
+        """Two sp_lanc_tridiag runs (two Green's-function channels) on one product, real H: vin_a, vin_b = REAL start vectors in
+        the complex layout (torch CUDA, contiguous or padded).  -> (alanc_a, blanc_a, n_a), (alanc_b, blanc_b, n_b)."""
+        import torch
+
+        vs = []
+        for vin in (vin_a, vin_b):
+            assert vin.is_cuda and vin.dtype == torch.complex128
+            if vin.numel() != self.localElems:
+                assert vin.numel() == self.vecDim
+                vin = self.pad(vin, self.mpiQdw)
+            vs.append(vin)
+        torch.cuda.synchronize()
+        aa, ba, ab, bb = (np.zeros(nlanc) for _ in range(4))
+        na, nb = C.c_int32(), C.c_int32()
+        _chk(load_library().hxv_lanczos_tridiag_pair(self._h, vs[0].data_ptr(), vs[1].data_ptr(), nlanc, _p(aa, C.c_double), _p(ba, C.c_double),
+                                                     _p(ab, C.c_double), _p(bb, C.c_double), threshold, C.byref(na), C.byref(nb)),
+             "hxv_lanczos_tridiag_pair")
+        return (aa, ba, na.value), (ab, bb, nb.value)
+
+    def lanczos_tridiag_pair_host(self, vin_a: np.ndarray, vin_b: np.ndarray, nlanc: int, threshold: float = 1e-12):
+        va = np.ascontiguousarray(vin_a, dtype=np.complex128)
+        vb = np.ascontiguousarray(vin_b, dtype=np.complex128)
+        assert va.size == self.vecDim and vb.size == self.vecDim
+        aa, ba, ab, bb = (np.zeros(nlanc) for _ in range(4))
+        na, nb = C.c_int32(), C.c_int32()
+        _chk(load_library().hxv_lanczos_tridiag_pair_host(self._h, va.ctypes.data, vb.ctypes.data, nlanc, _p(aa, C.c_double), _p(ba, C.c_double),
+                                                          _p(ab, C.c_double), _p(bb, C.c_double), threshold, C.byref(na), C.byref(nb)),
+             "hxv_lanczos_tridiag_pair_host")
+        return (aa, ba, na.value), (ab, bb, nb.value)
 
     def lanczos_eigh(self, nitermax: int = 512, threshold: float = 1e-12, want_vector: bool = True, native: bool = False):
         """sp_lanc_eigh(MatVec, egs, vect, Nitermax, threshold): lowest eigenpair; the vector comes back

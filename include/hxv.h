@@ -191,6 +191,19 @@ int hxv_lanczos_eigh(hxv_handle *h, int32_t nitermax, double threshold, double *
 int hxv_lanczos_tridiag_host(hxv_handle *h, const void *vin_host, int32_t nlanc, double *alanc, double *blanc, double threshold,
                              int32_t *nsteps);
 int hxv_lanczos_eigh_host(hxv_handle *h, int32_t nitermax, double threshold, double *egs, void *vect_host, int32_t *niter);
+/* TWO tridiagonalisations on one product, for real H (hxv_real_vectors_available): the Green's-function channels of one solve
+ * are independent runs of sp_lanc_tridiag (ED_GF_NORMAL.f90:123-306, one per call site :215,282,422,504,638,720,801,882), and
+ * a complex product IS two real ones, H(x + i y) = H x + i H y.  The two REAL start vectors (complex layout, imaginary parts
+ * exactly zero -- c / c^dagger applied to a real ground state; refused otherwise) travel as real and imaginary part of one
+ * complex Lanczos vector; every scalar of the recurrence, every dot product and both early exits exist once per component.
+ * alanc_x/blanc_x[nlanc], *nsteps_x as in hxv_lanczos_tridiag.  Each component's numbers are bit-identical to
+ * hxv_lanczos_tridiag on that start vector through the same kernels (options real_vectors = 0, job_up = 0).
+ * nranks == 1.  The _host form takes the start vectors in the reference's contiguous host layout.                        */
+int hxv_lanczos_tridiag_pair(hxv_handle *h, const void *d_vin_a, const void *d_vin_b, int32_t nlanc, double *alanc_a, double *blanc_a,
+                             double *alanc_b, double *blanc_b, double threshold, int32_t *nsteps_a, int32_t *nsteps_b);
+int hxv_lanczos_tridiag_pair_host(hxv_handle *h, const void *vin_a_host, const void *vin_b_host, int32_t nlanc, double *alanc_a,
+                                  double *blanc_a, double *alanc_b, double *blanc_b, double threshold, int32_t *nsteps_a,
+                                  int32_t *nsteps_b);
 /* ---- Several lowest eigenpairs on device: the call SciFortran's sp_eigh (P-ARPACK) serves at ED_DIAG.f90:152-160,
  *   call sp_eigh(spHtimesV_p, eig_values(Neigen), eig_basis(vecDim,Neigen), Nblock, Nitermax, tol=lanc_tolerance)
  * as a thick-restart Lanczos (the explicit-restart form of ARPACK's implicitly restarted Lanczos for Hermitian

@@ -80,3 +80,20 @@ def test_fortran_mpi_branch_call_text(built):
     e_l = float(re.search(r"C2 MPI-branch sp_lanc_eigh E0=\s*([-\d.Ee+]+)", txt).group(1))
     e_t = float(re.search(r"C2 MPI-branch sp_lanc_tridiag E0=\s*([-\d.Ee+]+)", txt).group(1))
     assert abs(e_l - float(ser.group(1))) < 1e-9 and abs(e_t - float(ser.group(1))) < 1e-8
+
+
+def test_fortran_paired_tridiagonalisation(built):
+    """gpu_sp_lanc_tridiag_pair: two channels of ED_GF_NORMAL.f90:123-306 on one product, called from the Fortran demo host;
+    both lowest Ritz values equal the ground state, and channel a equals its own single run."""
+    exe = built.build_fortran()
+    if exe is None:
+        pytest.skip("flang not available")
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    txt = out.stdout
+    mp = re.search(r"C2 device tridiag pair E0=\s*([-\d.Ee+]+)\s+([-\d.Ee+]+)", txt)
+    ms = re.search(r"C2 device tridiag channel a alone E0=\s*([-\d.Ee+]+)", txt)
+    e0 = float(re.search(r"C2 device tridiag E0=\s*([-\d.Ee+]+)", txt).group(1))
+    assert mp and ms, txt
+    assert abs(float(mp.group(1)) - float(ms.group(1))) < 1e-10
+    assert abs(float(mp.group(1)) - e0) < 1e-8 and abs(float(mp.group(2)) - e0) < 1e-8

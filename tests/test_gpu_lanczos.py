@@ -608,3 +608,75 @@ def test_lanczos_after_eigh_on_a_fresh_handle_c4(built):
     del hv, vec
     torch.cuda.empty_cache()
     hxv.pool_trim()  # (the Ns=18 tests that follow need nearly all of the HBM)
+
+
+@pytest.mark.parametrize("case", ["chain8", "C2", "unequal_norms", "breakdown_in_one"])
+def test_paired_tridiagonalisation_is_two_single_runs_bit_for_bit(built, case):
+    """hxv_lanczos_tridiag_pair: two REAL start vectors as Re / Im of one complex Lanczos vector (real H, H(x+iy) = Hx + iHy;
+    the independent Green's-function channels of ED_GF_NORMAL.f90:123-306).  Every alanc/blanc equals, bit for bit, what
+    hxv_lanczos_tridiag gives for that start vector through the same kernels (real_vectors = 0, job_up = 0), and agrees with
+    the oracle's recurrence."""
+    import torch
+    import hxv
+    from hxv import models
+    from oracle.oracle import OracleSector
+
+    if case == "C2":
+        m, (nup, ndw), nl = models.hm_1dchain(), (6, 6), 30
+    elif case == "breakdown_in_one":
+        m, (nup, ndw), nl = models.hm_1dchain(Nlat=2, Nbath=1), (2, 2), 40   # Dim 36 < nl: the Krylov spaces close
+    else:
+        m, (nup, ndw), nl = models.hm_1dchain(Nlat=2, Nbath=2, eps_bath=[0.3, 0.6]), (3, 3), 25
+    sec = hxv.HxvSector.from_model(m, nup, ndw)
+    assert sec.real_vectors_available
+    rng = np.random.default_rng(7)
+    xa = rng.standard_normal(sec.Dim)
+    xb = rng.standard_normal(sec.Dim)
+    xa /= np.linalg.norm(xa)
+    xb /= np.linalg.norm(xb)
+    if case == "unequal_norms":
+        xa *= 3.0      # the driver normalises each component by itself, like SciFortran's first iteration
+        xb *= 0.25
+    if case == "breakdown_in_one":
+        # vector a lives in a small invariant subspace: an eigenvector of H -> its recurrence stops after one step
+        orc = OracleSector(m, nup, ndw)
+        w, U = np.linalg.eigh(orc.dense())
+        xa = np.real(U[:, 3] * np.exp(-1j * np.angle(U[np.abs(U[:, 3]).argmax(), 3])))
+        xa /= np.linalg.norm(xa)
+    da = torch.from_numpy(xa.astype(np.complex128)).cuda()
+    db = torch.from_numpy(xb.astype(np.complex128)).cuda()
+    sec.set_option("lanczos_graph", 0)
+    (aa, ba, na), (ab, bb, nb) = sec.lanczos_tridiag_pair(da, db, nl)
+    assert sec.get_option("lanczos_real_last") == 2
+    sec.set_option("real_vectors", 0)
+    sec.set_option("job_up", 0)
+    a1, b1, n1 = sec.lanczos_tridiag(da, nl)
+    a2, b2, n2 = sec.lanczos_tridiag(db, nl)
+    assert (na, nb) == (n1, n2)
+    if case == "breakdown_in_one":
+        assert na < 5 and nb > na
+    # bit-identical in every step both runs made (entries past a breakdown stay zero in both)
+    assert np.array_equal(aa[:na], a1[:n1]) and np.array_equal(ba[:na], b1[:n1]), (np.abs(aa - a1).max(), np.abs(ba - b1).max())
+    assert np.array_equal(ab[:nb], a2[:n2]) and np.array_equal(bb[:nb], b2[:n2]), (np.abs(ab - a2).max(), np.abs(bb - b2).max())
+    if case != "breakdown_in_one":
+        orc = OracleSector(m, nup, ndw)
+        ar, br = orc.lanc_tridiag(xb.astype(np.complex128) / np.linalg.norm(xb), nl)
+        k = min(len(ar), 12)   # (the early steps: later ones amplify rounding differences of the start)
+        assert np.abs(ab[:k] - ar[:k]).max() <= 1e-9 * np.abs(ar).max()
+    # a complex start vector is refused
+    with pytest.raises(hxv.HxvError):
+        sec.lanczos_tridiag_pair(da * (1 + 0.5j), db, 4)
+    sec.close()
+
+
+def test_paired_tridiagonalisation_refused_for_complex_h(built):
+    import torch
+    import hxv
+    from hxv import models
+
+    m = models.bhz_2d(Nbath=0)
+    sec = hxv.HxvSector.from_model(m, 4, 4)
+    v = torch.ones(sec.Dim, dtype=torch.complex128, device="cuda")
+    with pytest.raises(hxv.HxvError):
+        sec.lanczos_tridiag_pair(v, v, 4)
+    sec.close()
