@@ -135,13 +135,13 @@ int finish_create(hxv_handle* h, int device, hxv_handle** out) {
 }  // namespace
 
 namespace hxv {
-// REAL-vector mode: available when every amplitude of H is real, the tiled kernels run, there is
-// no spH0nd block and the sector is not split.  Vectors are double[DimDw][pitch_real], pitch_real = roundup16(DimUp).
+// REAL-vector mode: available when every amplitude of H is real, the tiled kernels run and there is
+// no spH0nd block.  Vectors are double[qdw local columns][pitch_real], pitch_real = roundup16(DimUp); on a split sector the
+// exchange moves real slabs -- half the bytes on the links.
 const char* real_mode_blocker(const hxv_handle* h) {
   if (!h->dev.real_h) return "H has complex amplitudes";
   if (h->kernel != 1 || !h->plan.usable) return "the tiled kernels are not in use";
   if (h->dev.nd.active) return "the spH0nd block (Jx/Jp) is active";
-  if (h->host.nranks != 1) return "the sector is split over ranks";
   if (h->host.panel_rows > 0) return "panel handle";
   if (h->plan.opt.passes != 3 || h->plan.opt.debug != 0) return "debug options are set";
   return nullptr;
@@ -274,12 +274,13 @@ int hxv_apply_device(hxv_handle* h, const void* d_v_full, void* d_hv_local, void
 }
 
 int32_t hxv_pitch_real(const hxv_handle* h) { return h ? pitch_real_of(h) : -1; }
-int64_t hxv_realvec_elems(const hxv_handle* h) { return h ? (int64_t)h->host.dimdw * pitch_real_of(h) : -1; }
+int64_t hxv_realvec_elems(const hxv_handle* h) { return h ? (int64_t)h->host.dimdw * pitch_real_of(h) : -1; }  // (the FULL vector)
 int32_t hxv_real_vectors_available(const hxv_handle* h) { return h && !real_mode_blocker(h) ? 1 : 0; }
 
 int hxv_apply_device_real(hxv_handle* h, const void* d_v_real, void* d_hv_real, void* stream) {
   if (!h || !d_v_real || !d_hv_real) return fail(HXV_ERR_ARG, "hxv_apply_device_real: NULL argument");
   if (const char* why = real_mode_blocker(h)) return fail(HXV_ERR_UNSUPPORTED, std::string("hxv_apply_device_real: real vectors unavailable: ") + why);
+  if (h->host.nranks != 1) return fail(HXV_ERR_UNSUPPORTED, "hxv_apply_device_real takes the whole vector of an unsplit sector (split sectors: the device Lanczos drivers exchange real slabs themselves)");
   int rcw = ensure_wt(h);
   if (rcw) return rcw;
   DevSector d = h->dev;

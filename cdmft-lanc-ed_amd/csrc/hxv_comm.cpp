@@ -1,18 +1,25 @@
-// The slab exchange behind the C-ABI: one RCCL communicator per open (split) sector.
+// The slab exchange behind the C-ABI: one communicator per open (split) sector.
 //
 // The reference splits the vector along DimDw (ED_HAMILTONIAN.f90:93-105) and re-assembles what a rank needs with
 // MPI collectives inside spMatVec_MPI_main (ED_HAMILTONIAN_SPARSE_HxV.f90:272-296, ED_HAMILTONIAN_COMMON.f90:30-94).
-// Here the re-assembly is ONE equal-count ncclAllGather over xGMI of the padded slabs, on the handle's stream, so a
-// Fortran rank needs nothing but this library: hxv_comm_unique_id (rank 0) -> broadcast the 128 bytes with the host
-// program's own MPI_Bcast -> hxv_comm_init on every rank.  The dot products of the device Lanczos drivers become
-// ncclAllReduce on the same stream.
-//
-// RCCL is loaded with dlopen at the first hxv_comm_* call: the library has no link-time dependency on it (serial runs
-// and the CPU-only checks never touch it), and a process that already holds a copy (PyTorch ships its own) reuses it.
+// Here the re-assembly is ONE equal-count all-gather of the padded slabs (or the halo exchange: only the columns H_dw
+// couples across ranks), on the stream the product runs on, so a Fortran rank needs nothing but this library.
+// Two transports serve the same code path:
+//   * RCCL over xGMI, one process per GPU: hxv_comm_unique_id (rank 0) -> broadcast the 128 bytes with the host program's
+//     own MPI_Bcast -> hxv_comm_init on every rank.  RCCL is loaded with dlopen at the first of these calls: the library has
+//     no link-time dependency on it, and a process that already holds a copy (PyTorch ships its own) reuses it.
+//   * THREAD RANKS inside one process: hxv_comm_local_create(nranks) -> hxv_comm_init_local(handle, group) from one host
+//     thread per rank.  Slabs travel by device-to-device copies ordered with HIP events, scalars through host memory.  The
+//     ranks may share one GPU (how the multi-rank code paths -- uneven slabs, halo lists, the drivers' collectives --
+//     are executed and tested on a one-GPU box, where RCCL refuses two ranks on one device) or sit on different GPUs of
+//     a node driven by one process.
+// The dot products of the device Lanczos drivers are all-reduced on the same stream (comm_allreduce_sum), and a rank that
+// fails before a collective tells the others first (comm_agree), so that nobody waits for a peer that has already left.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <condition_variable>
 #include <mutex>
 
 #include "hxv_handle.hpp"
@@ -67,70 +74,237 @@ int nccl_fail(const char* what, ncclResult_t e) {
   Rccl* r = rccl();
   return fail(HXV_ERR_HIP, std::string(what) + ": " + (r->GetErrorString ? r->GetErrorString(e) : "RCCL error"));
 }
+
+// ---- thread ranks: the ranks of a sector are host threads of this process -----------------------------------------
+struct LocalGroup {
+  int n = 0;
+  std::mutex mu;
+  std::condition_variable cv;
+  int arrived = 0;
+  uint64_t gen = 0;
+  std::vector<hxv_handle*> member;       // by rank
+  std::vector<hipEvent_t> ready, done;   // by rank: "what I send is in place" / "I have read what the others sent"
+  std::vector<std::vector<double>> red;  // by rank: contribution to the running all-reduce
+  std::vector<int> flag;                 // by rank: comm_agree
+  // every rank calls it; returns when all have (the ranks issue their collectives in the same order, like MPI ranks)
+  void barrier() {
+    std::unique_lock<std::mutex> lk(mu);
+    const uint64_t g = gen;
+    if (++arrived == n) {
+      arrived = 0;
+      ++gen;
+      cv.notify_all();
+    } else {
+      cv.wait(lk, [&] { return gen != g; });
+    }
+  }
+};
+LocalGroup* lg(const hxv_handle* h) { return reinterpret_cast<LocalGroup*>(h->lgroup); }
+
+// bytes of one column of a Lanczos / product vector: complex(8) columns of `pitch` elements or real ones of pitch_real
+size_t col_bytes(const hxv_handle* h, bool real) { return real ? (size_t)pitch_real_of(h) * sizeof(double) : (size_t)h->host.pitch * sizeof(double2); }
+
+int ensure_gather(hxv_handle* h, hipStream_t st) {
+  const SectorHost& s = h->host;
+  if (h->d_gather) return HXV_OK;
+  // sized for complex vectors; real ones (half the bytes per column) use the front of the same buffer
+  const size_t cb = col_bytes(h, false);
+  if (s.exchange == 1) {
+    const size_t nfull = (size_t)s.qdw + s.halo_cols.size();
+    HIPCHK(pool_alloc(h->device, std::max<size_t>(nfull, 1) * cb, (void**)&h->d_gather));
+    HIPCHK(pool_alloc(h->device, std::max<size_t>(s.send_cols.size(), 1) * cb, (void**)&h->d_send));
+    HIPCHK(hipMalloc((void**)&h->d_send_cols, std::max<size_t>(s.send_cols.size(), 1) * sizeof(int32_t)));
+    HIPCHK(hipMemcpy(h->d_send_cols, s.send_cols.data(), s.send_cols.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    h->device_bytes += (int64_t)((nfull + s.send_cols.size()) * cb);
+  } else {
+    const size_t bytes = (size_t)s.cmax * s.nranks * cb;
+    HIPCHK(pool_alloc(h->device, std::max<size_t>(bytes, 1), (void**)&h->d_gather));
+    HIPCHK(hipMemsetAsync(h->d_gather, 0, bytes, st));
+    h->device_bytes += (int64_t)bytes;
+  }
+  return HXV_OK;
+}
+
+// Exchange: this rank's slab d_v_local -> the gathered vector h->d_gather in the layout the kernels expect
+// (all-gather layout or halo layout, hxv.h); asynchronous on st.
+int exchange(hxv_handle* h, const void* d_v_local, bool real, hipStream_t st) {
+  const SectorHost& s = h->host;
+  HIPCHK(hipSetDevice(h->device));
+  int rc = ensure_gather(h, st);
+  if (rc) return rc;
+  const size_t cb = col_bytes(h, real);
+  char* gather = reinterpret_cast<char*>(h->d_gather);
+  LocalGroup* G = lg(h);
+  if (s.exchange == 1) {
+    // HALO exchange: only the columns H_dw couples to another rank's rows travel -- packed per destination; they land
+    // behind the local slab, where the column -> slot table of this layout expects them
+    HIPCHK(hipMemcpyAsync(gather, d_v_local, (size_t)s.qdw * cb, hipMemcpyDeviceToDevice, st));
+    hipError_t pe = launch_pack_columns((const double2*)d_v_local, h->d_send, h->d_send_cols, (int)s.send_cols.size(), (int)(cb / sizeof(double2)), st);
+    if (pe != hipSuccess) return fail(HXV_ERR_HIP, std::string("pack kernel: ") + hipGetErrorString(pe));
+    char* send = reinterpret_cast<char*>(h->d_send);
+    if (G) {
+      HIPCHK(hipEventRecord(G->ready[s.rank], st));
+      G->barrier();
+      int bad = 0;
+      for (int p = 0; p < s.nranks; ++p) {
+        if (p == s.rank) continue;
+        const SectorHost& o = G->member[p]->host;
+        const size_t nr = (size_t)(s.halo_ptr[p + 1] - s.halo_ptr[p]);
+        if ((size_t)(o.send_ptr[s.rank + 1] - o.send_ptr[s.rank]) != nr) bad = 1;  // the two ranks' plans disagree
+        if (!nr || bad) continue;
+        HIPCHK(hipStreamWaitEvent(st, G->ready[p], 0));
+        HIPCHK(hipMemcpyAsync(gather + (size_t)(s.qdw + s.halo_ptr[p]) * cb, reinterpret_cast<const char*>(G->member[p]->d_send) + (size_t)o.send_ptr[s.rank] * cb,
+                              nr * cb, hipMemcpyDefault, st));
+      }
+      HIPCHK(hipEventRecord(G->done[s.rank], st));
+      G->barrier();
+      for (int p = 0; p < s.nranks; ++p)
+        if (p != s.rank) HIPCHK(hipStreamWaitEvent(st, G->done[p], 0));  // my send buffer is free again once they have read it
+      if (bad) return fail(HXV_ERR_STATE, "halo exchange: a peer's send list does not match this rank's receive list");
+    } else {
+      Rccl* r = rccl();
+      ncclResult_t e = r->GroupStart();
+      for (int p = 0; p < s.nranks && e == ncclSuccess; ++p) {
+        if (p == s.rank) continue;
+        const size_t ns = (size_t)(s.send_ptr[p + 1] - s.send_ptr[p]) * cb / sizeof(double), nr = (size_t)(s.halo_ptr[p + 1] - s.halo_ptr[p]) * cb / sizeof(double);
+        if (ns) e = r->Send(send + (size_t)s.send_ptr[p] * cb, ns, ncclFloat64, p, (ncclComm_t)h->comm, st);
+        if (nr && e == ncclSuccess) e = r->Recv(gather + (size_t)(s.qdw + s.halo_ptr[p]) * cb, nr, ncclFloat64, p, (ncclComm_t)h->comm, st);
+      }
+      ncclResult_t e2 = r->GroupEnd();
+      if (e != ncclSuccess || e2 != ncclSuccess) return nccl_fail("halo send/recv", e != ncclSuccess ? e : e2);
+    }
+    h->n_exchange++;
+    return HXV_OK;
+  }
+  // ALL-GATHER: copy the slab into its slot of the gather buffer, all-gather in place (equal counts: ranks that own one
+  // column less leave their last column unused)
+  const size_t slot = (size_t)s.cmax * cb;
+  char* mine = gather + (size_t)s.rank * slot;
+  HIPCHK(hipMemcpyAsync(mine, d_v_local, (size_t)s.qdw * cb, hipMemcpyDeviceToDevice, st));
+  if (G) {
+    HIPCHK(hipEventRecord(G->ready[s.rank], st));
+    G->barrier();
+    for (int p = 0; p < s.nranks; ++p) {
+      if (p == s.rank) continue;
+      HIPCHK(hipStreamWaitEvent(st, G->ready[p], 0));
+      HIPCHK(hipMemcpyAsync(gather + (size_t)p * slot, reinterpret_cast<const char*>(G->member[p]->d_gather) + (size_t)p * slot, slot, hipMemcpyDefault, st));
+    }
+    HIPCHK(hipEventRecord(G->done[s.rank], st));
+    G->barrier();
+    for (int p = 0; p < s.nranks; ++p)
+      if (p != s.rank) HIPCHK(hipStreamWaitEvent(st, G->done[p], 0));
+  } else {
+    ncclResult_t e = rccl()->AllGather(mine, gather, slot / sizeof(double), ncclFloat64, (ncclComm_t)h->comm, st);
+    if (e != ncclSuccess) return nccl_fail("ncclAllGather", e);
+  }
+  h->n_exchange++;
+  return HXV_OK;
+}
 }  // namespace
 
 namespace hxv {
 
-bool comm_ready(const hxv_handle* h) { return h->comm != nullptr; }
+bool comm_ready(const hxv_handle* h) { return h->comm != nullptr || h->lgroup != nullptr; }
 
 int comm_allreduce_sum(hxv_handle* h, double* d_buf, size_t count, hipStream_t st) {
+  if (LocalGroup* G = lg(h)) {
+    // through host memory, summed in rank order on every rank: the same bits everywhere
+    const int r = h->host.rank;
+    std::vector<double> mine(count);
+    HIPCHK(hipMemcpyAsync(mine.data(), d_buf, count * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    G->red[r] = mine;
+    G->barrier();
+    std::vector<double> tot(count, 0.0);
+    for (int p = 0; p < G->n; ++p)
+      for (size_t i = 0; i < count; ++i) tot[i] += G->red[p][i];
+    G->barrier();  // (everybody has read every contribution before anybody overwrites its own)
+    HIPCHK(hipMemcpyAsync(d_buf, tot.data(), count * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return HXV_OK;
+  }
   if (!h->comm) return HXV_OK;  // serial: nothing to add
   ncclResult_t e = rccl()->AllReduce(d_buf, d_buf, count, ncclFloat64, ncclSum, (ncclComm_t)h->comm, st);
   if (e != ncclSuccess) return nccl_fail("ncclAllReduce", e);
   return HXV_OK;
 }
 
-// d_hv_local = (H v)|slab with v given as this rank's slab: copy the slab into its slot of the gather buffer, all-gather
-// in place, run the product on the gathered vector
-int apply_slab(hxv_handle* h, const double2* d_v_local, double2* d_hv_local, hipStream_t st) {
+// Collective error agreement: every rank passes its local status; all return non-zero if any rank failed.  Called by the
+// drivers after their rank-local preparations (allocations, argument checks) and BEFORE their first collective, so that a
+// rank that cannot go on does not leave its peers waiting inside an all-reduce.
+int comm_agree(hxv_handle* h, int rc_local) {
+  if (!comm_ready(h)) return rc_local;
+  int worst = rc_local;
+  if (LocalGroup* G = lg(h)) {
+    G->flag[h->host.rank] = rc_local;
+    G->barrier();
+    for (int p = 0; p < G->n; ++p)
+      if (G->flag[p] != 0 && worst == 0) worst = G->flag[p];
+    G->barrier();
+  } else {
+    double v = rc_local ? 1.0 : 0.0;
+    hipError_t e = hipMemcpyAsync(h->d_scalars + 7, &v, sizeof(double), hipMemcpyHostToDevice, h->stream);
+    ncclResult_t ne = ncclSuccess;
+    if (e == hipSuccess) ne = rccl()->AllReduce(h->d_scalars + 7, h->d_scalars + 7, 1, ncclFloat64, ncclMax, (ncclComm_t)h->comm, h->stream);
+    if (e == hipSuccess && ne == ncclSuccess) e = hipMemcpyAsync(&v, h->d_scalars + 7, sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess && ne == ncclSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess || ne != ncclSuccess) return fail(HXV_ERR_HIP, "comm_agree: the status all-reduce failed");
+    if (v != 0.0 && worst == 0) worst = HXV_ERR_STATE;
+  }
+  if (worst != 0 && rc_local == 0) return fail(worst, "a peer rank of this sector reported an error before the collective step: all ranks stop");
+  return worst;
+}
+
+// d_hv_local = (H v)|slab with v given as this rank's slab: exchange, then the product on the gathered vector.
+// `ep`: optional Lanczos epilogue of pass A (fused recurrence on a split sector: the partial sums are this rank's share).
+int apply_slab(hxv_handle* h, const double2* d_v_local, double2* d_hv_local, hipStream_t st, const LzEpilogue* ep) {
   const SectorHost& s = h->host;
-  if (s.nranks == 1 && !h->comm) return hxv_apply_device(h, d_v_local, d_hv_local, st);
-  if (!h->comm) return fail(HXV_ERR_STATE, "split sector without a communicator: call hxv_comm_init after opening the sector");
-  HIPCHK(hipSetDevice(h->device));
-  if (s.exchange == 1) {
-    // HALO exchange: only the columns H_dw couples to another rank's rows travel -- packed per destination, one grouped
-    // send/receive; they land behind the local slab, where the column -> slot table of this layout expects them
-    const size_t nfull = (size_t)(s.qdw + s.halo_cols.size()) * s.pitch;
-    if (!h->d_gather) {
-      HIPCHK(pool_alloc(h->device, std::max<size_t>(nfull, 1) * sizeof(double2), (void**)&h->d_gather));
-      HIPCHK(pool_alloc(h->device, std::max<size_t>(s.send_cols.size(), 1) * s.pitch * sizeof(double2), (void**)&h->d_send));
-      HIPCHK(hipMalloc((void**)&h->d_send_cols, std::max<size_t>(s.send_cols.size(), 1) * sizeof(int32_t)));
-      HIPCHK(hipMemcpy(h->d_send_cols, s.send_cols.data(), s.send_cols.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    }
-    HIPCHK(hipMemcpyAsync(h->d_gather, d_v_local, (size_t)s.qdw * s.pitch * sizeof(double2), hipMemcpyDeviceToDevice, st));
-    hipError_t pe = launch_pack_columns(d_v_local, h->d_send, h->d_send_cols, (int)s.send_cols.size(), s.pitch, st);
-    if (pe != hipSuccess) return fail(HXV_ERR_HIP, std::string("pack kernel: ") + hipGetErrorString(pe));
-    Rccl* r = rccl();
-    ncclResult_t e = r->GroupStart();
-    for (int p = 0; p < s.nranks && e == ncclSuccess; ++p) {
-      if (p == s.rank) continue;
-      const size_t ns = (size_t)(s.send_ptr[p + 1] - s.send_ptr[p]) * s.pitch, nr = (size_t)(s.halo_ptr[p + 1] - s.halo_ptr[p]) * s.pitch;
-      if (ns) e = r->Send(h->d_send + (size_t)s.send_ptr[p] * s.pitch, ns * 2, ncclFloat64, p, (ncclComm_t)h->comm, st);
-      if (nr && e == ncclSuccess) e = r->Recv(h->d_gather + (size_t)(s.qdw + s.halo_ptr[p]) * s.pitch, nr * 2, ncclFloat64, p, (ncclComm_t)h->comm, st);
-    }
-    ncclResult_t e2 = r->GroupEnd();
-    if (e != ncclSuccess || e2 != ncclSuccess) return nccl_fail("halo send/recv", e != ncclSuccess ? e : e2);
-    h->n_exchange++;
-    return hxv_apply_device(h, h->d_gather, d_hv_local, st);
+  const double2* vfull = d_v_local;
+  if (s.nranks != 1 || comm_ready(h)) {
+    if (!comm_ready(h)) return fail(HXV_ERR_STATE, "split sector without a communicator: call hxv_comm_init after opening the sector");
+    int rc = exchange(h, d_v_local, false, st);
+    if (rc) return rc;
+    vfull = h->d_gather;
   }
-  const size_t slot = (size_t)s.cmax * s.pitch;
-  if (!h->d_gather) {
-    HIPCHK(pool_alloc(h->device, slot * s.nranks * sizeof(double2), (void**)&h->d_gather));
-    HIPCHK(hipMemsetAsync(h->d_gather, 0, slot * s.nranks * sizeof(double2), st));
-    h->device_bytes += (int64_t)(slot * s.nranks * sizeof(double2));
+  if (!ep) return hxv_apply_device(h, vfull, d_hv_local, st);
+  int rcw = ensure_wt(h);
+  if (rcw) return rcw;
+  hipError_t e = launch_hxv_tiled(h->dev, h->plan, vfull, h->d_wt, d_hv_local, st, ep);
+  if (e != hipSuccess) return fail(HXV_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+  h->n_apply++;
+  return HXV_OK;
+}
+
+// the same on REAL vectors (double[qdw][pitch_real] slabs; half the bytes on the links)
+int apply_slab_real(hxv_handle* h, const double* d_v_local, double* d_hv_local, hipStream_t st, const LzEpilogue* ep) {
+  const SectorHost& s = h->host;
+  const double* vfull = d_v_local;
+  if (s.nranks != 1 || comm_ready(h)) {
+    if (!comm_ready(h)) return fail(HXV_ERR_STATE, "split sector without a communicator: call hxv_comm_init after opening the sector");
+    int rc = exchange(h, d_v_local, true, st);
+    if (rc) return rc;
+    vfull = reinterpret_cast<const double*>(h->d_gather);
   }
-  double2* mine = h->d_gather + (size_t)s.rank * slot;
-  HIPCHK(hipMemcpyAsync(mine, d_v_local, (size_t)s.qdw * s.pitch * sizeof(double2), hipMemcpyDeviceToDevice, st));
-  ncclResult_t e = rccl()->AllGather(mine, h->d_gather, slot * 2, ncclFloat64, (ncclComm_t)h->comm, st);
-  if (e != ncclSuccess) return nccl_fail("ncclAllGather", e);
-  h->n_exchange++;
-  return hxv_apply_device(h, h->d_gather, d_hv_local, st);
+  int rcw = ensure_wt(h);
+  if (rcw) return rcw;
+  DevSector d = h->dev;
+  d.pitch = pitch_real_of(h);
+  hipError_t e = launch_hxv_tiled_real(d, h->plan, vfull, (double*)h->d_wt, d_hv_local, st, ep);
+  if (e != hipSuccess) return fail(HXV_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+  h->n_apply++;
+  return HXV_OK;
 }
 
 void comm_release(hxv_handle* h) {
   if (h->comm) {
     (void)rccl()->CommDestroy((ncclComm_t)h->comm);
     h->comm = nullptr;
+  }
+  if (LocalGroup* G = lg(h)) {
+    // (the group object itself belongs to whoever created it: hxv_comm_local_destroy)
+    std::lock_guard<std::mutex> lk(G->mu);
+    if (h->host.rank < (int)G->member.size() && G->member[h->host.rank] == h) G->member[h->host.rank] = nullptr;
+    h->lgroup = nullptr;
   }
   if (h->d_gather) {
     pool_free(h->device, h->d_gather);
@@ -164,7 +338,7 @@ int hxv_comm_unique_id(void* id128) {
 
 int hxv_comm_init(hxv_handle* h, const void* id128) {
   if (!h || !id128) return fail(HXV_ERR_ARG, "hxv_comm_init: NULL");
-  if (h->comm) return fail(HXV_ERR_STATE, "hxv_comm_init: the handle already has a communicator");
+  if (comm_ready(h)) return fail(HXV_ERR_STATE, "hxv_comm_init: the handle already has a communicator");
   if (h->host.panel_rows > 0) return fail(HXV_ERR_STATE, "hxv_comm_init: panel handles take no communicator");
   Rccl* r = rccl();
   if (!r->err.empty()) return fail(HXV_ERR_UNSUPPORTED, r->err);
@@ -175,6 +349,52 @@ int hxv_comm_init(hxv_handle* h, const void* id128) {
   ncclResult_t e = r->CommInitRank(&c, h->host.nranks, id, h->host.rank);
   if (e != ncclSuccess) return nccl_fail("ncclCommInitRank", e);
   h->comm = c;
+  return HXV_OK;
+}
+
+int hxv_comm_local_create(int32_t nranks, void** group) {
+  if (nranks < 1 || !group) return fail(HXV_ERR_ARG, "hxv_comm_local_create: bad argument");
+  LocalGroup* G = new LocalGroup();
+  G->n = nranks;
+  G->member.assign(nranks, nullptr);
+  G->ready.assign(nranks, nullptr);
+  G->done.assign(nranks, nullptr);
+  G->red.resize(nranks);
+  G->flag.assign(nranks, 0);
+  *group = G;
+  return HXV_OK;
+}
+
+int hxv_comm_local_destroy(void* group) {
+  LocalGroup* G = reinterpret_cast<LocalGroup*>(group);
+  if (!G) return HXV_OK;
+  for (auto* m : G->member)
+    if (m) return fail(HXV_ERR_STATE, "hxv_comm_local_destroy: a handle still belongs to the group (hxv_comm_free / hxv_destroy it first)");
+  for (auto& e : G->ready)
+    if (e) (void)hipEventDestroy(e);
+  for (auto& e : G->done)
+    if (e) (void)hipEventDestroy(e);
+  delete G;
+  return HXV_OK;
+}
+
+int hxv_comm_init_local(hxv_handle* h, void* group) {
+  LocalGroup* G = reinterpret_cast<LocalGroup*>(group);
+  if (!h || !G) return fail(HXV_ERR_ARG, "hxv_comm_init_local: NULL");
+  if (comm_ready(h)) return fail(HXV_ERR_STATE, "hxv_comm_init_local: the handle already has a communicator");
+  if (h->host.panel_rows > 0) return fail(HXV_ERR_STATE, "hxv_comm_init_local: panel handles take no communicator");
+  if (h->host.nranks != G->n) return fail(HXV_ERR_ARG, "hxv_comm_init_local: the group's size is not the handle's nranks");
+  HIPCHK(hipSetDevice(h->device));
+  const int r = h->host.rank;
+  {
+    std::lock_guard<std::mutex> lk(G->mu);
+    if (G->member[r]) return fail(HXV_ERR_STATE, "hxv_comm_init_local: this rank has already joined the group");
+    G->member[r] = h;
+  }
+  if (!G->ready[r]) HIPCHK(hipEventCreateWithFlags(&G->ready[r], hipEventDisableTiming));
+  if (!G->done[r]) HIPCHK(hipEventCreateWithFlags(&G->done[r], hipEventDisableTiming));
+  h->lgroup = G;
+  G->barrier();  // collective: every rank has joined (one host thread per rank)
   return HXV_OK;
 }
 
@@ -193,5 +413,37 @@ int hxv_apply_device_slab(hxv_handle* h, const void* d_v_local, void* d_hv_local
 }
 
 int64_t hxv_exchange_count(const hxv_handle* h) { return h ? h->n_exchange : -1; }
+
+// The plan, not the transport: what rank `rank` of an `nranks`-way split of the DimDw axis receives from and sends to every
+// peer in the halo exchange, computed from the one-spin matrix H_dw alone (CSR in the reference's convention: 1-based columns, as
+// hxv_get_csr returns and spH0dws(1) stores) -- no handle, no device, no communicator.  Lets one process check that rank p's send
+// list towards q equals rank q's receive list from p for every pair.
+// counts: [nranks] columns per peer; cols: GLOBAL 0-based column indices (recv: slot order = ascending; send: grouped by destination).
+int hxv_halo_plan_from_csr(int32_t dimdw, const int64_t* dw_rowptr, const int32_t* dw_cols, int32_t rank, int32_t nranks, int32_t* recv_counts,
+                           int32_t* send_counts, int32_t* recv_cols, int32_t* send_cols, int32_t* n_recv, int32_t* n_send) {
+  if (dimdw < 1 || !dw_rowptr || !dw_cols || rank < 0 || nranks < 1 || rank >= nranks) return fail(HXV_ERR_ARG, "hxv_halo_plan_from_csr: bad argument");
+  SectorHost s;
+  s.dimdw = dimdw;
+  s.dw.rowptr.assign(dw_rowptr, dw_rowptr + dimdw + 1);
+  s.dw.cols.resize((size_t)dw_rowptr[dimdw]);
+  for (size_t p = 0; p < s.dw.cols.size(); ++p) {
+    if (dw_cols[p] < 1 || dw_cols[p] > dimdw) return fail(HXV_ERR_ARG, "hxv_halo_plan_from_csr: column index out of range (1-based expected)");
+    s.dw.cols[p] = dw_cols[p] - 1;
+  }
+  s.rank = rank;
+  s.nranks = nranks;
+  dw_split(s.dimdw, rank, nranks, s.qdw, s.dw0);
+  make_halo(s);
+  for (int r = 0; r < nranks; ++r) {
+    if (recv_counts) recv_counts[r] = s.halo_ptr[r + 1] - s.halo_ptr[r];
+    if (send_counts) send_counts[r] = s.send_ptr[r + 1] - s.send_ptr[r];
+  }
+  if (n_recv) *n_recv = (int32_t)s.halo_cols.size();
+  if (n_send) *n_send = (int32_t)s.send_cols.size();
+  if (recv_cols) std::copy(s.halo_cols.begin(), s.halo_cols.end(), recv_cols);
+  if (send_cols)
+    for (size_t k = 0; k < s.send_cols.size(); ++k) send_cols[k] = s.send_cols[k] + s.dw0;  // local -> global
+  return HXV_OK;
+}
 
 }  // extern "C"

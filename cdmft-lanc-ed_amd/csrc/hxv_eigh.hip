@@ -273,18 +273,25 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
   if (h->host.nranks != 1 && !comm_ready(h))
     return fail(HXV_ERR_STATE, "hxv_eigh_lowest on a split sector needs the communicator: call hxv_comm_init after opening the sector");
   const int64_t dim = h->host.dim;
-  if (neigen > dim) return fail(HXV_ERR_ARG, "hxv_eigh_lowest: neigen > Dim");
   if (ncv <= 0) ncv = 10 * neigen;  // the reference's default: lanc_ncv_factor=10, lanc_ncv_add=0 (ED_INPUT_VARS.f90:174-175)
   const int m = (int)std::min<int64_t>(std::max(ncv, neigen + 1), dim);
-  if (m > MAXCV) return fail(HXV_ERR_ARG, "hxv_eigh_lowest: ncv > 64 is not supported");
+  {
+    // argument errors are agreed on by the ranks of a split sector as well (a rank whose caller passed something else must not
+    // leave the others waiting in the first all-reduce)
+    int arg_rc = HXV_OK;
+    if (neigen > dim) arg_rc = fail(HXV_ERR_ARG, "hxv_eigh_lowest: neigen > Dim");
+    else if (m > MAXCV) arg_rc = fail(HXV_ERR_ARG, "hxv_eigh_lowest: ncv > 64 is not supported");
+    arg_rc = comm_agree(h, arg_rc);
+    if (arg_rc) return arg_rc;
+  }
   HIPCHK(hipSetDevice(h->device));
   // REAL-vector mode (H real, our own real start vector): the basis holds double[DimDw][pitch_real]; every kernel below
   // is elementwise with real coefficients, so it runs unchanged on the vectors viewed as n double2 elements.
   const bool real = h->real_vectors && !real_mode_blocker(h);
   h->last_real = real ? 1 : 0;
   const int64_t nc = (int64_t)h->host.pitch * h->host.qdw;  // this rank's padded complex slab (pads are zero and stay zero)
-  const int64_t n = real ? (int64_t)pitch_real_of(h) * h->host.dimdw / 2 : nc;
-  const int g = (int)std::min<int64_t>((n + 255) / 256, TR_BLOCKS);
+  const int64_t n = real ? (int64_t)pitch_real_of(h) * h->host.qdw / 2 : nc;
+  const int g = (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, TR_BLOCKS));  // (never an empty grid: a rank may own no column)
   const double eps = 2.220446049250313e-16, eps23 = std::pow(eps, 2.0 / 3.0);
   tol = std::max(tol, eps);
 
@@ -295,15 +302,26 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
     (void)hxv_pool_stats(h->device, &cached, nullptr, nullptr);
     free_b += (size_t)std::max<int64_t>(cached, 0);
   }
-  const size_t need = (size_t)(m + 1) * (size_t)n * sizeof(double2);
+  const size_t need = (size_t)(m + 1) * (size_t)std::max<int64_t>(n, 1) * sizeof(double2);
+  // (the shortfall is rank-local: the ranks of a split sector agree on it before anybody enters a collective)
+  int short_rc = HXV_OK;
   if (need + ((size_t)n * sizeof(double2)) > free_b)
-    return fail(HXV_ERR_HIP, "hxv_eigh_lowest: the Krylov basis needs " + std::to_string(need >> 20) + " MiB of HBM for ncv=" + std::to_string(m) +
-                                 " but only " + std::to_string(free_b >> 20) + " MiB are free: lower ncv or use hxv_lanczos_eigh (3 vectors)");
+    short_rc = fail(HXV_ERR_HIP, "hxv_eigh_lowest: the Krylov basis needs " + std::to_string(need >> 20) + " MiB of HBM for ncv=" + std::to_string(m) +
+                                     " but only " + std::to_string(free_b >> 20) + " MiB are free: lower ncv or use hxv_lanczos_eigh (3 vectors)");
+  short_rc = comm_agree(h, short_rc);
+  if (short_rc) return short_rc;
   DevFree mem;
   double2* V = nullptr;
   double *d_part = nullptr, *d_coef = nullptr, *d_S = nullptr;
   mem.device = h->device;
-  HIPCHK(pool_alloc(h->device, need, (void**)&V));
+  {
+    hipError_t ea = pool_alloc(h->device, need, (void**)&V);
+    int rca = comm_agree(h, ea == hipSuccess ? HXV_OK : fail(HXV_ERR_HIP, std::string("hxv_eigh_lowest: Krylov basis allocation: ") + hipGetErrorString(ea)));
+    if (rca) {
+      if (ea == hipSuccess) pool_free(h->device, V);
+      return rca;
+    }
+  }
   mem.pooled.push_back(V);
   HIPCHK(hipMemsetAsync(V, 0, need, h->stream));  // pad rows must be zero: the products never write them, the dots read them
   HIPCHK(hipMalloc((void**)&d_part, (size_t)TR_BLOCKS * (2 * JB + 1) * sizeof(double)));
@@ -453,7 +471,7 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
           c[2 * (jt - 1) + 1] = 0.0;
           w2 = nw * nw;
         } else {
-          rc = real ? hxv_apply_device_real(h, av(j), av(j + 1), st) : apply_slab(h, av(j), av(j + 1), st);
+          rc = real ? apply_slab_real(h, (const double*)av(j), (double*)av(j + 1), st) : apply_slab(h, av(j), av(j + 1), st);
           if (rc) return rc;
         }
         ++nmv;

@@ -20,7 +20,10 @@ int ensure_wt(hxv_handle* h);                // (re)allocates the dw-hop scratch
 // slab exchange of a split sector (hxv_comm.cpp)
 bool comm_ready(const hxv_handle* h);
 int comm_allreduce_sum(hxv_handle* h, double* d_buf, size_t count, hipStream_t st);  // no-op without a communicator
-int apply_slab(hxv_handle* h, const double2* d_v_local, double2* d_hv_local, hipStream_t st);
+int comm_agree(hxv_handle* h, int rc_local);  // collective: non-zero on every rank if any rank passes non-zero (no-op without a communicator)
+// (H v)|slab from this rank's slab: exchange + product; `ep`: optional Lanczos epilogue of pass A (its partial sums are this rank's share)
+int apply_slab(hxv_handle* h, const double2* d_v_local, double2* d_hv_local, hipStream_t st, const LzEpilogue* ep = nullptr);
+int apply_slab_real(hxv_handle* h, const double* d_v_local, double* d_hv_local, hipStream_t st, const LzEpilogue* ep = nullptr);
 void comm_release(hxv_handle* h);
 // REAL-vector mode helpers shared by the Lanczos drivers (hxv_capi.hip / hxv_lanczos.hip)
 const char* real_mode_blocker(const hxv_handle* h);  // nullptr when real vectors can be used with this handle
@@ -71,6 +74,7 @@ struct hxv_handle {
   int kernel = 1;
   // split sector: RCCL communicator over the nranks handles (hxv_comm_init) and the gathered vector
   void* comm = nullptr;          // ncclComm_t
+  void* lgroup = nullptr;        // thread ranks of one process (hxv_comm_init_local): the group object, see hxv_comm.cpp
   double2* d_gather = nullptr;   // nranks * cmax * pitch elements (all-gather layout) / (qdw + halo) * pitch (halo layout)
   double2* d_send = nullptr;     // halo exchange: packed columns, grouped by destination rank
   int32_t* d_send_cols = nullptr;

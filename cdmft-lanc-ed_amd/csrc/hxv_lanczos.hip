@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(256) lz_init(int64_t n, double2* __restrict__ 
   }
 }
 
-int grid_for(int64_t n) { return (int)std::min<int64_t>((n + 255) / 256, RED_BLOCKS); }
+int grid_for(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, RED_BLOCKS)); }  // (never an empty grid: a rank may own no column)
 
 // ---- REAL-vector mode: layout conversions and the real start vector ----------------------------------------------
 // real [DimDw][pr] <- Re(complex [DimDw][pc]); pads zero.  partial = per-block sum of Im^2 (may be null)
@@ -256,10 +256,11 @@ __global__ void __launch_bounds__(256) lz_to_complex(int dimup, int dimdw, int p
 }
 
 // real start vector: the real part of lz_init's vector
-__global__ void __launch_bounds__(256) lz_init_real(int64_t n, double* __restrict__ q, uint64_t seed, int dimup, int pitch) {
+__global__ void __launch_bounds__(256) lz_init_real(int64_t n, double* __restrict__ q, uint64_t seed, int dimup, int pitch, int col0) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t col = i / pitch;
-    const int row = (int)(i - col * pitch);
+    const int64_t lcol = i / pitch;
+    const int row = (int)(i - lcol * pitch);
+    const int64_t col = lcol + col0;  // global column: a split sector starts from the same global vector as the unsplit one
     if (row >= dimup) {
       q[i] = 0.0;
       continue;
@@ -379,10 +380,10 @@ struct LzRunner {
   double beta_prev = 1.0;
 
   LzRunner(hxv_handle* hh, double2* x, double2* xm, double2* w, bool real_vec = false) : h(hh), b{x, xm, w}, real(real_vec) {
-    fused = hh->kernel == 1 && hh->plan.usable && !hh->dev.nd.active && hh->plan.opt.passes == 3 && hh->plan.opt.debug == 0 &&
-            hh->host.nranks == 1 && !comm_ready(hh) && hh->lz_fused;
+    // (split sectors included: the epilogue's partial sums are this rank's share, alpha and beta are all-reduced)
+    fused = hh->kernel == 1 && hh->plan.usable && !hh->dev.nd.active && hh->plan.opt.passes == 3 && hh->plan.opt.debug == 0 && hh->lz_fused;
     // (local slab: qdw == DimDw on an unsplit sector)
-    n2 = real ? (int64_t)pitch_real_of(hh) * hh->host.dimdw / 2 : (int64_t)hh->host.pitch * hh->host.qdw;
+    n2 = real ? (int64_t)pitch_real_of(hh) * hh->host.qdw / 2 : (int64_t)hh->host.pitch * hh->host.qdw;
     hh->last_real = real ? 1 : 0;
   }
 
@@ -400,7 +401,7 @@ struct LzRunner {
     const int g = grid_for(n);
     if (!fused) {
       // (apply_slab = exchange + product on a split sector, the plain product otherwise)
-      int rc = real ? hxv_apply_device_real(h, b.q, b.w, h->stream) : apply_slab(h, b.q, b.w, h->stream);
+      int rc = real ? apply_slab_real(h, (const double*)b.q, (double*)b.w, h->stream) : apply_slab(h, b.q, b.w, h->stream);
       if (rc) return rc;
       hipLaunchKernelGGL(lz_sub_dot, dim3(g), dim3(256), 0, h->stream, n, b.w, b.qm, b.q, h->d_scalars, first ? -1 : 2, h->d_partials);
       rc = reduce_scalar(h, h->d_partials, g, 0, 0);
@@ -409,14 +410,15 @@ struct LzRunner {
       rc = reduce_scalar(h, h->d_partials + RED_BLOCKS, g, 1, 1);
       if (rc) return rc;
     } else {
-      const int64_t nwg = tiled_pass_up_workgroups(h->dev, h->plan, real);
+      const int64_t nwg = std::max<int64_t>(1, tiled_pass_up_workgroups(h->dev, h->plan, real));
       if (nwg > h->lz_partial_n) {
         if (h->d_lz_partial) (void)hipFree(h->d_lz_partial);
+        h->d_lz_partial = nullptr;
+        h->lz_partial_n = 0;
         HIPCHK(hipMalloc((void**)&h->d_lz_partial, (size_t)nwg * sizeof(double)));
+        HIPCHK(hipMemsetAsync(h->d_lz_partial, 0, (size_t)nwg * sizeof(double), h->stream));  // (a rank without columns launches nothing)
         h->lz_partial_n = nwg;
       }
-      int rcw = ensure_wt(h);
-      if (rcw) return rcw;
       // scal[2] = s, scal[3] = c = beta_k / beta_{k-1}
       const double sc[2] = {s_cur, first ? 0.0 : 1.0 / (s_cur * beta_prev)};
       HIPCHK(hipMemcpyAsync(h->d_scalars + 2, sc, 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -426,20 +428,14 @@ struct LzRunner {
       ep.i_s = 2;
       ep.i_c = 3;
       ep.partial = h->d_lz_partial;
-      hipError_t e;
-      if (real) {
-        DevSector d = h->dev;
-        d.pitch = pitch_real_of(h);
-        e = launch_hxv_tiled_real(d, h->plan, (const double*)b.q, (double*)h->d_wt, (double*)b.w, h->stream, &ep);
-      } else {
-        e = launch_hxv_tiled(h->dev, h->plan, b.q, h->d_wt, b.w, h->stream, &ep);
-      }
-      if (e != hipSuccess) return fail(HXV_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
-      h->n_apply++;
-      hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_lz_partial, (int)nwg, h->d_scalars, 0, 0);
+      int rc = real ? apply_slab_real(h, (const double*)b.q, (double*)b.w, h->stream, &ep) : apply_slab(h, b.q, b.w, h->stream, &ep);
+      if (rc) return rc;
+      rc = reduce_scalar(h, h->d_lz_partial, (int)nwg, 0, 0);  // alpha: summed over the ranks of a split sector
+      if (rc) return rc;
       hipLaunchKernelGGL(lz_mul, dim3(1), dim3(1), 0, h->stream, h->d_scalars, 4, 0, 2);
       hipLaunchKernelGGL(lz_sub_nrm, dim3(g), dim3(256), 0, h->stream, n, b.w, b.q, h->d_scalars, 4, h->d_partials + RED_BLOCKS);
-      hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_partials + RED_BLOCKS, g, h->d_scalars, 1, 1);
+      rc = reduce_scalar(h, h->d_partials + RED_BLOCKS, g, 1, 1);
+      if (rc) return rc;
     }
     double host[2];
     HIPCHK(hipMemcpyAsync(host, h->d_scalars, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -587,32 +583,32 @@ int ensure_lz(hxv_handle* h, bool real) {
 namespace hxv {
 void launch_to_real(const hxv_handle* h, const double2* src, double* dst, hipStream_t st) {
   const int pr = pitch_real_of(h);
-  hipLaunchKernelGGL(lz_to_real, dim3(grid_for((int64_t)pr * h->host.dimdw)), dim3(256), 0, st, h->host.dimup, h->host.dimdw, h->host.pitch, pr,
+  hipLaunchKernelGGL(lz_to_real, dim3(grid_for((int64_t)pr * h->host.qdw)), dim3(256), 0, st, h->host.dimup, h->host.qdw, h->host.pitch, pr,
                      src, dst, (double*)nullptr);
 }
 void launch_to_complex(const hxv_handle* h, const double* src, double2* dst, hipStream_t st) {
-  hipLaunchKernelGGL(lz_to_complex, dim3(grid_for((int64_t)h->host.pitch * h->host.dimdw)), dim3(256), 0, st, h->host.dimup, h->host.dimdw,
+  hipLaunchKernelGGL(lz_to_complex, dim3(grid_for((int64_t)h->host.pitch * h->host.qdw)), dim3(256), 0, st, h->host.dimup, h->host.qdw,
                      h->host.pitch, pitch_real_of(h), src, dst);
 }
 // One Lanczos step on NORMALISED vectors for callers that keep their own basis (hxv_eigh_lowest): w = H q - beta*qm through
 // pass A's epilogue (qm may be null), alpha = <q,w> from its partial sums, then w -= alpha*q and |w|.  False if the fused
 // product does not apply to this handle (the caller then measures the two projections itself).
 bool lanczos_local_step_available(const hxv_handle* h) {
-  return h->kernel == 1 && h->plan.usable && !h->dev.nd.active && h->plan.opt.passes == 3 && h->plan.opt.debug == 0 && h->host.nranks == 1 &&
-         !comm_ready(h) && h->lz_fused;
+  return h->kernel == 1 && h->plan.usable && !h->dev.nd.active && h->plan.opt.passes == 3 && h->plan.opt.debug == 0 && h->lz_fused;
 }
 
 int lanczos_local_step(hxv_handle* h, bool real, const double2* q, const double2* qm, double beta, double2* w, double* alpha, double* nrm_w) {
-  const int64_t n2 = real ? (int64_t)pitch_real_of(h) * h->host.dimdw / 2 : (int64_t)h->host.pitch * h->host.qdw;
+  const int64_t n2 = real ? (int64_t)pitch_real_of(h) * h->host.qdw / 2 : (int64_t)h->host.pitch * h->host.qdw;
   const int g = grid_for(n2);
-  const int64_t nwg = tiled_pass_up_workgroups(h->dev, h->plan, real);
+  const int64_t nwg = std::max<int64_t>(1, tiled_pass_up_workgroups(h->dev, h->plan, real));
   if (nwg > h->lz_partial_n) {
     if (h->d_lz_partial) (void)hipFree(h->d_lz_partial);
+    h->d_lz_partial = nullptr;
+    h->lz_partial_n = 0;
     HIPCHK(hipMalloc((void**)&h->d_lz_partial, (size_t)nwg * sizeof(double)));
+    HIPCHK(hipMemsetAsync(h->d_lz_partial, 0, (size_t)nwg * sizeof(double), h->stream));
     h->lz_partial_n = nwg;
   }
-  int rc = ensure_wt(h);
-  if (rc) return rc;
   const double sc[2] = {1.0, qm ? beta : 0.0};
   HIPCHK(hipMemcpyAsync(h->d_scalars + 2, sc, 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
   LzEpilogue ep;
@@ -621,19 +617,13 @@ int lanczos_local_step(hxv_handle* h, bool real, const double2* q, const double2
   ep.i_s = 2;
   ep.i_c = 3;
   ep.partial = h->d_lz_partial;
-  hipError_t e;
-  if (real) {
-    DevSector d = h->dev;
-    d.pitch = pitch_real_of(h);
-    e = launch_hxv_tiled_real(d, h->plan, (const double*)q, (double*)h->d_wt, (double*)w, h->stream, &ep);
-  } else {
-    e = launch_hxv_tiled(h->dev, h->plan, q, h->d_wt, w, h->stream, &ep);
-  }
-  if (e != hipSuccess) return fail(HXV_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
-  h->n_apply++;
-  hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_lz_partial, (int)nwg, h->d_scalars, 0, 0);
+  int rc = real ? apply_slab_real(h, (const double*)q, (double*)w, h->stream, &ep) : apply_slab(h, q, w, h->stream, &ep);
+  if (rc) return rc;
+  rc = reduce_scalar(h, h->d_lz_partial, (int)nwg, 0, 0);
+  if (rc) return rc;
   hipLaunchKernelGGL(lz_sub_nrm, dim3(g), dim3(256), 0, h->stream, n2, w, q, h->d_scalars, 0, h->d_partials + RED_BLOCKS);
-  hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_partials + RED_BLOCKS, g, h->d_scalars, 1, 1);
+  rc = reduce_scalar(h, h->d_partials + RED_BLOCKS, g, 1, 1);
+  if (rc) return rc;
   double host[2];
   HIPCHK(hipMemcpyAsync(host, h->d_scalars, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -643,8 +633,8 @@ int lanczos_local_step(hxv_handle* h, bool real, const double2* q, const double2
 }
 
 void launch_init_real(const hxv_handle* h, double* q, uint64_t seed, hipStream_t st) {
-  const int64_t n = (int64_t)pitch_real_of(h) * h->host.dimdw;
-  hipLaunchKernelGGL(lz_init_real, dim3(grid_for(n)), dim3(256), 0, st, n, q, seed, h->host.dimup, pitch_real_of(h));
+  const int64_t n = (int64_t)pitch_real_of(h) * h->host.qdw;
+  hipLaunchKernelGGL(lz_init_real, dim3(grid_for(n)), dim3(256), 0, st, n, q, seed, h->host.dimup, pitch_real_of(h), h->host.dw0);
 }
 }  // namespace hxv
 
@@ -658,18 +648,21 @@ int hxv_lanczos_tridiag(hxv_handle* h, const void* d_vin, int32_t nlanc, double*
   // REAL-vector mode: H real and the start vector purely real (c / c^dagger applied to a real ground state is) ->
   // the whole recurrence stays real; alanc/blanc are the same numbers at half the bytes per pass
   bool real = want_real(h);
-  if (real) {  // sum of Im(vin)^2 (dst = null: reduction only)
+  if (h->host.nranks != 1 && !comm_ready(h))
+    return fail(HXV_ERR_STATE, "device Lanczos on a split sector needs the communicator: call hxv_comm_init after opening the sector");
+  if (real) {  // sum of Im(vin)^2 over ALL ranks (dst = null: reduction only): every rank must take the same path
     const int pr = pitch_real_of(h);
-    const int g = grid_for((int64_t)pr * h->host.dimdw);
-    hipLaunchKernelGGL(lz_to_real, dim3(g), dim3(256), 0, h->stream, h->host.dimup, h->host.dimdw, h->host.pitch, pr,
+    const int g = grid_for((int64_t)pr * h->host.qdw);
+    hipLaunchKernelGGL(lz_to_real, dim3(g), dim3(256), 0, h->stream, h->host.dimup, h->host.qdw, h->host.pitch, pr,
                        (const double2*)d_vin, (double*)nullptr, h->d_partials);
-    hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_partials, g, h->d_scalars, 5, 0);
+    int rci = reduce_scalar(h, h->d_partials, g, 5, 0);
+    if (rci) return rci;
     double im2 = 0.0;
     HIPCHK(hipMemcpyAsync(&im2, h->d_scalars + 5, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     real = im2 == 0.0;
   }
-  int rc = ensure_lz(h, real);
+  int rc = comm_agree(h, ensure_lz(h, real));  // (a rank that could not allocate tells its peers before the first all-reduce)
   if (rc) return rc;
   LzRunner lz(h, h->d_lz[0], h->d_lz[1], h->d_lz[2], real);
   if (real)
@@ -702,7 +695,7 @@ int hxv_lanczos_tridiag(hxv_handle* h, const void* d_vin, int32_t nlanc, double*
     blanc[k] = 0;
   }
   int k = 0;
-  if (lz.fused && h->lz_graph && nlanc >= 8) {
+  if (lz.fused && h->lz_graph && nlanc >= 8 && !comm_ready(h)) {  // (device-only iterations: serial sectors; the all-reduces of a split one go through the host loop)
     // Fixed-length run (the Green's-function use, ED_GF_NORMAL.f90:204-220): iteration 0 with the host in the loop, the
     // other nlanc-1 on the device alone -- scalars stay in device memory, the pointer-rotation cycle of three
     // iterations is one hipGraph -- and alpha/beta come back once at the end.  A breakdown (beta < threshold) is
@@ -772,10 +765,10 @@ int hxv_lanczos_tridiag(hxv_handle* h, const void* d_vin, int32_t nlanc, double*
 int hxv_lanczos_eigh(hxv_handle* h, int32_t nitermax, double threshold, double* egs, void* d_vect, int32_t* niter) {
   if (!h || nitermax < 1 || !egs) return fail(HXV_ERR_ARG, "hxv_lanczos_eigh: bad argument");
   const bool real = want_real(h);  // the start vector is ours: real when H is (REAL-vector mode)
-  int rc = ensure_lz(h, real);
+  int rc = comm_agree(h, ensure_lz(h, real));
   if (rc) return rc;
-  const int64_t nc = (int64_t)h->host.pitch * h->host.qdw;                        // this rank's slab
-  const int64_t n = real ? (int64_t)pitch_real_of(h) * h->host.dimdw / 2 : nc;  // double2 elements per vector
+  const int64_t nc = (int64_t)h->host.pitch * h->host.qdw;                      // this rank's slab
+  const int64_t n = real ? (int64_t)pitch_real_of(h) * h->host.qdw / 2 : nc;  // double2 elements per vector
   const int g = grid_for(n);
   const int nmax = (int)std::min<int64_t>(nitermax, h->host.dim);
   const uint64_t seed = 0x5EED5EEDull;
@@ -882,6 +875,7 @@ int hxv_lanczos_tridiag_pair(hxv_handle* h, const void* d_vin_a, const void* d_v
   if (!h || !d_vin_a || !d_vin_b || nlanc < 1 || !alanc_a || !blanc_a || !alanc_b || !blanc_b)
     return fail(HXV_ERR_ARG, "hxv_lanczos_tridiag_pair: bad argument");
   if (const char* why = real_mode_blocker(h)) return fail(HXV_ERR_UNSUPPORTED, std::string("hxv_lanczos_tridiag_pair: unavailable: ") + why);
+  if (h->host.nranks != 1 || comm_ready(h)) return fail(HXV_ERR_UNSUPPORTED, "hxv_lanczos_tridiag_pair: unsplit sectors only");
   if (!h->lz_fused) return fail(HXV_ERR_UNSUPPORTED, "hxv_lanczos_tridiag_pair needs the fused recurrence (option lanczos_fused)");
   if (std::min(4, h->plan.opt.cols_per_tile) > 4) return fail(HXV_ERR_UNSUPPORTED, "hxv_lanczos_tridiag_pair: tile shape");
   HIPCHK(hipSetDevice(h->device));
@@ -1111,7 +1105,7 @@ int hxv_time_lanczos(hxv_handle* h, void* d_work3, int32_t nrep, float* ms_per_i
   double a, bt;
   rc = lz.step(&a, &bt);  // untimed first step (lazy allocations)
   if (rc) return rc;
-  if (lz.fused && h->lz_graph && nrep >= 8) {
+  if (lz.fused && h->lz_graph && nrep >= 8 && !comm_ready(h)) {
     // the fixed-length device-only path of hxv_lanczos_tridiag: iterations 1..nrep, three per hipGraph
     double* d_ab = nullptr;
     HIPCHK(hipMalloc((void**)&d_ab, (size_t)2 * (nrep + 1) * sizeof(double)));

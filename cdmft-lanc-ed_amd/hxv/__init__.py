@@ -3,7 +3,8 @@
 Layout: csrc/ (HIP kernels + C-ABI, built into lib/libhxv.so), fortran/ (ISO_C_BINDING glue for
 the reference's own host code), hxv/ (this Python mirror of the reference interface).
 """
-from .engine import HxvError, HxvSector, LIB_PATH, load_library, EXPORTS, pool_stats, pool_trim, set_exchange_default  # noqa: F401
+from .engine import (HxvError, HxvSector, LIB_PATH, LocalGroup, halo_plan_from_csr, load_library, EXPORTS, pool_stats, pool_trim, run_ranks,  # noqa: F401
+                     set_exchange_default)
 from .hamiltonian import EDContext  # noqa: F401
 from . import models  # noqa: F401
 from .distributed import (HaloHxv, ShardedHxv, ShardedLanczos, TransposedHxv, dw_split, exchange_ingest_bytes, halo_plan,  # noqa: F401

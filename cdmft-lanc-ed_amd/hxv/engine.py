@@ -44,7 +44,8 @@ EXPORTS = [
     "hxv_apply_device", "hxv_apply_device_real", "hxv_real_vectors_available", "hxv_pitch_real", "hxv_realvec_elems", "hxv_fullvec_elems", "hxv_localvec_elems", "hxv_pitch", "hxv_time_apply", "hxv_lanczos_tridiag", "hxv_lanczos_eigh", "hxv_lanczos_tridiag_host", "hxv_lanczos_eigh_host", "hxv_lanczos_tridiag_pair", "hxv_lanczos_tridiag_pair_host", "hxv_eigh_lowest", "hxv_eigh_lowest_host", "hxv_time_lanczos", "hxv_apply_ladder", "hxv_apply_ladder_axpy", "hxv_get_maps",
     "hxv_nnz", "hxv_get_csr", "hxv_get_diag", "hxv_set_option", "hxv_get_option", "hxv_get_stats", "hxv_pool_trim", "hxv_pool_stats", "hxv_last_error",
     "hxv_version", "hxv_comm_unique_id", "hxv_comm_init", "hxv_comm_free", "hxv_apply_device_slab", "hxv_exchange_count",
-    "hxv_set_exchange_default", "hxv_exchange_mode", "hxv_halo_counts", "hxv_halo_lists",
+    "hxv_set_exchange_default", "hxv_exchange_mode", "hxv_halo_counts", "hxv_halo_lists", "hxv_halo_plan_from_csr",
+    "hxv_comm_local_create", "hxv_comm_init_local", "hxv_comm_local_destroy",
 ]
 
 _lib = None
@@ -123,6 +124,10 @@ def load_library():
     L.hxv_exchange_mode.restype = i32
     L.hxv_halo_counts.argtypes = [vp, pi32, pi32]
     L.hxv_halo_lists.argtypes = [vp, pi32, pi32]
+    L.hxv_halo_plan_from_csr.argtypes = [i32, pi64, pi32, i32, i32, pi32, pi32, pi32, pi32, pi32, pi32]
+    L.hxv_comm_local_create.argtypes = [i32, C.POINTER(vp)]
+    L.hxv_comm_init_local.argtypes = [vp, vp]
+    L.hxv_comm_local_destroy.argtypes = [vp]
     _lib = L
     return L
 
@@ -142,6 +147,65 @@ def pool_stats(device: int = 0) -> dict:
     c, h, m = C.c_int64(), C.c_int64(), C.c_int64()
     load_library().hxv_pool_stats(device, C.byref(c), C.byref(h), C.byref(m))
     return {"cached_bytes": c.value, "hits": h.value, "misses": m.value}
+
+
+def halo_plan_from_csr(dimdw: int, rowptr, cols, rank: int, nranks: int):
+    """(recv_counts, send_counts, recv_cols, send_cols) of one rank of a split, global 0-based columns, from H_dw alone (CSR with 1-based
+    columns as HxvSector.csr / the oracle return it).  Host only: works without a GPU."""
+    L = load_library()
+    rp = np.ascontiguousarray(rowptr, dtype=np.int64)
+    cl = np.ascontiguousarray(cols, dtype=np.int32)
+    rc = np.zeros(nranks, dtype=np.int32)
+    sc = np.zeros(nranks, dtype=np.int32)
+    nr, ns = C.c_int32(), C.c_int32()
+    _chk(L.hxv_halo_plan_from_csr(dimdw, _p(rp, C.c_int64), _p(cl, C.c_int32), rank, nranks, _p(rc, C.c_int32), _p(sc, C.c_int32), None, None,
+                                  C.byref(nr), C.byref(ns)), "hxv_halo_plan_from_csr")
+    rcols = np.zeros(max(nr.value, 1), dtype=np.int32)
+    scols = np.zeros(max(ns.value, 1), dtype=np.int32)
+    _chk(L.hxv_halo_plan_from_csr(dimdw, _p(rp, C.c_int64), _p(cl, C.c_int32), rank, nranks, _p(rc, C.c_int32), _p(sc, C.c_int32),
+                                  _p(rcols, C.c_int32), _p(scols, C.c_int32), C.byref(nr), C.byref(ns)), "hxv_halo_plan_from_csr")
+    return rc, sc, rcols[: nr.value], scols[: ns.value]
+
+
+class LocalGroup:
+    """A communicator whose ranks are host threads of this process (hxv_comm_local_create): how several ranks of a split sector
+    run on one GPU (RCCL refuses two ranks on one device) or on the GPUs of a node under one process."""
+
+    def __init__(self, nranks: int):
+        g = C.c_void_p()
+        _chk(load_library().hxv_comm_local_create(nranks, C.byref(g)), "hxv_comm_local_create")
+        self._g = g
+        self.nranks = nranks
+
+    def close(self):
+        if getattr(self, "_g", None):
+            _chk(load_library().hxv_comm_local_destroy(self._g), "hxv_comm_local_destroy")
+            self._g = None
+
+
+def run_ranks(nranks: int, fn):
+    """Run fn(rank, group) on one host thread per rank of a fresh LocalGroup; returns the list of results (re-raises the first error)."""
+    import threading
+
+    group = LocalGroup(nranks)
+    out, err = [None] * nranks, [None] * nranks
+
+    def work(r):
+        try:
+            out[r] = fn(r, group)
+        except BaseException as e:  # noqa: BLE001 (reported to the caller below)
+            err[r] = e
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for e in err:
+        if e is not None:
+            raise e
+    group.close()
+    return out
 
 
 def _chk(rc: int, what: str):
@@ -339,6 +403,10 @@ class HxvSector:
         """Collective over the nranks handles of this sector (one process per GPU)."""
         assert len(id128) == 128
         _chk(load_library().hxv_comm_init(self._h, C.create_string_buffer(id128, 128)), "hxv_comm_init")
+
+    def comm_init_local(self, group: "LocalGroup"):
+        """Join a group of THREAD ranks (include/hxv.h): collective over the group's nranks handles, one host thread per rank."""
+        _chk(load_library().hxv_comm_init_local(self._h, group._g), "hxv_comm_init_local")
 
     def comm_free(self):
         _chk(load_library().hxv_comm_free(self._h), "hxv_comm_free")

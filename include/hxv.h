@@ -94,6 +94,18 @@ int hxv_apply_host(hxv_handle *h, int64_t nloc, const void *v, void *hv);
 int hxv_comm_unique_id(void *id128);
 int hxv_comm_init(hxv_handle *h, const void *id128);
 int hxv_comm_free(hxv_handle *h);
+/* STATUS of N>1 through RCCL: no round of this project has had more than one GPU, and RCCL refuses two ranks on one device, so
+ * the RCCL transport has only ever run with ONE rank.  Everything around it -- slab copies, uneven splits, halo lists and
+ * offsets, the drivers' all-reduces, the collective error agreement -- is executed with several ranks by the second
+ * transport below, which shares that code.
+ * THREAD RANKS: the nranks handles of a sector live in ONE process, one host thread per rank (same GPU or different GPUs of
+ * the node); slabs travel by device-to-device copies ordered with HIP events, scalars through host memory.  Create the group
+ * once, then every rank's thread calls hxv_comm_init_local (collective: it returns when all nranks have joined); from then on
+ * hxv_apply_host / hxv_apply_device_slab / the device drivers behave exactly as with hxv_comm_init, each called from its
+ * rank's thread.  hxv_comm_free / hxv_destroy leave the group; destroy it afterwards.                                        */
+int hxv_comm_local_create(int32_t nranks, void **group);
+int hxv_comm_init_local(hxv_handle *h, void *group);
+int hxv_comm_local_destroy(void *group);
 /* d_hv_local = (H v)|slab from this rank's slab d_v_local (hxv_localvec_elems() elements each, padded device layout):
  * exchange + product, asynchronous on `stream`.  nranks==1 without a communicator: the plain product.              */
 int hxv_apply_device_slab(hxv_handle *h, const void *d_v_local, void *d_hv_local, void *stream);
@@ -110,6 +122,13 @@ int hxv_set_exchange_default(int32_t mode); /* 0 all-gather [default], 1 halo; a
 int32_t hxv_exchange_mode(const hxv_handle *h);
 int hxv_halo_counts(const hxv_handle *h, int32_t *recv_counts, int32_t *send_counts);
 int hxv_halo_lists(const hxv_handle *h, int32_t *recv_cols, int32_t *send_cols);
+/* The halo PLAN of any rank of any split, computed from H_dw alone (CSR as hxv_get_csr returns it / as spH0dws(1) stores it:
+ * 1-based columns) -- no handle, no device, no communicator: counts[nranks] columns per peer; recv_cols (slot order) and send_cols
+ * (grouped by destination) as GLOBAL 0-based column indices, *n_recv / *n_send their lengths (call once with NULL lists to size
+ * them).  What one process needs to check that rank p's send list towards q IS rank q's receive list from p, for every pair. */
+int hxv_halo_plan_from_csr(int32_t dimdw, const int64_t *dw_rowptr, const int32_t *dw_cols, int32_t rank, int32_t nranks,
+                           int32_t *recv_counts, int32_t *send_counts, int32_t *recv_cols, int32_t *send_cols, int32_t *n_recv,
+                           int32_t *n_send);
 
 /* Device-resident product.  d_v_full: the FULL vector in the ALL-GATHER LAYOUT: nranks slabs of
  * cmax*pitch elements each, cmax = ceil(DimDw/nranks), slab r holding rank r's columns (ranks
@@ -154,7 +173,9 @@ int hxv_apply_up_add(hxv_handle *h, const void *d_v_local, const void *d_w, void
  * Lanczos drivers below select it by themselves when it applies (option "real_vectors", default 1) and convert at
  * their boundaries; hxv_apply_device_real is the product itself.
  *   layout: double[DimDw columns][hxv_pitch_real(h) = roundup16(DimUp)], pad rows zero / ignored like above.
- *   available iff H is real, the tiled kernels are in use, no spH0nd block, nranks==1 (hxv_real_vectors_available).  */
+ *   available iff H is real, the tiled kernels are in use, no spH0nd block (hxv_real_vectors_available).  On a split sector
+ *   the drivers exchange REAL slabs (half the bytes on the links); hxv_apply_device_real itself takes the whole vector of an
+ *   unsplit sector.                                                                                                  */
 int32_t hxv_real_vectors_available(const hxv_handle *h);
 int32_t hxv_pitch_real(const hxv_handle *h);
 int64_t hxv_realvec_elems(const hxv_handle *h);
@@ -166,7 +187,9 @@ int hxv_time_apply(hxv_handle *h, const void *d_v_full, void *d_hv_local, int32_
 
 /* ---- Lanczos on device (SciFortran sp_lanc_tridiag / sp_lanc_eigh call shapes,
  * ED_GF_NORMAL.f90:215-220, ED_DIAG.f90:176-184).  Split sectors (nranks>1) after hxv_comm_init:
- * vectors are this rank's slab, dot products are all-reduced.
+ * vectors are this rank's slab, dot products are all-reduced; the fused recurrence and the REAL-vector mode apply there too
+ * (the epilogue's partial sums are a rank's share of alpha).  A rank that fails in its local preparations tells the others before
+ * the first collective: all ranks return an error together instead of waiting for each other.
  * All vectors in the padded device layout (hxv_localvec_elems() elements, pad rows zero).
  * tridiag: d_vin = start vector (normalised by the driver if it is not, as SciFortran does); alanc[nlanc], blanc[nlanc]
  *   filled as alanc(k)=<q_k|H|q_k>, blanc(k+1)=beta_{k+1}, blanc(1)=0 (ED_GF_NORMAL.f90:949-951);

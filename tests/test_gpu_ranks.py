@@ -1,0 +1,160 @@
+"""SEVERAL ranks of a split sector on ONE GPU: the thread-rank transport of csrc/hxv_comm.cpp (hxv_comm_init_local) runs the
+multi-rank code of the C-ABI for real -- slab copies into the all-gather layout, uneven splits, halo lists and offsets, the
+drivers' all-reduces, the fused recurrence and the REAL-vector mode on slabs, the collective error agreement -- everything but
+RCCL's own transport (RCCL refuses two ranks on one device; it has run with one rank only: tests/test_gpu_comm.py).
+Reference semantics: spMatVec_MPI_main (ED_HAMILTONIAN_SPARSE_HxV.f90:230-315), the DimDw split of ED_HAMILTONIAN.f90:93-105,
+sp_lanc_tridiag / sp_lanc_eigh / sp_eigh called with MpiComm (ED_GF_NORMAL.f90:215, ED_DIAG.f90:152-156,176-177)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-13
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def _model(name):
+    from hxv import models
+
+    if name == "chain":
+        return models.hm_1dchain(Nlat=2, Nbath=2, eps_bath=[0.3, 0.6]), (3, 3)      # DimDw = 20: uneven for 3 ranks
+    if name == "C2":
+        return models.hm_1dchain(eps_bath=[0.3, 0.6]), (6, 6)                         # DimDw = 924
+    if name == "bhz":
+        return models.bhz_2d(Nbath=0), (4, 4)                                         # complex H, DimDw = 70
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("name,nranks,exchange", [("chain", 2, "allgather"), ("chain", 3, "allgather"), ("chain", 3, "halo"), ("C2", 4, "halo"),
+                                                  ("C2", 3, "allgather"), ("bhz", 3, "allgather"), ("bhz", 4, "halo")])
+def test_product_of_every_rank_through_the_exchange(built, name, nranks, exchange):
+    import torch
+    import hxv
+    from hxv import models
+    from oracle.oracle import OracleSector
+
+    m, (nup, ndw) = _model(name)
+    orc = OracleSector(m, nup, ndw)
+    v = models.deterministic_vector(orc.Dim)
+    v /= np.linalg.norm(v)
+    ref = orc.spMatVec_main(v)
+    hxv.set_exchange_default(exchange)
+
+    def rank(r, group):
+        sec = hxv.HxvSector.from_model(m, nup, ndw, rank=r, nranks=nranks)
+        assert sec.exchange_mode == exchange
+        sec.comm_init_local(group)
+        lo, hi = sec.mpiIshift, sec.mpiIshift + sec.vecDim
+        got_host = sec.apply_host(v[lo:hi])                        # spMatVec_MPI_main on this rank's slab, host arrays
+        dv = sec.pad(torch.from_numpy(v[lo:hi].copy()).cuda(), sec.mpiQdw)
+        got_dev = sec.unpad(sec.apply_device_slab(dv)).cpu().numpy()
+        n_ex = sec.exchange_count
+        sec.close()
+        return lo, hi, got_host, got_dev, n_ex
+
+    try:
+        res = hxv.run_ranks(nranks, rank)
+    finally:
+        hxv.set_exchange_default("allgather")
+    scale = np.abs(ref).max()
+    for lo, hi, gh, gd, n_ex in res:
+        assert np.abs(gh - ref[lo:hi]).max() <= TOL * scale and np.abs(gd - ref[lo:hi]).max() <= TOL * scale
+        assert n_ex == 2
+
+
+@pytest.mark.parametrize("name,nranks,exchange,real_vectors,fused", [("C2", 3, "allgather", 0, 1), ("C2", 3, "halo", 1, 1), ("C2", 2, "allgather", 1, 0),
+                                                                     ("chain", 3, "halo", 0, 0), ("bhz", 3, "allgather", 0, 1)])
+def test_lanczos_drivers_on_split_sector_equal_the_serial_ones(built, name, nranks, exchange, real_vectors, fused):
+    """tridiag, eigh and eigh_lowest with slabs per rank: the same Krylov space as the unsplit sector (the start vectors hash the
+    GLOBAL index), alpha/beta/E equal to rounding; every rank returns the same numbers; real vectors and the fused recurrence run
+    on slabs as well."""
+    import torch
+    import hxv
+    from hxv import models
+
+    m, (nup, ndw) = _model(name)
+    ser = hxv.HxvSector.from_model(m, nup, ndw)
+    ser.set_option("real_vectors", real_vectors)
+    ser.set_option("lanczos_fused", fused)
+    rng = np.random.default_rng(5)
+    v = rng.standard_normal(ser.Dim) + (0.0 if real_vectors else 1j * rng.standard_normal(ser.Dim))
+    v = (v / np.linalg.norm(v)).astype(np.complex128)
+    nl = 40 if name != "chain" else 25
+    a0, b0, n0 = ser.lanczos_tridiag(torch.from_numpy(v).cuda(), nl)
+    e0, vec0, _ = ser.lanczos_eigh(400, 1e-14)
+    ev0, _, nc0, _ = ser.eigh_lowest(2, 16, 200, 0.0)
+    want_real = bool(real_vectors) and ser.real_vectors_available
+    assert ser.get_option("lanczos_real_last") == (1 if want_real else 0)
+    hxv.set_exchange_default(exchange)
+
+    def rank(r, group):
+        sec = hxv.HxvSector.from_model(m, nup, ndw, rank=r, nranks=nranks)
+        sec.set_option("real_vectors", real_vectors)
+        sec.set_option("lanczos_fused", fused)
+        sec.comm_init_local(group)
+        lo, hi = sec.mpiIshift, sec.mpiIshift + sec.vecDim
+        a, b, n = sec.lanczos_tridiag(torch.from_numpy(v[lo:hi].copy()).cuda(), nl)
+        was_real = sec.get_option("lanczos_real_last")
+        e, vec, _ = sec.lanczos_eigh(400, 1e-14)
+        ev, vecs, nc, _ = sec.eigh_lowest(2, 16, 200, 0.0)
+        out = (lo, hi, a, b, n, e, vec.cpu().numpy(), ev, nc, was_real, vecs[0].cpu().numpy())
+        sec.close()
+        return out
+
+    try:
+        res = hxv.run_ranks(nranks, rank)
+    finally:
+        hxv.set_exchange_default("allgather")
+    gs = np.zeros(ser.Dim, dtype=np.complex128)
+    g2 = np.zeros(ser.Dim, dtype=np.complex128)
+    for lo, hi, a, b, n, e, vec, ev, nc, was_real, v2 in res:
+        # (the early steps entry by entry; later ones amplify rounding differences once Ritz values converge: there the lowest
+        #  eigenvalue of the tridiagonal matrix is the meaningful comparison)
+        assert n == n0 and np.abs(a[:12] - a0[:12]).max() < 1e-10 and np.abs(b[:12] - b0[:12]).max() < 1e-10
+        t_split = np.linalg.eigvalsh(np.diag(a[:n]) + np.diag(b[1:n], 1) + np.diag(b[1:n], -1))[0]
+        t_ser = np.linalg.eigvalsh(np.diag(a0[:n0]) + np.diag(b0[1:n0], 1) + np.diag(b0[1:n0], -1))[0]
+        assert abs(t_split - t_ser) < 1e-9
+        assert np.array_equal(a, res[0][2]) and np.array_equal(b, res[0][3])          # every rank holds the same numbers, bit for bit
+        assert abs(e - e0) < 1e-10 and nc == nc0 == 2 and np.abs(ev - ev0).max() < 1e-9
+        assert was_real == (1 if want_real else 0)
+        gs[lo:hi] = vec
+        g2[lo:hi] = v2
+    # the slabs of the eigenvector assemble to the serial one (up to a phase), and to an eigenvector of H
+    ov = abs(np.vdot(gs, vec0.cpu().numpy()))
+    assert abs(ov - 1.0) < 1e-8 and abs(np.linalg.norm(gs) - 1.0) < 1e-10
+    hg = ser.apply_device(torch.from_numpy(g2).cuda()).cpu().numpy()
+    assert np.linalg.norm(hg - ev0[0] * g2) < 1e-7
+    ser.close()
+
+
+def test_a_failing_rank_stops_all_ranks_before_the_collective(built):
+    """comm_agree: one rank is asked for more HBM than the device has; every rank returns an error instead of waiting inside an
+    all-reduce for a peer that has already left (rank-local early exits)."""
+    import hxv
+    from hxv import models
+
+    m, (nup, ndw) = _model("chain")
+
+    def rank(r, group):
+        sec = hxv.HxvSector.from_model(m, nup, ndw, rank=r, nranks=2)
+        sec.comm_init_local(group)
+        try:
+            # ncv beyond the engine's limit is an argument error on every rank: harmless.  The collective one: neigen > Dim on nobody,
+            # but a bad ncv only on rank 1 -> rank 0 must not hang
+            sec.eigh_lowest(2, 16 if r == 0 else 9999, 50, 0.0)
+            return "ok"
+        except hxv.HxvError as e:
+            return str(e)
+        finally:
+            sec.close()
+
+    import threading
+
+    done = []
+    t = threading.Thread(target=lambda: done.append(hxv.run_ranks(2, rank)))
+    t.start()
+    t.join(60)
+    assert not t.is_alive(), "a rank is still waiting for its peer: the failure was not made collective"
+    assert all(x != "ok" for x in done[0]), done
