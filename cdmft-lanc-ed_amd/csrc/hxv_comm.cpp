@@ -125,6 +125,54 @@ int ensure_gather(hxv_handle* h, hipStream_t st) {
   return HXV_OK;
 }
 
+}  // namespace
+
+namespace hxv {
+// Columns of `cb` bytes between the ranks of h's communicator: rank r sends send[send_ptr[p] .. send_ptr[p+1]) to every peer p and
+// receives recv[recv_ptr[p] .. recv_ptr[p+1]) from it (offsets in columns; both buffers on the device; asynchronous on st).  The
+// halo exchange of the product and the column moves of the spin-dw ladder operators are this one step.
+int comm_sendrecv_cols(hxv_handle* h, const void* send_v, const int32_t* send_ptr, void* recv_v, const int32_t* recv_ptr, size_t cb, hipStream_t st) {
+  const SectorHost& s = h->host;
+  const char* send = reinterpret_cast<const char*>(send_v);
+  char* recv = reinterpret_cast<char*>(recv_v);
+  if (LocalGroup* G = lg(h)) {
+    h->xfer_send = send;
+    h->xfer_send_ptr = send_ptr;
+    HIPCHK(hipEventRecord(G->ready[s.rank], st));
+    G->barrier();
+    int bad = 0;
+    for (int p = 0; p < s.nranks; ++p) {
+      if (p == s.rank) continue;
+      const hxv_handle* o = G->member[p];
+      const size_t nr = (size_t)(recv_ptr[p + 1] - recv_ptr[p]);
+      if ((size_t)(o->xfer_send_ptr[s.rank + 1] - o->xfer_send_ptr[s.rank]) != nr) bad = 1;  // the two ranks' plans disagree
+      if (!nr || bad) continue;
+      HIPCHK(hipStreamWaitEvent(st, G->ready[p], 0));
+      HIPCHK(hipMemcpyAsync(recv + (size_t)recv_ptr[p] * cb, o->xfer_send + (size_t)o->xfer_send_ptr[s.rank] * cb, nr * cb, hipMemcpyDefault, st));
+    }
+    HIPCHK(hipEventRecord(G->done[s.rank], st));
+    G->barrier();
+    for (int p = 0; p < s.nranks; ++p)
+      if (p != s.rank) HIPCHK(hipStreamWaitEvent(st, G->done[p], 0));  // my send buffer is free again once they have read it
+    if (bad) return fail(HXV_ERR_STATE, "column exchange: a peer's send list does not match this rank's receive list");
+    return HXV_OK;
+  }
+  if (!h->comm) return fail(HXV_ERR_STATE, "column exchange without a communicator");
+  Rccl* r = rccl();
+  ncclResult_t e = r->GroupStart();
+  for (int p = 0; p < s.nranks && e == ncclSuccess; ++p) {
+    if (p == s.rank) continue;
+    const size_t ns = (size_t)(send_ptr[p + 1] - send_ptr[p]) * cb / sizeof(double), nr = (size_t)(recv_ptr[p + 1] - recv_ptr[p]) * cb / sizeof(double);
+    if (ns) e = r->Send(send + (size_t)send_ptr[p] * cb, ns, ncclFloat64, p, (ncclComm_t)h->comm, st);
+    if (nr && e == ncclSuccess) e = r->Recv(recv + (size_t)recv_ptr[p] * cb, nr, ncclFloat64, p, (ncclComm_t)h->comm, st);
+  }
+  ncclResult_t e2 = r->GroupEnd();
+  if (e != ncclSuccess || e2 != ncclSuccess) return nccl_fail("grouped send/recv", e != ncclSuccess ? e : e2);
+  return HXV_OK;
+}
+}  // namespace hxv
+
+namespace {
 // Exchange: this rank's slab d_v_local -> the gathered vector h->d_gather in the layout the kernels expect
 // (all-gather layout or halo layout, hxv.h); asynchronous on st.
 int exchange(hxv_handle* h, const void* d_v_local, bool real, hipStream_t st) {
@@ -141,38 +189,8 @@ int exchange(hxv_handle* h, const void* d_v_local, bool real, hipStream_t st) {
     HIPCHK(hipMemcpyAsync(gather, d_v_local, (size_t)s.qdw * cb, hipMemcpyDeviceToDevice, st));
     hipError_t pe = launch_pack_columns((const double2*)d_v_local, h->d_send, h->d_send_cols, (int)s.send_cols.size(), (int)(cb / sizeof(double2)), st);
     if (pe != hipSuccess) return fail(HXV_ERR_HIP, std::string("pack kernel: ") + hipGetErrorString(pe));
-    char* send = reinterpret_cast<char*>(h->d_send);
-    if (G) {
-      HIPCHK(hipEventRecord(G->ready[s.rank], st));
-      G->barrier();
-      int bad = 0;
-      for (int p = 0; p < s.nranks; ++p) {
-        if (p == s.rank) continue;
-        const SectorHost& o = G->member[p]->host;
-        const size_t nr = (size_t)(s.halo_ptr[p + 1] - s.halo_ptr[p]);
-        if ((size_t)(o.send_ptr[s.rank + 1] - o.send_ptr[s.rank]) != nr) bad = 1;  // the two ranks' plans disagree
-        if (!nr || bad) continue;
-        HIPCHK(hipStreamWaitEvent(st, G->ready[p], 0));
-        HIPCHK(hipMemcpyAsync(gather + (size_t)(s.qdw + s.halo_ptr[p]) * cb, reinterpret_cast<const char*>(G->member[p]->d_send) + (size_t)o.send_ptr[s.rank] * cb,
-                              nr * cb, hipMemcpyDefault, st));
-      }
-      HIPCHK(hipEventRecord(G->done[s.rank], st));
-      G->barrier();
-      for (int p = 0; p < s.nranks; ++p)
-        if (p != s.rank) HIPCHK(hipStreamWaitEvent(st, G->done[p], 0));  // my send buffer is free again once they have read it
-      if (bad) return fail(HXV_ERR_STATE, "halo exchange: a peer's send list does not match this rank's receive list");
-    } else {
-      Rccl* r = rccl();
-      ncclResult_t e = r->GroupStart();
-      for (int p = 0; p < s.nranks && e == ncclSuccess; ++p) {
-        if (p == s.rank) continue;
-        const size_t ns = (size_t)(s.send_ptr[p + 1] - s.send_ptr[p]) * cb / sizeof(double), nr = (size_t)(s.halo_ptr[p + 1] - s.halo_ptr[p]) * cb / sizeof(double);
-        if (ns) e = r->Send(send + (size_t)s.send_ptr[p] * cb, ns, ncclFloat64, p, (ncclComm_t)h->comm, st);
-        if (nr && e == ncclSuccess) e = r->Recv(gather + (size_t)(s.qdw + s.halo_ptr[p]) * cb, nr, ncclFloat64, p, (ncclComm_t)h->comm, st);
-      }
-      ncclResult_t e2 = r->GroupEnd();
-      if (e != ncclSuccess || e2 != ncclSuccess) return nccl_fail("halo send/recv", e != ncclSuccess ? e : e2);
-    }
+    rc = comm_sendrecv_cols(h, h->d_send, s.send_ptr.data(), gather + (size_t)s.qdw * cb, s.halo_ptr.data(), cb, st);
+    if (rc) return rc;
     h->n_exchange++;
     return HXV_OK;
   }

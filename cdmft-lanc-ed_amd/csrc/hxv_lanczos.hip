@@ -1049,33 +1049,173 @@ int hxv_apply_ladder(hxv_handle* from, hxv_handle* to, int32_t orbital, int32_t 
   return hxv_apply_ladder_axpy(from, to, orbital, spin, create, 1.0, 0.0, 0, d_psi, d_out, norm2);
 }
 
+namespace {
+// out[c][:] = (accumulate ? out[c][:] : 0) + coef * sign[c] * src_c[:]  for the local target columns c of a spin-dw ladder operator on a
+// split sector: src_c = column slot[c] of the local source slab (slot >= 0), column -1-slot[c] of the received columns (slot < 0),
+// or nothing (sign[c] == 0: the target column is not reached).  Rows are untouched by a dw operator; pad rows stay as they are.
+__global__ void __launch_bounds__(256) ladder_cols_kernel(int dimup, int ncols, int pitch_from, int pitch_to, const int32_t* __restrict__ slot,
+                                                         const int32_t* __restrict__ sign, const double2* __restrict__ psi_local,
+                                                         const double2* __restrict__ recv, double2* __restrict__ out, double2 coef, int accumulate) {
+  const int c = blockIdx.x;
+  if (c >= ncols) return;
+  const int sg = sign[c];
+  const double2* __restrict__ src = sg == 0 ? nullptr : (slot[c] >= 0 ? psi_local + (int64_t)slot[c] * pitch_from : recv + (int64_t)(-1 - slot[c]) * pitch_from);
+  double2* __restrict__ dst = out + (int64_t)c * pitch_to;
+  for (int i = threadIdx.x; i < dimup; i += 256) {
+    double2 r = make_double2(0.0, 0.0);
+    if (sg != 0) {
+      const double2 x = src[i];
+      r = make_double2(sg * (coef.x * x.x - coef.y * x.y), sg * (coef.x * x.y + coef.y * x.x));
+    }
+    if (accumulate) {
+      const double2 o = dst[i];
+      r.x += o.x;
+      r.y += o.y;
+    }
+    dst[i] = r;
+  }
+}
+
+// position of a bit pattern in a sorted sector map (ED_SETUP.f90:1044-1061 binary_search), -1 if absent
+int rank_in_map_host(const std::vector<uint32_t>& map, uint32_t m) {
+  auto it = std::lower_bound(map.begin(), map.end(), m);
+  return (it != map.end() && *it == m) ? (int)(it - map.begin()) : -1;
+}
+}  // namespace
+
 int hxv_apply_ladder_axpy(hxv_handle* from, hxv_handle* to, int32_t orbital, int32_t spin, int32_t create, double coef_re, double coef_im,
                           int32_t accumulate, const void* d_psi, void* d_out, double* norm2) {
   if (!from || !to || !d_psi || !d_out) return fail(HXV_ERR_ARG, "hxv_apply_ladder: NULL argument");
   const SectorHost &a = from->host, &b = to->host;
-  if (a.nranks != 1 || b.nranks != 1) return fail(HXV_ERR_STATE, "hxv_apply_ladder needs nranks==1 (the reference does this step on the master)");
   if (a.map_up.empty() || b.map_up.empty()) return fail(HXV_ERR_STATE, "hxv_apply_ladder needs handles built from a model (basis maps)");
   if (from->device != to->device) return fail(HXV_ERR_ARG, "hxv_apply_ladder: handles on different devices");
   if (a.ns != b.ns || orbital < 0 || orbital >= a.ns || spin < 0 || spin > 1) return fail(HXV_ERR_ARG, "hxv_apply_ladder: bad orbital/spin");
   const int d = create ? 1 : -1;
   if (spin == 0 ? (b.nup != a.nup + d || b.ndw != a.ndw) : (b.ndw != a.ndw + d || b.nup != a.nup))
     return fail(HXV_ERR_ARG, "hxv_apply_ladder: `to` is not the sector reached by this operator");
+  if (a.nranks != b.nranks || a.rank != b.rank) return fail(HXV_ERR_ARG, "hxv_apply_ladder: the two sectors must be split over the same ranks");
+  const bool split = b.nranks != 1 || comm_ready(to);
+  if (split && !comm_ready(to)) return fail(HXV_ERR_STATE, "hxv_apply_ladder on split sectors needs the communicator of `to` (hxv_comm_init after opening it)");
   HIPCHK(hipSetDevice(to->device));
-  if (!accumulate) HIPCHK(hipMemsetAsync(d_out, 0, (size_t)b.pitch * b.dimdw * sizeof(double2), to->stream));  // pad rows = 0
-  const uint32_t* mf = spin == 0 ? from->dev.diag.map_up : from->dev.diag.map_dw;
-  const uint32_t* mt = spin == 0 ? to->dev.diag.map_up : to->dev.diag.map_dw;
-  hipError_t e = launch_ladder(mf, spin == 0 ? a.dimup : a.dimdw, mt, spin == 0 ? b.dimup : b.dimdw, a.pitch, b.dimup, b.pitch, b.dimdw,
-                               orbital, spin, create ? 1 : 0, (const double2*)d_psi, (double2*)d_out, to->stream,
-                               make_double2(coef_re, coef_im), accumulate ? 1 : 0);
-  if (e != hipSuccess) return fail(HXV_ERR_HIP, std::string("ladder kernel: ") + hipGetErrorString(e));
-  if (norm2) {
-    const int64_t n = (int64_t)b.pitch * b.dimdw;  // pads of d_out must be zero (hxv.h)
-    const int g = grid_for(n);
-    hipLaunchKernelGGL(lz_nrm, dim3(g), dim3(256), 0, to->stream, n, (const double2*)d_out, to->d_partials);
-    hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, to->stream, to->d_partials, g, to->d_scalars, 5, 0);
-    HIPCHK(hipMemcpyAsync(norm2, to->d_scalars + 5, sizeof(double), hipMemcpyDeviceToHost, to->stream));
+  hipStream_t st = to->stream;
+  const double2 coef = make_double2(coef_re, coef_im);
+  // The reference applies c / c^dagger on the master and scatters the result (ED_GF_NORMAL.f90:174-214).  Here every rank builds its
+  // own slab of the new vector:
+  //  * spin up: the operator acts inside a column and both sectors have the same DimDw, hence the same split -- purely local;
+  //  * spin dw: target column j of sector B is (a sign times) ONE column of sector A, which may belong to another rank of A's split:
+  //    a column permutation.  Every rank derives from the two dw maps what it needs from whom and what everybody needs from it
+  //    (deterministic, no negotiation), packs, exchanges once, and assembles.
+  if (!accumulate) HIPCHK(hipMemsetAsync(d_out, 0, (size_t)b.pitch * std::max(b.qdw, 1) * sizeof(double2), st));  // pad rows = 0
+  if (spin == 0 || !split) {
+    const uint32_t* mf = spin == 0 ? from->dev.diag.map_up : from->dev.diag.map_dw;
+    const uint32_t* mt = spin == 0 ? to->dev.diag.map_up : to->dev.diag.map_dw + b.dw0;  // (dw: the local target columns)
+    if (spin == 0 && a.qdw != b.qdw) return fail(HXV_ERR_STATE, "hxv_apply_ladder: the DimDw splits of the two sectors differ");
+    hipError_t e = launch_ladder(mf, spin == 0 ? a.dimup : a.dimdw, mt, spin == 0 ? b.dimup : b.dimdw, a.pitch, b.dimup, b.pitch, b.qdw,
+                                 orbital, spin, create ? 1 : 0, (const double2*)d_psi, (double2*)d_out, st, coef, accumulate ? 1 : 0);
+    if (e != hipSuccess) return fail(HXV_ERR_HIP, std::string("ladder kernel: ") + hipGetErrorString(e));
+  } else {
+    const int P = b.nranks, r = b.rank;
+    const uint32_t bit = 1u << orbital;
+    // source column (global, in A) and sign of a target column (global, in B); -1: not reached
+    auto source_of = [&](int jb, int& sg) -> int {
+      const uint32_t mb = b.map_dw[jb];
+      if (((mb & bit) != 0u) != (create != 0)) return -1;
+      const uint32_t ma = mb ^ bit;
+      sg = (__builtin_popcount(ma & (bit - 1u)) & 1) ? -1 : 1;  // (-1)^(occupied orbitals of this spin below `orbital`): c/cdg, ED_SETUP.f90:807-833
+      return rank_in_map_host(a.map_dw, ma);
+    };
+    std::vector<int> first_a(P + 1), first_b(P + 1);
+    for (int p = 0; p < P; ++p) {
+      int q, c0;
+      dw_split(a.dimdw, p, P, q, c0);
+      first_a[p] = c0;
+      dw_split(b.dimdw, p, P, q, c0);
+      first_b[p] = c0;
+    }
+    first_a[P] = a.dimdw;
+    first_b[P] = b.dimdw;
+    auto owner_a = [&](int ja) { return (int)(std::upper_bound(first_a.begin(), first_a.end(), ja) - first_a.begin()) - 1; };
+    // what I receive: my target columns in order, grouped by the source's owner; what I send: every peer's target columns in ITS order
+    std::vector<int32_t> slot(std::max(b.qdw, 1), 0), sgn(std::max(b.qdw, 1), 0), recv_ptr(P + 1, 0), send_ptr(P + 1, 0), send_cols;
+    std::vector<std::vector<int>> want(P);  // per owner: my local target columns whose source it holds, ascending
+    for (int c = 0; c < b.qdw; ++c) {
+      int sg = 0;
+      const int ja = source_of(b.dw0 + c, sg);
+      if (ja < 0) continue;
+      sgn[c] = sg;
+      const int o = owner_a(ja);
+      if (o == r)
+        slot[c] = ja - a.dw0;
+      else
+        want[o].push_back(c);
+    }
+    int nrecv = 0;
+    for (int p = 0; p < P; ++p) {
+      recv_ptr[p] = nrecv;
+      for (int c : want[p]) slot[c] = -1 - nrecv++;
+    }
+    recv_ptr[P] = nrecv;
+    for (int p = 0; p < P; ++p) {
+      send_ptr[p] = (int32_t)send_cols.size();
+      if (p == r) continue;
+      for (int jb = first_b[p]; jb < first_b[p + 1]; ++jb) {
+        int sg = 0;
+        const int ja = source_of(jb, sg);
+        if (ja >= 0 && owner_a(ja) == r) send_cols.push_back(ja - a.dw0);
+      }
+    }
+    send_ptr[P] = (int32_t)send_cols.size();
+    const size_t cb = (size_t)a.pitch * sizeof(double2);
+    double2 *d_sendbuf = nullptr, *d_recvbuf = nullptr;
+    int32_t* d_lists = nullptr;
+    const size_t nl = send_cols.size() + 2 * (size_t)std::max(b.qdw, 1);
+    int rc_local = HXV_OK;
+    hipError_t e1 = pool_alloc(to->device, std::max<size_t>(send_cols.size(), 1) * cb, (void**)&d_sendbuf);
+    hipError_t e2 = pool_alloc(to->device, std::max<size_t>((size_t)nrecv, 1) * cb, (void**)&d_recvbuf);
+    hipError_t e3 = hipMalloc((void**)&d_lists, std::max<size_t>(nl, 1) * sizeof(int32_t));
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) rc_local = fail(HXV_ERR_HIP, "hxv_apply_ladder: staging buffers for the column exchange");
+    auto release = [&]() {
+      (void)hipStreamSynchronize(st);
+      if (d_sendbuf) pool_free(to->device, d_sendbuf);
+      if (d_recvbuf) pool_free(to->device, d_recvbuf);
+      if (d_lists) (void)hipFree(d_lists);
+    };
+    int rc = comm_agree(to, rc_local);
+    if (rc) {
+      release();
+      return rc;
+    }
+    int32_t* d_send_cols = d_lists;
+    int32_t* d_slot = d_lists + send_cols.size();
+    int32_t* d_sgn = d_slot + std::max(b.qdw, 1);
+    hipError_t e = hipSuccess;
+    if (!send_cols.empty()) e = hipMemcpyAsync(d_send_cols, send_cols.data(), send_cols.size() * sizeof(int32_t), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_slot, slot.data(), slot.size() * sizeof(int32_t), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_sgn, sgn.data(), sgn.size() * sizeof(int32_t), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = launch_pack_columns((const double2*)d_psi, d_sendbuf, d_send_cols, (int)send_cols.size(), a.pitch, st);
+    if (e != hipSuccess) {
+      release();
+      return fail(HXV_ERR_HIP, std::string("hxv_apply_ladder: ") + hipGetErrorString(e));
+    }
+    rc = comm_sendrecv_cols(to, d_sendbuf, send_ptr.data(), d_recvbuf, recv_ptr.data(), cb, st);
+    if (rc) {
+      release();
+      return rc;
+    }
+    if (b.qdw > 0)
+      hipLaunchKernelGGL(ladder_cols_kernel, dim3((unsigned)b.qdw), dim3(256), 0, st, b.dimup, b.qdw, a.pitch, b.pitch, d_slot, d_sgn, (const double2*)d_psi,
+                         d_recvbuf, (double2*)d_out, coef, accumulate ? 1 : 0);
+    release();  // (synchronises the stream: the host lists above are read by asynchronous copies)
   }
-  HIPCHK(hipStreamSynchronize(to->stream));
+  if (norm2) {
+    const int64_t n = (int64_t)b.pitch * b.qdw;  // pads of d_out must be zero (hxv.h)
+    const int g = grid_for(n);
+    hipLaunchKernelGGL(lz_nrm, dim3(g), dim3(256), 0, st, n, (const double2*)d_out, to->d_partials);
+    int rcn = reduce_scalar(to, to->d_partials, g, 5, 0);  // <out|out> over ALL ranks of a split sector
+    if (rcn) return rcn;
+    HIPCHK(hipMemcpyAsync(norm2, to->d_scalars + 5, sizeof(double), hipMemcpyDeviceToHost, st));
+  }
+  HIPCHK(hipStreamSynchronize(st));
   return HXV_OK;
 }
 

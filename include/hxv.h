@@ -258,8 +258,13 @@ int hxv_time_lanczos(hxv_handle *h, void *d_work3 /* 3*hxv_localvec_elems() comp
  * open in `from` (vector of its Dim) into the sector open in `to` (N_spin +- 1; vector of its Dim), sign =
  * (-1)^(# occupied orbitals of the SAME spin below `orbital`) (c/cdg, ED_SETUP.f90:807-833; no cross-spin sign,
  * as in the reference).  orbital is 0-based (= pos-1), spin 0 = up, 1 = dw, create 1 = c^dagger, 0 = c.
- * *norm2 = <out|out> (the reference normalises by it, ED_GF_NORMAL.f90:197-199).  Both handles from_model,
- * nranks==1, same device; padded device layouts, d_out's pad rows are written as zero.                                                                               */
+ * *norm2 = <out|out> (the reference normalises by it, ED_GF_NORMAL.f90:197-199).  Both handles from_model, same device; padded
+ * device layouts, d_out's pad rows are written as zero.
+ * SPLIT sectors (both handles with the same rank / nranks, `to` with its communicator): d_psi / d_out are this rank's slabs and
+ * every rank builds its own slab of the new vector -- the master-only loop + scatter of ED_GF_NORMAL.f90:174-214 is gone.
+ * A spin-up operator is local to a slab (both sectors share DimDw and its split); a spin-dw operator maps whole columns of
+ * one split onto the other: every rank derives from the two dw maps what it needs from whom and what the others need from it,
+ * and one column exchange moves them.  *norm2 is the GLOBAL <out|out>.                                                        */
 int hxv_apply_ladder(hxv_handle *from, hxv_handle *to, int32_t orbital, int32_t spin, int32_t create, const void *d_psi,
                      void *d_out, double *norm2);
 /* Mixed channels (ED_GF_NORMAL.f90:370-406 (c^dagger_i + c^dagger_j)|gs>, :746-780 (c^dagger_i + xi c^dagger_j)|gs>, and the

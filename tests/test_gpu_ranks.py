@@ -158,3 +158,52 @@ def test_a_failing_rank_stops_all_ranks_before_the_collective(built):
     t.join(60)
     assert not t.is_alive(), "a rank is still waiting for its peer: the failure was not made collective"
     assert all(x != "ok" for x in done[0]), done
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+@pytest.mark.parametrize("spin,create", [(0, True), (0, False), (1, True), (1, False)])
+def test_ladder_operators_on_split_sectors(built, nranks, spin, create):
+    """c / c^dagger on the slabs of a split sector (the reference: master-only loop + scatter, ED_GF_NORMAL.f90:174-214): every rank
+    builds its slab of the new vector; assembled, it equals the serial device ladder, norm included; mixed channels accumulate
+    ((c^dagger_i + xi c^dagger_j)|gs>, ED_GF_NORMAL.f90:746-780)."""
+    import torch
+    import hxv
+    from hxv import models
+
+    m = models.hm_1dchain(Nlat=2, Nbath=2, eps_bath=[0.3, 0.6])   # Ns = 6
+    nup, ndw = 3, 3
+    d = 1 if create else -1
+    tnup, tndw = (nup + d, ndw) if spin == 0 else (nup, ndw + d)
+    sa = hxv.HxvSector.from_model(m, nup, ndw)
+    sb = hxv.HxvSector.from_model(m, tnup, tndw)
+    rng = np.random.default_rng(11)
+    psi = rng.standard_normal(sa.Dim) + 1j * rng.standard_normal(sa.Dim)
+    psi /= np.linalg.norm(psi)
+    dpsi = torch.from_numpy(psi).cuda()
+    orb_i, orb_j, xi = 1, 4, 0.3 - 0.8j
+    ref1, n1 = sa.apply_ladder(sb, orb_i, spin, create, dpsi)
+    acc = sb.pad(ref1.clone())
+    ref2, n2 = sa.apply_ladder(sb, orb_j, spin, create, dpsi, coef=xi, out=acc)
+    ref1 = ref1.cpu().numpy()
+    ref2 = sb.unpad(ref2).cpu().numpy()
+
+    def rank(r, group):
+        fa = hxv.HxvSector.from_model(m, nup, ndw, rank=r, nranks=nranks)
+        fb = hxv.HxvSector.from_model(m, tnup, tndw, rank=r, nranks=nranks)
+        fb.comm_init_local(group)
+        slab = fa.pad(torch.from_numpy(psi[fa.mpiIshift: fa.mpiIshift + fa.vecDim].copy()).cuda(), fa.mpiQdw)
+        o1, m1 = fa.apply_ladder(fb, orb_i, spin, create, slab)
+        got1 = fb.unpad(o1).cpu().numpy()
+        o2, m2 = fa.apply_ladder(fb, orb_j, spin, create, slab, coef=xi, out=o1)
+        got2 = fb.unpad(o2).cpu().numpy()
+        lo, hi = fb.mpiIshift, fb.mpiIshift + fb.vecDim
+        fa.close()
+        fb.close()
+        return lo, hi, got1, m1, got2, m2
+
+    res = hxv.run_ranks(nranks, rank)
+    for lo, hi, g1, m1, g2, m2 in res:
+        assert np.abs(g1 - ref1[lo:hi]).max() < 1e-14 and np.abs(g2 - ref2[lo:hi]).max() < 1e-14
+        assert abs(m1 - n1) < 1e-13 and abs(m2 - n2) < 1e-13      # the GLOBAL norms, on every rank
+    sa.close()
+    sb.close()
