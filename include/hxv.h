@@ -244,7 +244,10 @@ int hxv_lanczos_tridiag_pair_host(hxv_handle *h, const void *vin_a_host, const v
  * A single Krylov space sees ONE vector of an exactly degenerate level (ARPACK included), while ED_DIAG.f90:234-244 keeps
  * every state within gs_threshold of the minimum: so, once the wanted pairs have converged, they are locked and the
  * same iteration in their orthogonal complement looks for a state below the current neigen-th lowest value (a hidden
- * copy), repeatedly (option "eigh_degenerate", default 1; costs up to ~2/3 more products when there is nothing to find).
+ * copy), repeatedly (option "eigh_degenerate", default 1; costs about as many products again when there is nothing to find).
+ * Every step of such a round removes the locked eigenvectors (they are converged to `tol` only).  "Nothing below" is a
+ * HEURISTIC answer: the lowest Ritz value of the complement minus its residual must clear the level from the second restart
+ * cycle on, with a falling residual -- a copy whose overlap with the start vector is at rounding level can still be missed.
  * Split sectors: after hxv_comm_init (vectors = slabs).  If Dim <= ncv the Krylov space closes and all returned pairs are exact. */
 int hxv_eigh_lowest(hxv_handle *h, int32_t neigen, int32_t ncv, int32_t maxrestart, double tol, double *evals, void *d_evecs,
                     int32_t *nconv, int32_t *nmatvec);

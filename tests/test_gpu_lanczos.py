@@ -680,3 +680,27 @@ def test_paired_tridiagonalisation_refused_for_complex_h(built):
     with pytest.raises(hxv.HxvError):
         sec.lanczos_tridiag_pair(v, v, 4)
     sec.close()
+
+
+def test_eigh_lowest_loose_tolerance_returns_no_duplicate(built):
+    """with tol far above machine epsilon the locked pairs are only converged to tol, every product re-injects a
+    component along them, and a locking round that did not subtract them could converge back onto a locked state and return it
+    twice.  Non-degenerate spectrum, tol = 1e-6: the returned values are the two lowest DISTINCT eigenvalues."""
+    import hxv
+    from hxv import models
+    from oracle.oracle import OracleSector
+
+    m = models.hm_1dchain(Nlat=2, Nbath=2, eps_bath=[0.3, 0.6])
+    sec = hxv.HxvSector.from_model(m, 3, 3)
+    w = np.linalg.eigvalsh(OracleSector(m, 3, 3).dense())
+    assert w[1] - w[0] > 1e-3 and w[2] - w[1] > 1e-3           # non-degenerate
+    for rv in (1, 0):
+        sec.set_option("real_vectors", rv)
+        for neigen in (2, 3):
+            ev, vecs, nconv, nmv = sec.eigh_lowest(neigen, 12, 300, 1e-6)
+            assert nconv == neigen
+            assert np.abs(ev - w[:neigen]).max() < 1e-5, (ev, w[:neigen])   # accuracy of a 1e-6 residual, and no repeated value
+            assert np.min(np.diff(ev)) > 1e-4
+            G = (vecs.conj() @ vecs.T).cpu().numpy()
+            assert np.abs(G - np.eye(neigen)).max() < 1e-6
+    sec.close()
