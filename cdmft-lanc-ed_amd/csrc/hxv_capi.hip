@@ -467,6 +467,7 @@ int hxv_set_option(hxv_handle* h, const char* name, int64_t value) {
   else if (!strcmp(name, "sort_mode")) o.sort_mode = (int)value;
   else if (!strcmp(name, "wt_cols")) o.wt_cols = (int)value;
   else if (!strcmp(name, "sort_mode_dw")) o.sort_mode_dw = (int)value;
+  else if (!strcmp(name, "spread_banks")) o.spread_banks = value ? 1 : 0;
   else if (!strcmp(name, "job_up")) o.job_up = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
   else if (!strcmp(name, "job_cols")) o.job_cols = (int)value;
   else if (!strcmp(name, "job_groups")) o.job_groups = (int)value;

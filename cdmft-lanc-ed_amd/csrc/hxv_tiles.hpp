@@ -68,6 +68,7 @@ struct TileOptions {
   int sort_mode = 0;  // pass A visiting order: 0 natural (keeps global accesses coalesced), 1 by inner count, 2 by (outer, inner)
   int sort_mode_dw = 1;  // pass B inner phase (LDS only): 0 natural, 1 by inner count
   int lds_min_kb_up = 0, lds_min_kb_dw = 0;  // request at least this much LDS per workgroup (limits workgroups per CU)
+  int spread_banks = 1;  // in-block hop lists re-dealt per wave so that the LDS gathers of a slot spread over the bank quads (host only)
   int pair_rows = -1;  // pass B order: -1 automatic (paired row groups when two panels exceed the XCD's L2), 0 off, 1 on
   int job_max_blocks = 32;  // pass A runs as jobs only up to this many blocks per spin (beyond, one chunk's jobs no longer fit an XCD's CUs)
   int wt_cols = 4;  // columns per group of the blocked dw-hop scratch (>= cols_per_tile): R*wt_cols*16-byte write runs in pass B

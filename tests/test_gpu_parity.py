@@ -347,8 +347,12 @@ def test_real_vector_mode_refused_for_complex_h_and_shards(built):
     assert not bhz.real_vectors_available
     with pytest.raises(hxv.HxvError, match="complex amplitudes"):
         bhz.apply_device_real(torch.zeros(bhz.Dim, dtype=torch.float64, device="cuda"))
+    # a slab of a split sector: the drivers exchange real slabs themselves (tests/test_gpu_ranks.py); the product entry that takes
+    # the WHOLE real vector is for unsplit sectors only
     shard = hxv.HxvSector.from_model(models.hm_1dchain(Nlat=2, Nbath=2), 3, 3, rank=1, nranks=2)
-    assert not shard.real_vectors_available
+    assert shard.real_vectors_available
+    with pytest.raises(hxv.HxvError, match="unsplit"):
+        shard.apply_device_real(torch.zeros(shard.Dim, dtype=torch.float64, device="cuda"))
 
 
 def test_full_size_c4_complex_hermiticity_and_linearity(built):
