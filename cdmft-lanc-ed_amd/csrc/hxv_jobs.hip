@@ -81,7 +81,8 @@ struct JobUp {
 
 constexpr int JOB_WAVES = 16, JOB_LOADER = JOB_WAVES - 1, JOB_MAX_STAGES = 8;
 
-template <int C, bool REALC, bool NORB1, bool LZ, int KIN, int KO, typename VT>
+// LZ: 0 plain product, 1 Lanczos epilogue, 2 PAIRED epilogue (real H: Re and Im are two independent real Lanczos vectors, hxv_tiles.hpp)
+template <int C, bool REALC, bool NORB1, int LZ, int KIN, int KO, typename VT>
 __global__ void __launch_bounds__(1024) hxv_up_job(DevSector s, DevTiles t, JobUp jb, LzEpilogue lz) {
   using CT = typename Coef<REALC>::type;
   constexpr uint32_t OFFM = (1u << TILE_COEF_SHIFT) - 1u;
@@ -94,7 +95,10 @@ __global__ void __launch_bounds__(1024) hxv_up_job(DevSector s, DevTiles t, JobU
   const int g1 = min(xcd * jb.gpx + (int)(((int64_t)(chunk + 1) * jb.gpx) / jb.chunks), jb.ngroups);
   const int ntile = g1 - g0;
   if (chunk >= jb.chunks || ntile <= 0) {
-    if (LZ && threadIdx.x == 0) lz.partial[blockIdx.x] = 0.0;
+    if (LZ && threadIdx.x == 0) {
+      lz.partial[blockIdx.x] = 0.0;
+      if (LZ == 2) lz.partial2[blockIdx.x] = 0.0;
+    }
     return;
   }
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -240,9 +244,11 @@ __global__ void __launch_bounds__(1024) hxv_up_job(DevSector s, DevTiles t, JobU
       mu = s.diag.map_up[r0 + pr];
     }
   }
-  double asum = 0.0;
+  double asum = 0.0, asum2 = 0.0;
   const double sc = LZ ? lz.scal[lz.i_s] : 1.0;
   const double cm = (LZ && lz.xm) ? lz.scal[lz.i_c] : 0.0;
+  const double sc2 = LZ == 2 ? lz.scal[lz.i_s2] : 1.0;
+  const double cm2 = (LZ == 2 && lz.xm) ? lz.scal[lz.i_c2] : 0.0;
   char* __restrict__ hvb = reinterpret_cast<char*>(jb.hv) + (int64_t)r0 * 16;
   const char* __restrict__ vb = reinterpret_cast<const char*>(v);
   const uint32_t p16 = (uint32_t)p << 4, pw16 = p16 << lw;
@@ -361,10 +367,18 @@ __global__ void __launch_bounds__(1024) hxv_up_job(DevSector s, DevTiles t, JobU
 #pragma unroll
     for (int cc = 0; cc < C; ++cc) {
       VT w = acc[cc];
-      if (LZ) {
+      if constexpr (LZ == 2) {
+        // component-wise: the same operations, in the same order, as two LZ == 1 runs on (x, 0) and (y, 0)
+        pair_scale(w, sc, sc2);
+        if (lz.xm) pair_fma(w, -cm, -cm2, lds_ld<VT>(tile_off + (uint32_t)((C + cc) * ns) * 16 + p16));
+        if (row_ok && cc < nc) {
+          asum = ::fma(sc, pair_dot_re(xq[cc], w), asum);
+          asum2 = ::fma(sc2, pair_dot_im(xq[cc], w), asum2);
+        }
+      } else if (LZ) {
         vscale(w, sc);
         if (lz.xm) Coef<true>::fma(w, -cm, lds_ld<VT>(tile_off + (uint32_t)((C + cc) * ns) * 16 + p16));
-        if (row_ok && cc < nc) asum += sc * vdot(xq[cc], w);
+        if (row_ok && cc < nc) asum = ::fma(sc, vdot(xq[cc], w), asum);
       }
       pend[cc] = w;
     }
@@ -376,14 +390,24 @@ __global__ void __launch_bounds__(1024) hxv_up_job(DevSector s, DevTiles t, JobU
   if (LZ) {
     // wavefront partial sums first (DPP/shuffle), one LDS word per wave afterwards
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) asum += __shfl_down(asum, off, 64);
+    for (int off = 32; off > 0; off >>= 1) {
+      asum += __shfl_down(asum, off, 64);
+      if (LZ == 2) asum2 += __shfl_down(asum2, off, 64);
+    }
     wg_barrier();  // every tile buffer is free (the loader has left)
-    if (lane == 0) lds_st<double>(ring0 + 8 * wave, asum);
+    if (lane == 0) {
+      lds_st<double>(ring0 + 8 * wave, asum);
+      if (LZ == 2) lds_st<double>(ring0 + 8 * (JOB_WAVES + wave), asum2);
+    }
     wg_barrier();
     if (threadIdx.x == 0) {
-      double tot = 0.0;
-      for (int w = 0; w < JOB_LOADER; ++w) tot += lds_ld<double>(ring0 + 8 * w);
+      double tot = 0.0, tot2 = 0.0;
+      for (int w = 0; w < JOB_LOADER; ++w) {
+        tot += lds_ld<double>(ring0 + 8 * w);
+        if (LZ == 2) tot2 += lds_ld<double>(ring0 + 8 * (JOB_WAVES + w));
+      }
       lz.partial[blockIdx.x] = tot;
+      if (LZ == 2) lz.partial2[blockIdx.x] = tot2;
     }
   }
 }
@@ -409,12 +433,15 @@ hipError_t allow_lds(const void* kern, int bytes) {
 // workgroup at C4, so such plans do not run as jobs.
 constexpr int JOB_KIN = 24, JOB_KO = 8;
 
-template <int C, bool LZ, int KIN, int KO>
+template <int C, int LZ, int KIN, int KO>
 hipError_t launch_up_job_k(const DevSector& s, const DevTiles& t, const JobUp& jb, int lds_bytes, int64_t nwg, const LzEpilogue& lz,
                            hipStream_t st) {
   const bool norb1 = s.diag.cross.norb == 1;
-  void (*kern)(DevSector, DevTiles, JobUp, LzEpilogue);
-  if (s.real_h)
+  void (*kern)(DevSector, DevTiles, JobUp, LzEpilogue) = nullptr;
+  if constexpr (LZ == 2) {  // the paired epilogue exists for real H only
+    if (!s.real_h) return hipErrorInvalidValue;
+    kern = norb1 ? hxv_up_job<C, true, true, 2, KIN, KO, double2> : hxv_up_job<C, true, false, 2, KIN, KO, double2>;
+  } else if (s.real_h)
     kern = norb1 ? hxv_up_job<C, true, true, LZ, KIN, KO, double2> : hxv_up_job<C, true, false, LZ, KIN, KO, double2>;
   else
     kern = norb1 ? hxv_up_job<C, false, true, LZ, KIN, KO, double2> : hxv_up_job<C, false, false, LZ, KIN, KO, double2>;
@@ -424,7 +451,7 @@ hipError_t launch_up_job_k(const DevSector& s, const DevTiles& t, const JobUp& j
   return hipGetLastError();
 }
 
-template <int C, bool LZ>
+template <int C, int LZ>
 hipError_t launch_up_job_c(const DevSector& s, const DevTiles& t, const JobUp& jb, int lds_bytes, int64_t nwg, const LzEpilogue& lz,
                            hipStream_t st) {
   // fewer table registers when the longest in-block list / the out-of-block slot count allow it
@@ -493,7 +520,8 @@ hipError_t launch_up_job(const DevSector& s, const TilePlan& plan, const DevTile
   jb.wc = wc;
   // (two columns per tile were measured slower, and every such kernel spills vector and scalar registers: not built any more)
   if (plan.opt.job_cols != 1) return hipErrorInvalidValue;
-  return lz ? launch_up_job_c<1, true>(s, tu, jb, lds_bytes, nwg, *lz, st) : launch_up_job_c<1, false>(s, tu, jb, lds_bytes, nwg, LzEpilogue(), st);
+  if (lz && lz->pair) return launch_up_job_c<1, 2>(s, tu, jb, lds_bytes, nwg, *lz, st);
+  return lz ? launch_up_job_c<1, 1>(s, tu, jb, lds_bytes, nwg, *lz, st) : launch_up_job_c<1, 0>(s, tu, jb, lds_bytes, nwg, LzEpilogue(), st);
 }
 
 }  // namespace hxv

@@ -1117,7 +1117,8 @@ static bool use_job_up(const DevSector& s, const TilePlan& plan, bool real_vec, 
 }
 
 int64_t tiled_pass_up_workgroups(const DevSector& s, const TilePlan& plan, bool real_vec, bool pair) {
-  if (!pair && use_job_up(s, plan, real_vec, true, false)) return job_up_workgroups(s, plan);  // (the paired epilogue runs on the tile kernel)
+  (void)pair;  // (both epilogues run on the same kernel: jobs where they apply, else one tile per workgroup)
+  if (use_job_up(s, plan, real_vec, true, false)) return job_up_workgroups(s, plan);
   const int C = real_vec ? real_cols(plan) : cplx_cols(plan);
   const int ngroups = (s.qdw + C - 1) / C;
   return (int64_t)((ngroups + 7) / 8) * 8 * plan.up.nblocks;
@@ -1146,7 +1147,7 @@ static hipError_t launch_tiled_vt(const DevSector& s, const TilePlan& plan, cons
   // (with the job kernels pass A's tile width no longer constrains the scratch layout)
   int wc = wt_natural ? 0 : (RV ? real_wc(plan) : std::max(C, plan.opt.wt_cols));
   bool job_a = false;
-  if constexpr (!RV) job_a = (passes & 1) && !(lz && lz->pair) && use_job_up(s, plan, false, lz != nullptr, wt_natural, &wc);
+  if constexpr (!RV) job_a = (passes & 1) && use_job_up(s, plan, false, lz != nullptr, wt_natural, &wc);
   const int lds_a = std::max(plan.up.max_block * C * (int)sizeof(VT) + tu.nscoef * 16, plan.opt.lds_min_kb_up * 1024);
   const int lds_b = std::max(plan.dw.max_block * R * (int)sizeof(VT) + ((td.nscoef * 16 + 255) & ~255), plan.opt.lds_min_kb_dw * 1024);
   const int ta = plan.opt.threads_up, tb = plan.opt.threads_dw;

@@ -614,7 +614,7 @@ def test_lanczos_after_eigh_on_a_fresh_handle_c4(built):
 def test_paired_tridiagonalisation_is_two_single_runs_bit_for_bit(built, case):
     """hxv_lanczos_tridiag_pair: two REAL start vectors as Re / Im of one complex Lanczos vector (real H, H(x+iy) = Hx + iHy;
     the independent Green's-function channels of ED_GF_NORMAL.f90:123-306).  Every alanc/blanc equals, bit for bit, what
-    hxv_lanczos_tridiag gives for that start vector through the same kernels (real_vectors = 0, job_up = 0), and agrees with
+    hxv_lanczos_tridiag gives for that start vector through the same kernels (real_vectors = 0, same job_up), and agrees with
     the oracle's recurrence."""
     import torch
     import hxv
@@ -646,18 +646,19 @@ def test_paired_tridiagonalisation_is_two_single_runs_bit_for_bit(built, case):
     da = torch.from_numpy(xa.astype(np.complex128)).cuda()
     db = torch.from_numpy(xb.astype(np.complex128)).cuda()
     sec.set_option("lanczos_graph", 0)
-    (aa, ba, na), (ab, bb, nb) = sec.lanczos_tridiag_pair(da, db, nl)
-    assert sec.get_option("lanczos_real_last") == 2
     sec.set_option("real_vectors", 0)
-    sec.set_option("job_up", 0)
-    a1, b1, n1 = sec.lanczos_tridiag(da, nl)
-    a2, b2, n2 = sec.lanczos_tridiag(db, nl)
-    assert (na, nb) == (n1, n2)
-    if case == "breakdown_in_one":
-        assert na < 5 and nb > na
-    # bit-identical in every step both runs made (entries past a breakdown stay zero in both)
-    assert np.array_equal(aa[:na], a1[:n1]) and np.array_equal(ba[:na], b1[:n1]), (np.abs(aa - a1).max(), np.abs(ba - b1).max())
-    assert np.array_equal(ab[:nb], a2[:n2]) and np.array_equal(bb[:nb], b2[:n2]), (np.abs(ab - a2).max(), np.abs(bb - b2).max())
+    for job_up in (2, 0):   # the fused product as pipelined jobs (default, where the plan allows) and as one tile per workgroup
+        sec.set_option("job_up", job_up)
+        (aa, ba, na), (ab, bb, nb) = sec.lanczos_tridiag_pair(da, db, nl)
+        assert sec.get_option("lanczos_real_last") == 2
+        a1, b1, n1 = sec.lanczos_tridiag(da, nl)
+        a2, b2, n2 = sec.lanczos_tridiag(db, nl)
+        assert (na, nb) == (n1, n2)
+        if case == "breakdown_in_one":
+            assert na < 5 and nb > na
+        # bit-identical in every step both runs made (entries past a breakdown stay zero in both)
+        assert np.array_equal(aa[:na], a1[:n1]) and np.array_equal(ba[:na], b1[:n1]), (job_up, np.abs(aa - a1).max(), np.abs(ba - b1).max())
+        assert np.array_equal(ab[:nb], a2[:n2]) and np.array_equal(bb[:nb], b2[:n2]), (job_up, np.abs(ab - a2).max(), np.abs(bb - b2).max())
     if case != "breakdown_in_one":
         orc = OracleSector(m, nup, ndw)
         ar, br = orc.lanc_tridiag(xb.astype(np.complex128) / np.linalg.norm(xb), nl)
