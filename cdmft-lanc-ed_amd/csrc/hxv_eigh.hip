@@ -348,6 +348,11 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
   // exceeds GS_TAU*|w| -- in practice the kept Ritz vectors that are close to convergence, which is where a Lanczos basis
   // loses orthogonality (Paige).  The rest are rounding noise (<= 1e-13 relative): skipping them leaves the basis
   // orthogonal to ~1e-12 and saves about two thirds of the update traffic.
+  // The basis is stored UNNORMALISED where that saves a pass: slot i holds nv[i] * (the unit vector v_i).  A Lanczos step leaves its new
+  // vector as it comes out of the recurrence (nv = its norm = beta) and the next product divides in its epilogue; the projections below
+  // fold the factors into their coefficients (<v_i, w> = <V_i, w> / nv[i]; w -= <v_i, w> v_i = (<V_i, w> / nv[i]^2) V_i), the restart
+  // rotation into the rows of S.  c[] always holds the coefficients on the UNIT vectors.
+  std::vector<double> nv(MAXCV + 2, 1.0);
   std::vector<double> c(2 * (MAXCV + 1)), csel(2 * (MAXCV + 1));
   std::vector<int> isel(MAXCV + 1);
   auto gs_pass = [&](int jt, int nlock, bool all, double* nrm2_after) -> int {
@@ -360,6 +365,11 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
     if (int rca = comm_allreduce_sum(h, d_coef, (size_t)2 * nj, st)) return rca;
     HIPCHK(hipMemcpyAsync(c.data(), d_coef, (size_t)2 * nj * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    for (int i = 0; i < nj; ++i)
+      if (nv[i] != 1.0) {
+        c[2 * i] /= nv[i];
+        c[2 * i + 1] /= nv[i];
+      }
     double ssum = 0.0;
     for (int t = 0; t < 2 * nj; ++t) ssum += c[t] * c[t];
     const double thr2 = GS_TAU * GS_TAU * ssum;
@@ -367,8 +377,8 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
     for (int i = 0; i < nj; ++i)
       if (all || i < nlock || i + 1 >= jt || c[2 * i] * c[2 * i] + c[2 * i + 1] * c[2 * i + 1] > thr2) {
         isel[nsel] = i;
-        csel[2 * nsel] = c[2 * i];
-        csel[2 * nsel + 1] = c[2 * i + 1];
+        csel[2 * nsel] = c[2 * i] / nv[i];
+        csel[2 * nsel + 1] = c[2 * i + 1] / nv[i];
         ++nsel;
       }
     HIPCHK(hipMemcpyAsync(d_csel, csel.data(), (size_t)2 * nsel * sizeof(double), hipMemcpyHostToDevice, st));
@@ -410,8 +420,10 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
     for (int i = 0; i < nsel; ++i) {
       const int iv = i < nlock ? i : b0 + (i - nlock);
       isel[i] = iv;
-      c[2 * iv] = csel[2 * i];
-      c[2 * iv + 1] = csel[2 * i + 1];
+      c[2 * iv] = csel[2 * i] / nv[iv];
+      c[2 * iv + 1] = csel[2 * i + 1] / nv[iv];
+      csel[2 * i] = c[2 * iv] / nv[iv];
+      csel[2 * i + 1] = c[2 * iv + 1] / nv[iv];
     }
     HIPCHK(hipMemcpyAsync(d_csel, csel.data(), (size_t)2 * nsel * sizeof(double), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d_isel, isel.data(), (size_t)nsel * sizeof(int), hipMemcpyHostToDevice, st));
@@ -423,10 +435,49 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
     return HXV_OK;
   };
 
+  // A fused step of a LOCKING round: the product's epilogue has already removed beta_j v_{j-1} from w = V[jt+1] and measured alpha_j;
+  // here the projections on the locked eigenvectors are measured and removed together with alpha_j v_j in ONE update pass.
+  auto gs_locked_alpha = [&](int jt, int nlock, double alpha, double* nrm2_after) -> int {
+    for (int g0 = 0; g0 < nlock; g0 += JB) {
+      const int nl = std::min(JB, nlock - g0);
+      hipLaunchKernelGGL(tr_mdot, dim3(g), dim3(256), 0, st, n, vec(g0), n, nl, vec(jt + 1), d_part);
+      hipLaunchKernelGGL(tr_colsum, dim3(1), dim3(256), 0, st, d_part, g, 2 * JB, 2 * nl, d_coef + 2 * g0, real ? 1 : 0);
+    }
+    if (int rca = comm_allreduce_sum(h, d_coef, (size_t)2 * nlock, st)) return rca;
+    HIPCHK(hipMemcpyAsync(csel.data(), d_coef, (size_t)2 * nlock * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int i = 0; i < nlock; ++i) {
+      isel[i] = i;
+      c[2 * i] = csel[2 * i] / nv[i];
+      c[2 * i + 1] = csel[2 * i + 1] / nv[i];
+      csel[2 * i] = c[2 * i] / nv[i];
+      csel[2 * i + 1] = c[2 * i + 1] / nv[i];
+    }
+    isel[nlock] = jt;
+    csel[2 * nlock] = alpha / nv[jt];
+    csel[2 * nlock + 1] = 0.0;
+    const int nsel = nlock + 1;
+    HIPCHK(hipMemcpyAsync(d_csel, csel.data(), (size_t)2 * nsel * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_isel, isel.data(), (size_t)nsel * sizeof(int), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(tr_maxpy, dim3(g), dim3(256), 0, st, n, V, n, nsel, d_isel, d_csel, vec(jt + 1), d_npart);
+    hipLaunchKernelGGL(tr_colsum, dim3(1), dim3(256), 0, st, d_npart, g, 1, 1, d_nrm, 0);
+    if (int rca = comm_allreduce_sum(h, d_nrm, 1, st)) return rca;
+    HIPCHK(hipMemcpyAsync(nrm2_after, d_nrm, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return HXV_OK;
+  };
+  // bring a stored vector to unit length where a kernel needs it so (the plain product, the start of a round)
+  auto normalise_slot = [&](int i) {
+    if (nv[i] != 1.0) {
+      hipLaunchKernelGGL(tr_scale_nrm, dim3(g), dim3(256), 0, st, n, vec(i), 1.0 / nv[i], (double*)nullptr);
+      nv[i] = 1.0;
+    }
+  };
+
   // Thick-restart Lanczos for the `nwant` lowest pairs of H restricted to the orthogonal complement of the `nlock`
   // LOCKED eigenvectors V[0..nlock) (nlock = 0: H itself).  The active basis is V[nlock..nlock+ma]; on return its first
   // `ne` vectors are the Ritz vectors of theta[0..ne).
-  std::vector<double> T, A, theta, S;
+  std::vector<double> T, A, theta, S, Ssc;
   std::vector<double> lockval;  // eigenvalues of the locked vectors V[0..nlock)
   int nmv = 0, nconv = 0, ne = neigen;
   int n_full = 0, n_local = 0;  // Gram-Schmidt passes against the whole basis / against the two local vectors only
@@ -440,6 +491,7 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
     auto av = [&](int j) { return vec(nlock + j); };
     T.assign((size_t)ma * ma, 0.0);
     auto t_at = [&](int i, int j) -> double& { return T[i + (size_t)j * ma]; };
+    for (int i = nlock; i <= m; ++i) nv[i] = 1.0;  // (the locked vectors are unit vectors: every round ends with a rotation)
     // start vector (deterministic hash of the global index; a different seed per round), made orthogonal to the locked set
     if (real)
       launch_init_real(h, (double*)av(0), seed, st);
@@ -470,19 +522,23 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
         // a step that is known in advance to need only the two local projections runs through the fused product: pass A
         // subtracts beta_j q_{j-1} and reduces alpha_j in its epilogue, one more pass subtracts alpha_j q_j and measures |w|
         // (not in the locking rounds: there every step also removes the locked eigenvectors, see gs_local)
-        const bool fused_local = local_fused && !h->eigh_measure_all && j > k && !force_full && nlock == 0;
+        const bool fused_local = local_fused && !h->eigh_measure_all && j > k && !force_full;
         int rc;
         double w2 = 0.0;
         if (fused_local) {
           double al = 0.0, nw = 0.0;
-          rc = lanczos_local_step(h, real, av(j), av(j - 1), t_at(j, j - 1), av(j + 1), &al, &nw);
+          rc = lanczos_local_step(h, real, av(j), nv[jt], av(j - 1), nv[jt - 1], t_at(j, j - 1), av(j + 1), nlock == 0, &al, &nw);
           if (rc) return rc;
           c[2 * jt] = al;
           c[2 * jt + 1] = 0.0;
           c[2 * (jt - 1)] = t_at(j, j - 1);
           c[2 * (jt - 1) + 1] = 0.0;
-          w2 = nw * nw;
+          if (nlock == 0)
+            w2 = nw * nw;
+          else if ((rc = gs_locked_alpha(jt, nlock, al, &w2)))
+            return rc;
         } else {
+          normalise_slot(jt);
           rc = real ? apply_slab_real(h, (const double*)av(j), (double*)av(j + 1), st) : apply_slab(h, av(j), av(j + 1), st);
           if (rc) return rc;
         }
@@ -510,7 +566,7 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
           for (int t = 0; t < 2 * (jt + 1); ++t) c2sum += c[t] * c[t];
         else
           c2sum = c[2 * jt] * c[2 * jt] + c[2 * jt + 1] * c[2 * jt + 1] + (j > k ? c[2 * (jt - 1)] * c[2 * (jt - 1)] + c[2 * (jt - 1) + 1] * c[2 * (jt - 1) + 1] : 0.0);
-        if (!full && !fused_local)
+        if (!full)
           for (int b = 0; b < nlock; ++b) c2sum += c[2 * b] * c[2 * b] + c[2 * b + 1] * c[2 * b + 1];
         double nrm = std::sqrt(std::max(w2, 0.0));
         bool was_forced = force_full;
@@ -592,7 +648,7 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
         }
         if (j + 1 < ma) t_at(j + 1, j) = t_at(j, j + 1) = nrm;
         beta_last = nrm;
-        hipLaunchKernelGGL(tr_scale_nrm, dim3(g), dim3(256), 0, st, n, av(j + 1), 1.0 / nrm, (double*)nullptr);
+        nv[jt + 1] = nrm;  // left unnormalised: the next product (or whoever needs a unit vector) divides
       }
       A.assign((size_t)meff * meff, 0.0);
       for (int a = 0; a < meff; ++a)
@@ -619,10 +675,16 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
       }
       if (nconv == ne || closed || it >= maxrestart) break;
       k = keep_count(ma, nwant, nconv);
-      HIPCHK(hipMemcpyAsync(d_S, S.data(), (size_t)ma * k * sizeof(double), hipMemcpyHostToDevice, st));
+      // Ritz vectors = (stored vectors) * diag(1/nv) * S
+      Ssc.assign(S.begin(), S.begin() + (size_t)ma * k);
+      for (int i = 0; i < k; ++i)
+        for (int l = 0; l < ma; ++l) Ssc[l + (size_t)i * ma] /= nv[nlock + l];
+      HIPCHK(hipMemcpyAsync(d_S, Ssc.data(), (size_t)ma * k * sizeof(double), hipMemcpyHostToDevice, st));
       launch_rotate(g, st, n, Va, n, ma, k, d_S);
       HIPCHK(hipMemcpyAsync(av(k), av(ma), (size_t)n * sizeof(double2), hipMemcpyDeviceToDevice, st));
-      HIPCHK(hipStreamSynchronize(st));  // S (host) is reused below
+      HIPCHK(hipStreamSynchronize(st));  // Ssc (host) is reused at the next restart
+      for (int i = 0; i < k; ++i) nv[nlock + i] = 1.0;
+      nv[nlock + k] = nv[nlock + ma];
       if (!h->eigh_measure_all) {
         // The residual vector inherits whatever orthogonality the old basis had lost against the directions that are now
         // the kept Ritz vectors: clean it once per restart, so that the estimates of the new cycle start from rounding
@@ -631,7 +693,7 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
         int rcr = gs_pass(nlock + k - 1, nlock, true, &r2);
         if (rcr) return rcr;
         ++n_full;
-        if (r2 > 0.0) hipLaunchKernelGGL(tr_scale_nrm, dim3(g), dim3(256), 0, st, n, av(k), 1.0 / std::sqrt(r2), (double*)nullptr);
+        if (r2 > 0.0) nv[nlock + k] = std::sqrt(r2);  // (its length after the clean-up; it stays unnormalised)
       }
       std::fill(T.begin(), T.end(), 0.0);
       theta_keep.assign(k, 0.0);
@@ -648,9 +710,13 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
     }
     if (above) return HXV_OK;
     // Ritz vectors of the wanted pairs to the front of the active basis
-    HIPCHK(hipMemcpyAsync(d_S, S.data(), (size_t)meff * ne * sizeof(double), hipMemcpyHostToDevice, st));
+    Ssc.assign(S.begin(), S.begin() + (size_t)meff * ne);
+    for (int i = 0; i < ne; ++i)
+      for (int l = 0; l < meff; ++l) Ssc[l + (size_t)i * meff] /= nv[nlock + l];
+    HIPCHK(hipMemcpyAsync(d_S, Ssc.data(), (size_t)meff * ne * sizeof(double), hipMemcpyHostToDevice, st));
     launch_rotate(g, st, n, Va, n, meff, ne, d_S);
     HIPCHK(hipStreamSynchronize(st));
+    for (int i = 0; i < ne; ++i) nv[nlock + i] = 1.0;
     return HXV_OK;
   };
 

@@ -36,7 +36,8 @@ void launch_to_complex(const hxv_handle* h, const double* src, double2* dst, hip
 void launch_init_real(const hxv_handle* h, double* q, uint64_t seed, hipStream_t st);
 // one Lanczos step on normalised vectors through the fused product (hxv_lanczos.hip): w = H q - beta*qm, alpha = <q,w>, w -= alpha*q, |w|
 bool lanczos_local_step_available(const hxv_handle* h);
-int lanczos_local_step(hxv_handle* h, bool real, const double2* q, const double2* qm, double beta, double2* w, double* alpha, double* nrm_w);
+int lanczos_local_step(hxv_handle* h, bool real, const double2* q, double sq, const double2* qm, double sqm, double beta, double2* w,
+                       bool sub_alpha, double* alpha, double* nrm_w);
 }  // namespace hxv
 
 #define HIPCHK(expr)                                                                                   \

@@ -597,7 +597,12 @@ bool lanczos_local_step_available(const hxv_handle* h) {
   return h->kernel == 1 && h->plan.usable && !h->dev.nd.active && h->plan.opt.passes == 3 && h->plan.opt.debug == 0 && h->lz_fused;
 }
 
-int lanczos_local_step(hxv_handle* h, bool real, const double2* q, const double2* qm, double beta, double2* w, double* alpha, double* nrm_w) {
+// One Lanczos step on an UNNORMALISED pair: q = sq * (unit q_j), qm = sqm * (unit q_{j-1}).  The product's epilogue stores
+//   w = H q / sq - (beta / sqm) qm   and reduces   alpha = <q / sq, w>;
+// with sub_alpha one more pass subtracts alpha (q / sq) and measures |w|, otherwise w is left as it is and *nrm_w is not set (the caller
+// subtracts alpha together with other projections).  Scale factors 1.0 reproduce the normalised step bit for bit.
+int lanczos_local_step(hxv_handle* h, bool real, const double2* q, double sq, const double2* qm, double sqm, double beta, double2* w,
+                       bool sub_alpha, double* alpha, double* nrm_w) {
   const int64_t n2 = real ? (int64_t)pitch_real_of(h) * h->host.qdw / 2 : (int64_t)h->host.pitch * h->host.qdw;
   const int g = grid_for(n2);
   const int64_t nwg = std::max<int64_t>(1, tiled_pass_up_workgroups(h->dev, h->plan, real));
@@ -609,7 +614,7 @@ int lanczos_local_step(hxv_handle* h, bool real, const double2* q, const double2
     HIPCHK(hipMemsetAsync(h->d_lz_partial, 0, (size_t)nwg * sizeof(double), h->stream));
     h->lz_partial_n = nwg;
   }
-  const double sc[2] = {1.0, qm ? beta : 0.0};
+  const double sc[2] = {1.0 / sq, qm ? beta / sqm : 0.0};
   HIPCHK(hipMemcpyAsync(h->d_scalars + 2, sc, 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
   LzEpilogue ep;
   ep.xm = qm;
@@ -621,14 +626,17 @@ int lanczos_local_step(hxv_handle* h, bool real, const double2* q, const double2
   if (rc) return rc;
   rc = reduce_scalar(h, h->d_lz_partial, (int)nwg, 0, 0);
   if (rc) return rc;
-  hipLaunchKernelGGL(lz_sub_nrm, dim3(g), dim3(256), 0, h->stream, n2, w, q, h->d_scalars, 0, h->d_partials + RED_BLOCKS);
-  rc = reduce_scalar(h, h->d_partials + RED_BLOCKS, g, 1, 1);
-  if (rc) return rc;
-  double host[2];
-  HIPCHK(hipMemcpyAsync(host, h->d_scalars, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (sub_alpha) {
+    hipLaunchKernelGGL(lz_mul, dim3(1), dim3(1), 0, h->stream, h->d_scalars, 4, 0, 2);  // alpha / sq: the coefficient of the stored q
+    hipLaunchKernelGGL(lz_sub_nrm, dim3(g), dim3(256), 0, h->stream, n2, w, q, h->d_scalars, 4, h->d_partials + RED_BLOCKS);
+    rc = reduce_scalar(h, h->d_partials + RED_BLOCKS, g, 1, 1);
+    if (rc) return rc;
+  }
+  double host[2] = {0.0, 0.0};
+  HIPCHK(hipMemcpyAsync(host, h->d_scalars, (sub_alpha ? 2 : 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   *alpha = host[0];
-  *nrm_w = host[1];
+  if (sub_alpha && nrm_w) *nrm_w = host[1];
   return HXV_OK;
 }
 
