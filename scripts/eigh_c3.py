@@ -13,11 +13,14 @@ sec.set_option("eigh_measure_all", int(os.environ.get("MEASURE_ALL", 0)))
 sec.set_option("lanczos_fused", int(os.environ.get("FUSED", 1)))
 sec.set_option("real_vectors", int(os.environ.get("REAL_VECTORS", 1)))
 neigen, ncv = int(os.environ.get("NEIGEN", 2)), int(os.environ.get("NCV", 20))
-t = time.time()
-ev, X, nconv, nmv = sec.eigh_lowest(neigen, ncv, native=True)
-torch.cuda.synchronize()
-dt = time.time() - t
-print(f"{wl} eigh_lowest neigen={neigen} ncv={ncv}: E={ev} nconv={nconv} matvecs={nmv} {dt:.2f}s ({dt / nmv * 1e3:.1f} ms per Lanczos step)", flush=True)
+for rep in range(int(os.environ.get("REPS", 1))):  # (a second run finds the Krylov basis in the engine's buffer cache)
+    t = time.time()
+    ev, X, nconv, nmv = sec.eigh_lowest(neigen, ncv, native=True)
+    torch.cuda.synchronize()
+    dt = time.time() - t
+    print(f"{wl} eigh_lowest neigen={neigen} ncv={ncv}: E={ev} nconv={nconv} matvecs={nmv} {dt:.2f}s ({dt / nmv * 1e3:.1f} ms per Lanczos step)", flush=True)
+    if rep + 1 < int(os.environ.get("REPS", 1)):
+        del X
 hv = sec.apply_device(X[0].contiguous())
 r = (hv - ev[0] * X[0]).norm().item()
 print(f"  residual |H x0 - E0 x0| = {r:.2e}", flush=True)
