@@ -267,7 +267,9 @@ int hxv_apply_device(hxv_handle* h, const void* d_v_full, void* d_hv_local, void
     if (rcw) return rcw;
     e = launch_hxv_tiled(h->dev, h->plan, (const double2*)d_v_full, h->d_wt, (double2*)d_hv_local, st);
   }
-  if (e == hipSuccess && h->dev.nd.active) e = launch_hxv_nonlocal(h->dev, (const double2*)d_v_full, (double2*)d_hv_local, st);
+  // (the tiled product adds the spH0nd block in its pass A when the move tables exist)
+  const bool nd_done = h->kernel != 0 && h->plan.usable && nd_folds(h->dev) && (h->plan.opt.passes & 1);
+  if (e == hipSuccess && h->dev.nd.active && !nd_done) e = launch_hxv_nonlocal(h->dev, (const double2*)d_v_full, (double2*)d_hv_local, st);
   if (e != hipSuccess) return fail(HXV_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
   h->n_apply++;
   return HXV_OK;
@@ -450,6 +452,10 @@ int hxv_set_option(hxv_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "passes")) {
     if (value < 1 || value > 3) return fail(HXV_ERR_ARG, "passes must be 1, 2 or 3");
     h->plan.opt.passes = (int)value;
+    return HXV_OK;
+  }
+  if (!strcmp(name, "fold_nd")) {  // spH0nd inside pass A (default) or as its own pass over hv
+    h->dev.nd.fold = h->host.nd.fold = value ? 1 : 0;
     return HXV_OK;
   }
   // tiling knobs: rebuild the plan (old tables stay allocated until hxv_destroy)

@@ -52,6 +52,7 @@ struct NonLocalParams {
   int32_t active = 0;  // Jhflag: Norb>1 and (Jx or Jp) != 0, ED_SETUP.f90:200-201
   int32_t nlat = 0, norb = 0;
   double jx = 0, jp = 0;
+  int32_t fold = 1;    // added inside pass A of the tiled product (option "fold_nd"; 0: a separate pass over hv afterwards)
 };
 
 struct SectorHost {
@@ -141,6 +142,8 @@ hipError_t launch_ladder(const uint32_t* map_from, int dim_from, const uint32_t*
                          double2 coef = double2{1.0, 0.0}, int accumulate = 0);
 // d_out[k*pitch + i] = d_in[cols[k]*pitch + i]: the columns a peer needs, packed for the halo exchange
 hipError_t launch_pack_columns(const double2* d_in, double2* d_out, const int32_t* d_cols, int ncols, int pitch, hipStream_t st);
+// true: the tiled product adds the spH0nd block itself (pass A, hxv_tiled.hip); false: launch_hxv_nonlocal after the product
+inline bool nd_folds(const DevSector& s) { return s.nd.active && s.nd_up && s.nd_dw && s.nd.fold; }
 hipError_t launch_hxv_nonlocal(const DevSector& s, const double2* v_full, double2* hv_local, hipStream_t st);
 
 }  // namespace hxv

@@ -381,7 +381,7 @@ struct LzRunner {
 
   LzRunner(hxv_handle* hh, double2* x, double2* xm, double2* w, bool real_vec = false) : h(hh), b{x, xm, w}, real(real_vec) {
     // (split sectors included: the epilogue's partial sums are this rank's share, alpha and beta are all-reduced)
-    fused = hh->kernel == 1 && hh->plan.usable && !hh->dev.nd.active && hh->plan.opt.passes == 3 && hh->plan.opt.debug == 0 && hh->lz_fused;
+    fused = hh->kernel == 1 && hh->plan.usable && (!hh->dev.nd.active || nd_folds(hh->dev)) && hh->plan.opt.passes == 3 && hh->plan.opt.debug == 0 && hh->lz_fused;
     // (local slab: qdw == DimDw on an unsplit sector)
     n2 = real ? (int64_t)pitch_real_of(hh) * hh->host.qdw / 2 : (int64_t)hh->host.pitch * hh->host.qdw;
     hh->last_real = real ? 1 : 0;
@@ -594,7 +594,7 @@ void launch_to_complex(const hxv_handle* h, const double* src, double2* dst, hip
 // pass A's epilogue (qm may be null), alpha = <q,w> from its partial sums, then w -= alpha*q and |w|.  False if the fused
 // product does not apply to this handle (the caller then measures the two projections itself).
 bool lanczos_local_step_available(const hxv_handle* h) {
-  return h->kernel == 1 && h->plan.usable && !h->dev.nd.active && h->plan.opt.passes == 3 && h->plan.opt.debug == 0 && h->lz_fused;
+  return h->kernel == 1 && h->plan.usable && (!h->dev.nd.active || nd_folds(h->dev)) && h->plan.opt.passes == 3 && h->plan.opt.debug == 0 && h->lz_fused;
 }
 
 // One Lanczos step on an UNNORMALISED pair: q = sq * (unit q_j), qm = sqm * (unit q_{j-1}).  The product's epilogue stores

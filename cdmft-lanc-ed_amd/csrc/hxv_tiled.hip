@@ -25,7 +25,12 @@ namespace hxv {
 //  12 -- and every such plan was slower at C3, C4 and C5 (profiles/r03_ab_mr_*.log): one row per thread it stays.)
 // LZ: 0 plain product, 1 Lanczos epilogue, 2 PAIRED Lanczos epilogue (real H, complex vectors): the real and the imaginary part
 // are two independent real Lanczos vectors (H(x + iy) = Hx + iHy), each with its own scalars and its own partial sums.
-template <int C, bool REAL, bool NORB1, int LZ, bool P16, typename VT>
+// ND: the spin-exchange / pair-hopping block spH0nd (Jx, Jp; sparse/H_non_local.f90:23-98, ED_HAMILTONIAN_SPARSE_HxV.f90:217-225) is
+// added here instead of in a third read-modify-write pass over hv: its terms are Kronecker products of two one-body moves on a site, so
+// an element's partner is (up move of the row) x (dw move of the column) -- the up moves of a row serve all C columns of the tile, the dw
+// moves of a column are uniform scalars, the partner values come from one other column of the gathered vector (rows of the same block:
+// the moves only touch impurity orbitals, the lowest bits).
+template <int C, bool REAL, bool NORB1, int LZ, bool P16, typename VT, bool ND = false>
 __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, const VT* __restrict__ v,
                                                       const VT* __restrict__ wt, VT* __restrict__ hv, int ngroups,
                                                       int groups_per_xcd, int wc, LzEpilogue lz) {
@@ -61,6 +66,26 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
     for (int r = threadIdx.x; r < n; r += T) lds[cc * n + r] = src[r];
   }
   for (int q = threadIdx.x; q < t.nscoef; q += T) lcoef[q] = Coef<REAL>::from(t.scoef[q]);
+  uint32_t* lrq = reinterpret_cast<uint32_t*>(lcoef + t.nscoef);  // (ND only; the launcher adds the bytes)
+  const int nvp = ND ? s.nd.nlat * s.nd.norb * (s.nd.norb - 1) : 0;  // ordered pairs of different orbitals of a site
+  uint32_t* lnd = lrq + nvp;
+  if constexpr (ND) {
+    const int O = s.nd.norb;
+    for (int idx = threadIdx.x; idx < nvp * 2 * C; idx += T) {
+      const int pp = idx / (2 * C), kind = (idx / C) & 1, cc = idx % C;
+      const int il = pp / (O * (O - 1)), rem = pp % (O * (O - 1)), io = rem / (O - 1);
+      int jo = rem % (O - 1);
+      jo += jo >= io ? 1 : 0;
+      const int q = (il * O + io) * O + jo, rq = (il * O + jo) * O + io;
+      const int c = s.dw0 + min(c0 + cc, s.qdw - 1);
+      // dw: spin exchange moves i -> j (entry q), pair hopping j -> i (entry rq); up (both terms): j -> i (entry rq)
+      uint32_t w = ND_INVALID;
+      if (kind == 0 && s.nd.jx != 0.0) w = s.nd_dw[(int64_t)q * s.dimdw + c];
+      if (kind == 1 && s.nd.jp != 0.0) w = s.nd_dw[(int64_t)rq * s.dimdw + c];
+      lnd[idx] = w;
+      if (kind == 0 && cc == 0) lrq[pp] = (uint32_t)rq;
+    }
+  }
   const uint32_t p16m = (1u << t.p16_bits) - 1u;  // half-size table words: (coefficient index << p16_bits) | offset
   double asum = 0.0;
   // one row per thread (the plan guarantees n <= blockDim.x)
@@ -155,6 +180,38 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
           const VT* __restrict__ src = vcol0 + t.rs_base[sl] + (e & TILE_OFF_MASK);
 #pragma unroll
           for (int cc = 0; cc < C; ++cc) Coef<REAL>::fma(acc[cc], cf, src[(int64_t)min(cc, nc - 1) * s.pitch]);
+        }
+      }
+    }
+    if constexpr (ND) {
+      // lrq / lnd (LDS, filled with the tile): per ordered orbital pair p of a site, the up-move table row and, per column of the tile, the
+      // dw partner columns of the two terms -- uniform values, read back as scalars; a term the column's dw state rules out costs nothing.
+      // Lanes whose up state rules the move out fetch their own row with a zero coefficient (no lane-divergent branch around a load).
+      for (int p0 = 0; p0 < nvp; p0 += 8) {
+        uint32_t u[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (p0 + k < nvp) u[k] = s.nd_up[(int64_t)__builtin_amdgcn_readfirstlane(lrq[p0 + k]) * s.dimup + i];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          if (p0 + k < nvp) {
+            const bool upok = u[k] != ND_INVALID;
+            const int64_t jup = upok ? (int64_t)(u[k] & 0x7FFFFFFFu) : (int64_t)r0;  // (idle lanes: one shared address)
+            uint32_t dw[2 * C];  // the pair's partner columns for the C columns of the tile: one batch of LDS reads
+#pragma unroll
+            for (int e = 0; e < 2 * C; ++e) dw[e] = lnd[(p0 + k) * 2 * C + e];
+#pragma unroll
+            for (int e = 0; e < 2 * C; ++e) dw[e] = __builtin_amdgcn_readfirstlane(dw[e]);
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc) {
+              const uint32_t dse = dw[cc], dph = dw[C + cc];
+              VT x1 = vzero<VT>(), x2 = vzero<VT>();
+              if (dse != ND_INVALID) x1 = v[(int64_t)(dse & 0x7FFFFFFFu) * s.pitch + jup];
+              if (dph != ND_INVALID) x2 = v[(int64_t)(dph & 0x7FFFFFFFu) * s.pitch + jup];
+              if (dse != ND_INVALID) Coef<true>::fma(acc[cc], upok ? (((u[k] ^ dse) >> 31) ? -s.nd.jx : s.nd.jx) : 0.0, x1);
+              if (dph != ND_INVALID) Coef<true>::fma(acc[cc], upok ? (((u[k] ^ dph) >> 31) ? -s.nd.jp : s.nd.jp) : 0.0, x2);
+            }
+          }
         }
       }
     }
@@ -935,6 +992,9 @@ hipError_t allow_dynamic_lds(const void* kern, int bytes) {
   return e;
 }
 
+// the spH0nd block is folded into pass A when its move tables exist (hxv_sector.cpp builds them up to 32 M entries per spin)
+static bool fold_nd(const DevSector& s) { return nd_folds(s); }
+
 template <int C, int LZ, typename VT>
 hipError_t launch_up_lz(const DevSector& s, const DevTiles& t, int lds_bytes, int threads, bool norb1, int wc, const VT* v,
                         const VT* wt, VT* hv, const LzEpilogue& lz, hipStream_t st) {
@@ -969,6 +1029,14 @@ hipError_t launch_up_lz(const DevSector& s, const DevTiles& t, int lds_bytes, in
       kern = norb1 ? hxv_pass_up<C, false, true, LZ, true, double2> : hxv_pass_up<C, false, false, LZ, true, double2>;
     else
       kern = norb1 ? hxv_pass_up<C, false, true, LZ, false, double2> : hxv_pass_up<C, false, false, LZ, false, double2>;
+  }
+  if constexpr (std::is_same<VT, double2>::value && C <= 4 && LZ != 2) {
+    if (fold_nd(s) && !norb1) {  // the spH0nd block rides along (Norb > 1: never the one-orbital diagonal)
+      if (s.real_h)
+        kern = p16 ? hxv_pass_up<C, true, false, LZ, true, double2, true> : hxv_pass_up<C, true, false, LZ, false, double2, true>;
+      else
+        kern = p16 ? hxv_pass_up<C, false, false, LZ, true, double2, true> : hxv_pass_up<C, false, false, LZ, false, double2, true>;
+    }
   }
   lds_bytes = std::max(lds_bytes, 32 * 8);  // the epilogue reduces through LDS: 16 (+16 paired) doubles
   hipError_t e = allow_dynamic_lds((const void*)kern, lds_bytes);
@@ -1101,6 +1169,7 @@ static int real_wc(const TilePlan& plan) { return std::max(real_cols(plan), std:
 // Pass A runs as jobs (hxv_jobs.hip) when the plan allows it and the tile ring fits the LDS; wc_out = scratch group width.
 static bool use_job_up(const DevSector& s, const TilePlan& plan, bool real_vec, bool lz, bool wt_natural, int* wc_out = nullptr) {
   if (real_vec || !plan.opt.job_up || plan.opt.sort_mode != 0 || plan.opt.debug != 0 || !job_up_usable(s, plan)) return false;
+  if (s.nd.active) return false;  // (the spH0nd block rides on the one-tile-per-workgroup kernel only)
   // job_up = 2 (default): jobs for the fused Lanczos product only.  With the in-block tables shared between blocks of a class
   // the one-tile-per-workgroup kernel is 2 % faster for the plain product (2.22 against 2.27 ms at C3), the job kernel 2.5 %
   // faster with the Lanczos epilogue, whose second input vector it streams through the tile ring (6.29 against 6.45 ms).
@@ -1148,7 +1217,9 @@ static hipError_t launch_tiled_vt(const DevSector& s, const TilePlan& plan, cons
   int wc = wt_natural ? 0 : (RV ? real_wc(plan) : std::max(C, plan.opt.wt_cols));
   bool job_a = false;
   if constexpr (!RV) job_a = (passes & 1) && use_job_up(s, plan, false, lz != nullptr, wt_natural, &wc);
-  const int lds_a = std::max(plan.up.max_block * C * (int)sizeof(VT) + tu.nscoef * 16, plan.opt.lds_min_kb_up * 1024);
+  // (folded spH0nd block: one table row index and 2*C partner-column words per ordered orbital pair of a site, behind the coefficients)
+  const int lds_nd = nd_folds(s) ? s.nd.nlat * s.nd.norb * (s.nd.norb - 1) * (2 * C + 1) * 4 : 0;
+  const int lds_a = std::max(plan.up.max_block * C * (int)sizeof(VT) + tu.nscoef * 16 + lds_nd, plan.opt.lds_min_kb_up * 1024);
   const int lds_b = std::max(plan.dw.max_block * R * (int)sizeof(VT) + ((td.nscoef * 16 + 255) & ~255), plan.opt.lds_min_kb_dw * 1024);
   const int ta = plan.opt.threads_up, tb = plan.opt.threads_dw;
   const bool norb1 = s.diag.mode == 0 && s.diag.cross.norb == 1;

@@ -168,6 +168,23 @@ def test_fused_and_plain_recurrence_agree(built):
     assert n0 == n1 == 60
     assert np.abs(a1 - a0).max() <= 1e-10 * np.abs(a0).max()
     assert np.abs(b1 - b0).max() <= 1e-10 * np.abs(b0).max()
+    sec.close()
+    # with the Jx / Jp block: folded into pass A the fused recurrence covers it too; as its own pass the plain recurrence runs
+    m = models.bhz_2d(Nbath=1, Ust=0.5, Jh=0.1, Jx=0.2, Jp=0.1)   # Ns = 12
+    sec = hxv.HxvSector.from_model(m, 6, 5)
+    v = models.deterministic_vector(sec.Dim)
+    v /= np.linalg.norm(v)
+    dv = torch.from_numpy(v).cuda()
+    runs = []
+    for fold, fused in ((1, 1), (1, 0), (0, 1)):
+        sec.set_option("fold_nd", fold)
+        sec.set_option("lanczos_fused", fused)
+        runs.append(sec.lanczos_tridiag(dv, 40))
+    for a, b, n in runs[1:]:
+        assert n == runs[0][2] == 40
+        assert np.abs(a - runs[0][0]).max() <= 1e-10 * np.abs(runs[0][0]).max()
+        assert np.abs(b - runs[0][1]).max() <= 1e-10 * np.abs(runs[0][1]).max()
+    sec.close()
 
 
 @pytest.mark.parametrize("spin,create", [(0, True), (0, False), (1, True), (1, False)])

@@ -512,3 +512,36 @@ def test_c5_ns18_slab_matches_oracle_matrices(built):
     ref = np.asarray(out).reshape(-1, order="F")
     assert _rel(hv.cpu().numpy(), ref) <= TOL
     sec.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shard", [(0, 1), (1, 2)])
+def test_spH0nd_inside_pass_a_and_as_its_own_pass_match_the_oracle(built, shard):
+    """The Jx / Jp block (sparse/H_non_local.f90:23-98, ED_HAMILTONIAN_SPARSE_HxV.f90:217-225) is added inside pass A of the tiled
+    product (option "fold_nd" = 1, default) or by its own pass over hv afterwards (0): both against the oracle's spH0nd CSR, for real
+    and complex one-body amplitudes, every tile width, unsplit and split."""
+    import torch
+    import hxv
+    from hxv import models
+    from oracle.oracle import OracleSector
+
+    rank, size = shard
+    cases = ((models.bhz_2d(Nbath=0, Ust=0.7, Jh=0.2, Jx=0.2, Jp=0.15), (4, 4)),        # complex amplitudes
+             (models.bhz_2d(Nbath=1, Ust=0.5, Jh=0.1, Jx=0.0, Jp=0.3), (5, 6)),         # pair hopping only, 12 orbitals
+             (models.bhz_2d(Nbath=0, Ust=0.3, Jh=0.1, Jx=-0.4, Jp=0.0, lam=0.0), (3, 4)))  # spin exchange only
+    for m, (nup, ndw) in cases:
+        sec = hxv.HxvSector.from_model(m, nup, ndw, rank=rank, nranks=size)
+        orc = OracleSector(m, nup, ndw, rank, size)
+        v = models.deterministic_vector(sec.Dim)
+        ref = _slab_reference(orc, v)
+        dv = torch.from_numpy(sec.to_gather_layout(v, size)).cuda()
+        outs = []
+        for fold in (1, 0):
+            for cols in (2, 4):
+                sec.set_option("fold_nd", fold)
+                sec.set_option("cols_per_tile", cols)
+                got = sec.unpad(sec.apply_device(dv)).cpu().numpy()
+                assert _rel(got, ref) <= TOL, (m.name, fold, cols)
+                outs.append(got)
+        assert np.abs(outs[0] - outs[2]).max() <= 1e-14 * max(1.0, np.abs(ref).max())
+        sec.close()
