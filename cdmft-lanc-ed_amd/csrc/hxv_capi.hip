@@ -112,6 +112,9 @@ int finish_create(hxv_handle* h, int device, hxv_handle** out) {
   d.vcol_identity = (s.nranks == 1) ? 1 : 0;
   d.nd = s.nd;
   d.nd_up = d.nd_dw = nullptr;
+  d.ndcsr_rowptr = nullptr;
+  d.ndcsr_cols = nullptr;
+  d.ndcsr_vals = nullptr;
   if (!s.nd_up.empty()) {
     uint32_t *ndu = nullptr, *ndd = nullptr;
     HC(h->upload(&ndu, s.nd_up));
@@ -194,6 +197,44 @@ int hxv_create_from_csr(int32_t dimup, int32_t dimdw, const int64_t* up_rowptr, 
     return fail(HXV_ERR_ARG, "hxv_create_from_csr: " + e);
   }
   return finish_create(h, device, out);
+}
+
+int hxv_set_nonlocal_csr(hxv_handle* h, const int64_t* rowptr, const int32_t* cols, const double* vals) {
+  if (!h || !rowptr) return fail(HXV_ERR_ARG, "hxv_set_nonlocal_csr: NULL argument");
+  if (h->host.panel_rows > 0) return fail(HXV_ERR_STATE, "hxv_set_nonlocal_csr: not on a panel handle");
+  if (h->host.nd.active) return fail(HXV_ERR_STATE, "hxv_set_nonlocal_csr: the handle already has an spH0nd block");
+  if (h->host.exchange == 1) return fail(HXV_ERR_UNSUPPORTED, "hxv_set_nonlocal_csr: the spH0nd block needs the whole vector (all-gather exchange), not the halo");
+  const int64_t nloc = (int64_t)h->host.qdw * h->host.dimup;
+  if (rowptr[0] != 0) return fail(HXV_ERR_ARG, "hxv_set_nonlocal_csr: rowptr[0] must be 0");
+  for (int64_t i = 0; i < nloc; ++i)
+    if (rowptr[i + 1] < rowptr[i]) return fail(HXV_ERR_ARG, "hxv_set_nonlocal_csr: rowptr must not decrease");
+  const int64_t nnz = rowptr[nloc];
+  if (nnz > 0 && (!cols || !vals)) return fail(HXV_ERR_ARG, "hxv_set_nonlocal_csr: NULL cols / vals");
+  bool real = true;
+  for (int64_t k = 0; k < nnz; ++k) {
+    if (cols[k] < 1 || (int64_t)cols[k] > h->host.dim) return fail(HXV_ERR_ARG, "hxv_set_nonlocal_csr: column index outside 1..Dim");
+    real = real && vals[2 * k + 1] == 0.0;
+  }
+  if (nnz == 0) return HXV_OK;  // (an all-zero block, stored: nothing to add)
+  HIPCHK(hipSetDevice(h->device));
+  int64_t* d_rp = nullptr;
+  int32_t* d_c = nullptr;
+  double2* d_v = nullptr;
+  HIPCHK(h->alloc(&d_rp, (size_t)nloc + 1));
+  HIPCHK(h->alloc(&d_c, (size_t)nnz));
+  HIPCHK(h->alloc(&d_v, (size_t)nnz));
+  HIPCHK(hipMemcpy(d_rp, rowptr, ((size_t)nloc + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_c, cols, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_v, vals, (size_t)nnz * sizeof(double2), hipMemcpyHostToDevice));
+  h->dev.ndcsr_rowptr = d_rp;
+  h->dev.ndcsr_cols = d_c;
+  h->dev.ndcsr_vals = d_v;
+  // from here on the handle behaves like one with Jx / Jp: the block is its own pass after the product (never folded, no REAL-vector
+  // mode, plain Lanczos recurrence)
+  h->dev.nd.active = h->host.nd.active = 1;
+  h->dev.nd.fold = h->host.nd.fold = 0;
+  (void)real;
+  return HXV_OK;
 }
 
 int hxv_destroy(hxv_handle* h) {

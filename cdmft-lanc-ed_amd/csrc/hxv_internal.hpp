@@ -131,6 +131,10 @@ struct DevSector {
   NonLocalParams nd;
   const uint32_t* nd_up;  // move tables of the spH0nd block (SectorHost::nd_up / nd_dw), null: search the basis instead
   const uint32_t* nd_dw;
+  // spH0nd as STORED by the caller (hxv_set_nonlocal_csr): local rows, global 1-based columns; null: none
+  const int64_t* ndcsr_rowptr;
+  const int32_t* ndcsr_cols;
+  const double2* ndcsr_vals;
   int real_h;
 };
 

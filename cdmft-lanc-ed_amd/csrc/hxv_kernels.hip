@@ -183,9 +183,37 @@ hipError_t launch_pack_columns(const double2* d_in, double2* d_out, const int32_
   return hipGetLastError();
 }
 
+// spH0nd handed over as stored rows (hxv_set_nonlocal_csr): hv(i) += sum_k vals(k) v(cols(k)), the loop of
+// ED_HAMILTONIAN_SPARSE_HxV.f90:217-225 with one thread per local row; the global column index is split into (iup, idw) to find the
+// element in the gathered layout.  A few entries per row: no tiling.
+__global__ void __launch_bounds__(256) hxv_nonlocal_csr(DevSector s, const double2* __restrict__ v, double2* __restrict__ hv) {
+  const int64_t nloc = (int64_t)s.qdw * s.dimup;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nloc; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t k0 = s.ndcsr_rowptr[t], k1 = s.ndcsr_rowptr[t + 1];
+    if (k0 == k1) continue;
+    double2 acc = make_double2(0.0, 0.0);
+    for (int64_t k = k0; k < k1; ++k) {
+      const int64_t j = (int64_t)s.ndcsr_cols[k] - 1;  // Fortran column
+      const int jdw = (int)(j / s.dimup), jup = (int)(j - (int64_t)jdw * s.dimup);
+      cfma(acc, s.ndcsr_vals[k], v[(int64_t)s.vcol[jdw] * s.pitch + jup]);
+    }
+    const int cl = (int)(t / s.dimup);
+    const int64_t o = (int64_t)cl * s.pitch + (t - (int64_t)cl * s.dimup);
+    double2 h = hv[o];
+    h.x += acc.x;
+    h.y += acc.y;
+    hv[o] = h;
+  }
+}
+
 hipError_t launch_hxv_nonlocal(const DevSector& s, const double2* v_full, double2* hv_local, hipStream_t st) {
   const int64_t nloc = (int64_t)s.qdw * s.dimup;
   if (nloc == 0 || !s.nd.active) return hipSuccess;
+  if (s.ndcsr_rowptr) {
+    int64_t blocks = std::min<int64_t>((nloc + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(hxv_nonlocal_csr, dim3((unsigned)blocks), dim3(256), 0, st, s, v_full, hv_local);
+    return hipGetLastError();
+  }
   if (s.nd_up && s.nd_dw) {
     const int rchunks = (s.dimup + 1023) / 1024;
     hipLaunchKernelGGL(hxv_nonlocal_tab, dim3((unsigned)((int64_t)s.qdw * rchunks)), dim3(1024), 0, st, s, v_full, hv_local, rchunks);

@@ -40,7 +40,7 @@ class _Stats(C.Structure):
 
 # every symbol include/hxv.h declares (tests check that the library exports all of them)
 EXPORTS = [
-    "hxv_create_from_model", "hxv_create_from_csr", "hxv_create_dw_panel", "hxv_apply_dw_panel", "hxv_apply_up_add", "hxv_destroy", "hxv_vecdim", "hxv_dims", "hxv_apply_host",
+    "hxv_create_from_model", "hxv_create_from_csr", "hxv_set_nonlocal_csr", "hxv_create_dw_panel", "hxv_apply_dw_panel", "hxv_apply_up_add", "hxv_destroy", "hxv_vecdim", "hxv_dims", "hxv_apply_host",
     "hxv_apply_device", "hxv_apply_device_real", "hxv_real_vectors_available", "hxv_pitch_real", "hxv_realvec_elems", "hxv_fullvec_elems", "hxv_localvec_elems", "hxv_pitch", "hxv_time_apply", "hxv_lanczos_tridiag", "hxv_lanczos_eigh", "hxv_lanczos_tridiag_host", "hxv_lanczos_eigh_host", "hxv_lanczos_tridiag_pair", "hxv_lanczos_tridiag_pair_host", "hxv_eigh_lowest", "hxv_eigh_lowest_host", "hxv_time_lanczos", "hxv_apply_ladder", "hxv_apply_ladder_axpy", "hxv_get_maps",
     "hxv_nnz", "hxv_get_csr", "hxv_get_diag", "hxv_set_option", "hxv_get_option", "hxv_get_stats", "hxv_pool_trim", "hxv_pool_stats", "hxv_last_error",
     "hxv_version", "hxv_comm_unique_id", "hxv_comm_init", "hxv_comm_free", "hxv_apply_device_slab", "hxv_exchange_count",
@@ -68,6 +68,7 @@ def load_library():
     pd, pi32, pi64 = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
     L.hxv_create_from_model.argtypes = [C.POINTER(_Model), i32, i32, i32, i32, i32, C.POINTER(vp)]
     L.hxv_create_from_csr.argtypes = [i32, i32, pi64, pi32, pd, pi64, pi32, pd, pd, i32, i32, i32, C.POINTER(vp)]
+    L.hxv_set_nonlocal_csr.argtypes = [vp, pi64, pi32, pd]
     L.hxv_create_dw_panel.argtypes = [C.POINTER(_Model), i32, i32, i32, i32, C.POINTER(vp)]
     L.hxv_apply_dw_panel.argtypes = [vp, vp, vp, vp]
     L.hxv_apply_up_add.argtypes = [vp, vp, vp, vp, vp]
@@ -306,9 +307,9 @@ class HxvSector:
         return cls(out, keep=(h, hb, vb), device_index=device)
 
     @classmethod
-    def from_csr(cls, DimUp, DimDw, up, dw, diag, rank: int = 0, nranks: int = 1, device: int = 0) -> "HxvSector":
+    def from_csr(cls, DimUp, DimDw, up, dw, diag, rank: int = 0, nranks: int = 1, device: int = 0, nd=None) -> "HxvSector":
         """up/dw = (rowptr int64, cols int32 1-based, vals complex128) as dumped from spH0ups(1)/spH0dws(1);
-        diag = local rows of spH0d (complex128)."""
+        diag = local rows of spH0d (complex128); nd = spH0nd likewise (local rows, GLOBAL 1-based columns) or None."""
         L = load_library()
         arrs = []
         for rp, cols, vals in (up, dw):
@@ -319,7 +320,17 @@ class HxvSector:
         _chk(L.hxv_create_from_csr(DimUp, DimDw, _p(arrs[0], C.c_int64), _p(arrs[1], C.c_int32), _p(arrs[2], C.c_double),
                                    _p(arrs[3], C.c_int64), _p(arrs[4], C.c_int32), _p(arrs[5], C.c_double), _p(dg, C.c_double),
                                    rank, nranks, device, C.byref(out)), "hxv_create_from_csr")
-        return cls(out, device_index=device)
+        sec = cls(out, device_index=device)
+        if nd is not None:
+            sec.set_nonlocal_csr(*nd)
+        return sec
+
+    def set_nonlocal_csr(self, rowptr, cols, vals):
+        """spH0nd as stored by the reference (ED_HAMILTONIAN_SPARSE_HxV.f90:217-225): local rows, global 1-based columns."""
+        rp = np.ascontiguousarray(rowptr, dtype=np.int64)
+        cc = np.ascontiguousarray(cols, dtype=np.int32)
+        vv = np.ascontiguousarray(vals, dtype=np.complex128).view(np.float64)
+        _chk(load_library().hxv_set_nonlocal_csr(self._h, _p(rp, C.c_int64), _p(cc, C.c_int32), _p(vv, C.c_double)), "hxv_set_nonlocal_csr")
 
     def _dev(self):
         import torch

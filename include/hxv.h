@@ -66,6 +66,13 @@ int hxv_create_from_csr(int32_t dimup, int32_t dimdw, const int64_t *up_rowptr, 
                         const int64_t *dw_rowptr, const int32_t *dw_cols, const double *dw_vals, const double *diag,
                         int32_t rank, int32_t nranks, int32_t device, hxv_handle **out);
 
+/* spH0nd of a from_csr handle (ED_VARS_GLOBAL.f90:145; built by sparse/H_non_local.f90:23-98 when Jhflag, added to Hv at
+ * ED_HAMILTONIAN_SPARSE_HxV.f90:217-225 serial / :298-312 MPI): the LOCAL rows (vecDim of them) with GLOBAL 1-based column indices
+ * i = iup + (idw-1)*DimUp, rowptr[vecDim+1] 0-based offsets, vals interleaved complex.  Applied as its own pass over Hv after the
+ * product, from the gathered vector (all-gather exchange only).  Once per handle; not on handles opened from a model with
+ * Jx / Jp (those build the block themselves).  Dim < 2^31 (the reference's column type).                                  */
+int hxv_set_nonlocal_csr(hxv_handle *h, const int64_t *rowptr, const int32_t *cols, const double *vals);
+
 /* delete_Hv_sector (ED_HAMILTONIAN.f90:149-190). NULL is a no-op. */
 int hxv_destroy(hxv_handle *h);
 

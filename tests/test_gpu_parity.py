@@ -234,6 +234,26 @@ def test_create_from_csr_matches_oracle(built, shard):
         assert np.array_equal(rp, rp0) and np.array_equal(cols, cols0) and np.array_equal(vals, vals0)
         assert np.array_equal(sec.diag(), orc.diag().real)
         sec.close()
+    # with the stored spH0nd block (Jx / Jp; local rows, global columns: ED_HAMILTONIAN_SPARSE_HxV.f90:217-225)
+    m, (nup, ndw) = models.bhz_2d(Nbath=0, Ust=0.7, Jh=0.2, Jx=0.2, Jp=0.15), (4, 3)
+    orc = OracleSector(m, nup, ndw, rank, size)
+    sec = hxv.HxvSector.from_csr(orc.DimUp, orc.DimDw, orc.csr("up"), orc.csr("dw"), orc.diag(), rank=rank, nranks=size, nd=orc.csr("nd"))
+    v = models.deterministic_vector(sec.Dim)
+    ref = _slab_reference(orc, v)
+    dv = torch.from_numpy(sec.to_gather_layout(v, size)).cuda()
+    for kernel in (0, 1):
+        sec.set_option("kernel", kernel)
+        assert _rel(sec.unpad(sec.apply_device(dv)).cpu().numpy(), ref) <= TOL, (shard, kernel)
+    assert not sec.real_vectors_available
+    with pytest.raises(hxv.HxvError, match="already has"):
+        sec.set_nonlocal_csr(*orc.csr("nd"))
+    if size == 1:   # the Lanczos drivers see the block too
+        vn = v / np.linalg.norm(v)
+        a, b, n = sec.lanczos_tridiag(torch.from_numpy(vn).cuda(), 12)
+        a0, b0 = orc.lanc_tridiag(vn, 12)
+        assert n == len(a0) == 12
+        assert np.abs(a - a0).max() <= 1e-11 * np.abs(a0).max() and np.abs(b[1:] - b0[1:]).max() <= 1e-11 * np.abs(b0).max()
+    sec.close()
 
 
 def test_edcontext_mirrors_reference_interface(built):
