@@ -54,7 +54,8 @@ typedef struct {
  * (nup,ndw) = get_Nup/get_Ndw(isector) (ED_SETUP.f90:477-500). rank/nranks = the DimDw
  * split of ED_HAMILTONIAN.f90:93-105 (nranks=1: serial, MpiStatus=F).  With Norb>1 and Jx or
  * Jp != 0 (Jhflag, ED_SETUP.f90:200-201) the spin-exchange / pair-hopping block spH0nd
- * (sparse/H_non_local.f90:4-100) is applied on the fly as a third kernel.               */
+ * (sparse/H_non_local.f90:4-100) is applied on the fly, inside the product's second pass (option "fold_nd" = 0: as a third
+ * pass over Hv).                                                                         */
 int hxv_create_from_model(const hxv_model *model, int32_t nup, int32_t ndw, int32_t rank, int32_t nranks, int32_t device,
                           hxv_handle **out);
 
@@ -227,7 +228,7 @@ int hxv_lanczos_eigh_host(hxv_handle *h, int32_t nitermax, double threshold, dou
  * exactly zero -- c / c^dagger applied to a real ground state; refused otherwise) travel as real and imaginary part of one
  * complex Lanczos vector; every scalar of the recurrence, every dot product and both early exits exist once per component.
  * alanc_x/blanc_x[nlanc], *nsteps_x as in hxv_lanczos_tridiag.  Each component's numbers are bit-identical to
- * hxv_lanczos_tridiag on that start vector through the same kernels (options real_vectors = 0, job_up = 0).
+ * hxv_lanczos_tridiag on that start vector through the same kernels (option real_vectors = 0; any job_up).
  * nranks == 1.  The _host form takes the start vectors in the reference's contiguous host layout.                        */
 int hxv_lanczos_tridiag_pair(hxv_handle *h, const void *d_vin_a, const void *d_vin_b, int32_t nlanc, double *alanc_a, double *blanc_a,
                              double *alanc_b, double *blanc_b, double threshold, int32_t *nsteps_a, int32_t *nsteps_b);
