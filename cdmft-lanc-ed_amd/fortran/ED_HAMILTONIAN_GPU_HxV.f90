@@ -350,8 +350,9 @@ contains
     !largest Krylov basis (64 vectors) once lanc_nstates_sector >= 7: clamp instead of stopping the run
     if(ncv>64)then
        write(*,"(A,I6,A)")"gpu_sp_eigh WARNING: Nblock=",ncv," > 64: using a Krylov basis of 64 vectors"
-       ncv=max(64_c_int32_t,int(size(eval)+1,c_int32_t))
+       ncv=64
     endif
+    if(size(eval)>=64)stop "gpu_sp_eigh ERROR: more than 63 eigenpairs per sector exceed the engine's Krylov basis (64 vectors)"
     !Nitermax bounds the RESTARTS here (each restart is up to ncv products; ARPACK's bound counts restarts too)
     nit=512; if(present(Nitermax))nit=int(Nitermax,c_int32_t)
     tl=0d0;  if(present(tol))tl=tol
