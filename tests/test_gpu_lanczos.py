@@ -722,3 +722,48 @@ def test_eigh_lowest_loose_tolerance_returns_no_duplicate(built):
             G = (vecs.conj() @ vecs.T).cpu().numpy()
             assert np.abs(G - np.eye(neigen)).max() < 1e-6
     sec.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model_name", ["hubbard_norb1", "bhz_complex", "kanamori_complex", "two_orbital_real_nd"])
+def test_fused_epilogue_matches_plain_recurrence_for_every_kernel_family(built, model_name):
+    """the fused Lanczos epilogue (pass A tile kernel with C = 2 / 4 columns, the job kernel, real-vector kernels, the
+    spH0nd variant) against the unfused recurrence on the same handle -- alanc / blanc of a run long enough that the previous-vector
+    term (xm non-null) and several out-of-block slots are exercised -- for every kernel family the launcher can pick."""
+    import torch
+    import hxv
+    from hxv import models
+
+    m, (nup, ndw) = {
+        "hubbard_norb1": (models.hm_1dchain(Nlat=2, Nbath=3), (4, 4)),                                   # Ns = 8, real H, one orbital
+        "bhz_complex": (models.bhz_2d(Nbath=0, Ust=0.3, Jh=0.1), (4, 3)),                                # complex H, Norb = 2
+        "kanamori_complex": (models.bhz_2d(Nbath=0, Ust=0.7, Jh=0.2, Jx=0.2, Jp=0.15), (4, 4)),          # + spH0nd folded into pass A
+        "two_orbital_real_nd": (models.bhz_2d(Nbath=0, lam=0.0, Ust=0.5, Jh=0.1, Jx=0.3, Jp=0.1), (3, 5)),
+    }[model_name]
+    sec = hxv.HxvSector.from_model(m, nup, ndw)
+    v = models.deterministic_vector(sec.Dim)
+    v /= np.linalg.norm(v)
+    dv = torch.from_numpy(v).cuda()
+    vr = torch.from_numpy((v.real / np.linalg.norm(v.real)).astype(np.complex128)).cuda()   # a real start vector
+    sec.set_option("lds_budget_kb_up", 8)    # several prefix blocks per spin: block hops and row slots in the epilogue path
+    sec.set_option("lds_budget_kb_dw", 8)
+    sec.set_option("lanczos_fused", 0)
+    sec.set_option("real_vectors", 0)
+    ref = sec.lanczos_tridiag(dv, 24)
+    ref_r = sec.lanczos_tridiag(vr, 24)
+    tried = 0
+    for cols in (2, 4):
+        for job_up in (0, 1, 2):
+            for real_vectors in (0, 1):
+                sec.set_option("cols_per_tile", cols)
+                sec.set_option("job_up", job_up)
+                sec.set_option("real_vectors", real_vectors)
+                sec.set_option("lanczos_fused", 1)
+                for start, want in ((dv, ref), (vr, ref_r)):
+                    a, b, n = sec.lanczos_tridiag(start, 24)
+                    assert n == want[2], (model_name, cols, job_up, real_vectors)
+                    assert np.abs(a - want[0]).max() <= 1e-10 * np.abs(want[0]).max(), (model_name, cols, job_up, real_vectors)
+                    assert np.abs(b - want[1]).max() <= 1e-10 * np.abs(want[1]).max(), (model_name, cols, job_up, real_vectors)
+                    tried += 1
+    assert tried == 24
+    sec.close()
