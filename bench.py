@@ -187,6 +187,10 @@ def main():
         ident = [hxv.HxvSector.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ident, src=0)
         sec.comm_init(ident[0])
+        # the slab lives where the exchange wants it (hxv_slab_home), as a device-resident Lanczos vector can: no slab copy per product
+        home = sec.slab_home()
+        home.copy_(v_local)
+        v_local = home
     hx = None
     if halo:
         rp, cols, _ = sec.csr("dw")

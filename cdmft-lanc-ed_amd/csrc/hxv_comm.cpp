@@ -186,7 +186,8 @@ int exchange(hxv_handle* h, const void* d_v_local, bool real, hipStream_t st) {
   if (s.exchange == 1) {
     // HALO exchange: only the columns H_dw couples to another rank's rows travel -- packed per destination; they land
     // behind the local slab, where the column -> slot table of this layout expects them
-    HIPCHK(hipMemcpyAsync(gather, d_v_local, (size_t)s.qdw * cb, hipMemcpyDeviceToDevice, st));
+    // (a caller that keeps its slab where the exchange wants it -- hxv_slab_home -- saves this copy)
+    if ((const void*)gather != d_v_local) HIPCHK(hipMemcpyAsync(gather, d_v_local, (size_t)s.qdw * cb, hipMemcpyDeviceToDevice, st));
     hipError_t pe = launch_pack_columns((const double2*)d_v_local, h->d_send, h->d_send_cols, (int)s.send_cols.size(), (int)(cb / sizeof(double2)), st);
     if (pe != hipSuccess) return fail(HXV_ERR_HIP, std::string("pack kernel: ") + hipGetErrorString(pe));
     rc = comm_sendrecv_cols(h, h->d_send, s.send_ptr.data(), gather + (size_t)s.qdw * cb, s.halo_ptr.data(), cb, st);
@@ -198,7 +199,7 @@ int exchange(hxv_handle* h, const void* d_v_local, bool real, hipStream_t st) {
   // column less leave their last column unused)
   const size_t slot = (size_t)s.cmax * cb;
   char* mine = gather + (size_t)s.rank * slot;
-  HIPCHK(hipMemcpyAsync(mine, d_v_local, (size_t)s.qdw * cb, hipMemcpyDeviceToDevice, st));
+  if ((const void*)mine != d_v_local) HIPCHK(hipMemcpyAsync(mine, d_v_local, (size_t)s.qdw * cb, hipMemcpyDeviceToDevice, st));
   if (G) {
     HIPCHK(hipEventRecord(G->ready[s.rank], st));
     G->barrier();
@@ -428,6 +429,21 @@ int hxv_apply_device_slab(hxv_handle* h, const void* d_v_local, void* d_hv_local
   if (!h || !d_v_local || !d_hv_local) return fail(HXV_ERR_ARG, "hxv_apply_device_slab: NULL argument");
   if (h->host.panel_rows > 0) return fail(HXV_ERR_STATE, "hxv_apply_device_slab: panel handles only do hxv_apply_dw_panel");
   return apply_slab(h, (const double2*)d_v_local, (double2*)d_hv_local, (hipStream_t)stream);
+}
+
+// Where the exchange wants this rank's slab: its slot of the gather buffer (all-gather) / the front of the halo layout.  A caller that
+// builds its vector THERE and passes that pointer to hxv_apply_device_slab saves the slab copy of every product (the vector's other
+// slots are overwritten by the exchange; the slab itself is only read).  Complex layout: [qdw columns][pitch].
+int hxv_slab_home(hxv_handle* h, void** d_slab) {
+  if (!h || !d_slab) return fail(HXV_ERR_ARG, "hxv_slab_home: NULL argument");
+  if (h->host.panel_rows > 0) return fail(HXV_ERR_STATE, "hxv_slab_home: not on a panel handle");
+  HIPCHK(hipSetDevice(h->device));
+  int rc = ensure_gather(h, h->stream);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream));  // (the buffer is zeroed on the handle's stream)
+  const size_t slot = (size_t)h->host.cmax * col_bytes(h, false);
+  *d_slab = reinterpret_cast<char*>(h->d_gather) + (h->host.exchange == 1 ? 0 : (size_t)h->host.rank * slot);
+  return HXV_OK;
 }
 
 int64_t hxv_exchange_count(const hxv_handle* h) { return h ? h->n_exchange : -1; }

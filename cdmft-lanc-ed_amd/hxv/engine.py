@@ -40,7 +40,7 @@ class _Stats(C.Structure):
 
 # every symbol include/hxv.h declares (tests check that the library exports all of them)
 EXPORTS = [
-    "hxv_create_from_model", "hxv_create_from_csr", "hxv_set_nonlocal_csr", "hxv_create_dw_panel", "hxv_apply_dw_panel", "hxv_apply_up_add", "hxv_destroy", "hxv_vecdim", "hxv_dims", "hxv_apply_host",
+    "hxv_create_from_model", "hxv_create_from_csr", "hxv_set_nonlocal_csr", "hxv_slab_home", "hxv_create_dw_panel", "hxv_apply_dw_panel", "hxv_apply_up_add", "hxv_destroy", "hxv_vecdim", "hxv_dims", "hxv_apply_host",
     "hxv_apply_device", "hxv_apply_device_real", "hxv_real_vectors_available", "hxv_pitch_real", "hxv_realvec_elems", "hxv_fullvec_elems", "hxv_localvec_elems", "hxv_pitch", "hxv_time_apply", "hxv_lanczos_tridiag", "hxv_lanczos_eigh", "hxv_lanczos_tridiag_host", "hxv_lanczos_eigh_host", "hxv_lanczos_tridiag_pair", "hxv_lanczos_tridiag_pair_host", "hxv_eigh_lowest", "hxv_eigh_lowest_host", "hxv_time_lanczos", "hxv_apply_ladder", "hxv_apply_ladder_axpy", "hxv_get_maps",
     "hxv_nnz", "hxv_get_csr", "hxv_get_diag", "hxv_set_option", "hxv_get_option", "hxv_get_stats", "hxv_pool_trim", "hxv_pool_stats", "hxv_last_error",
     "hxv_version", "hxv_comm_unique_id", "hxv_comm_init", "hxv_comm_free", "hxv_apply_device_slab", "hxv_exchange_count",
@@ -69,6 +69,7 @@ def load_library():
     L.hxv_create_from_model.argtypes = [C.POINTER(_Model), i32, i32, i32, i32, i32, C.POINTER(vp)]
     L.hxv_create_from_csr.argtypes = [i32, i32, pi64, pi32, pd, pi64, pi32, pd, pd, i32, i32, i32, C.POINTER(vp)]
     L.hxv_set_nonlocal_csr.argtypes = [vp, pi64, pi32, pd]
+    L.hxv_slab_home.argtypes = [vp, C.POINTER(vp)]
     L.hxv_create_dw_panel.argtypes = [C.POINTER(_Model), i32, i32, i32, i32, C.POINTER(vp)]
     L.hxv_apply_dw_panel.argtypes = [vp, vp, vp, vp]
     L.hxv_apply_up_add.argtypes = [vp, vp, vp, vp, vp]
@@ -421,6 +422,22 @@ class HxvSector:
 
     def comm_free(self):
         _chk(load_library().hxv_comm_free(self._h), "hxv_comm_free")
+
+    def slab_home(self):
+        """This rank's slot of the engine's gather buffer as a torch complex128 CUDA tensor of localElems elements: a vector built
+        THERE and passed to apply_device_slab saves the slab copy of every product (hxv_slab_home)."""
+        import torch
+
+        p = C.c_void_p()
+        _chk(load_library().hxv_slab_home(self._h, C.byref(p)), "hxv_slab_home")
+
+        class _View:
+            pass
+
+        view = _View()
+        view.__cuda_array_interface__ = {"shape": (int(self.localElems),), "typestr": "<c16", "data": (int(p.value), False), "version": 2,
+                                         "strides": None}
+        return torch.as_tensor(view, device=self._dev())
 
     def apply_device_slab(self, v_local, hv_local=None, stream=None):
         """(H v)|slab from this rank's slab: exchange (ncclAllGather on the stream) + product.  Padded layout, localElems each."""

@@ -117,6 +117,11 @@ int hxv_comm_local_destroy(void *group);
 /* d_hv_local = (H v)|slab from this rank's slab d_v_local (hxv_localvec_elems() elements each, padded device layout):
  * exchange + product, asynchronous on `stream`.  nranks==1 without a communicator: the plain product.              */
 int hxv_apply_device_slab(hxv_handle *h, const void *d_v_local, void *d_hv_local, void *stream);
+/* Where the exchange wants this rank's slab (its slot of the gather buffer): a caller that builds its vector there and hands
+ * THAT pointer to hxv_apply_device_slab saves the slab copy of every product.  [qdw columns][pitch] complex elements; allocated on
+ * first use; valid until hxv_comm_free / hxv_destroy.  The reference allocates the gathered vector per call and copies
+ * (ED_HAMILTONIAN_SPARSE_HxV.f90:277-296).                                                                                */
+int hxv_slab_home(hxv_handle *h, void **d_slab);
 int64_t hxv_exchange_count(const hxv_handle *h); /* exchanges since creation */
 /* HALO exchange (the lower-traffic alternative, replaces the transposes of ED_HAMILTONIAN_COMMON.f90:30-94 differently): with
  * the reference's own DimDw split a rank's rows of H_dw reference only a subset of the other ranks' columns (C3, 8 ranks:

@@ -37,6 +37,9 @@ def test_world_size_one_rccl_product_and_drivers(built):
     hv = sec.unpad(sec.apply_device_slab(dv))
     torch.cuda.synchronize()
     assert _rel(hv.cpu().numpy(), ref) <= TOL and sec.exchange_count == n0 + 1
+    home = sec.slab_home()                                   # the slab in its slot of the gather buffer: the all-gather runs in place
+    home.copy_(dv)
+    assert _rel(sec.unpad(sec.apply_device_slab(home)).cpu().numpy(), ref) <= TOL
     # Lanczos drivers: all-reduced dots, plain recurrence -> same numbers as the serial handle to rounding
     a1, b1, n1 = sec.lanczos_tridiag(torch.from_numpy(v).cuda(), 60)
     ser.set_option("lanczos_fused", 0)

@@ -51,6 +51,13 @@ def test_product_of_every_rank_through_the_exchange(built, name, nranks, exchang
         dv = sec.pad(torch.from_numpy(v[lo:hi].copy()).cuda(), sec.mpiQdw)
         got_dev = sec.unpad(sec.apply_device_slab(dv)).cpu().numpy()
         n_ex = sec.exchange_count
+        # the slab built where the exchange wants it (hxv_slab_home): same product, no slab copy
+        home = sec.slab_home()
+        assert home.numel() == sec.localElems
+        home.copy_(dv)
+        got_home = sec.unpad(sec.apply_device_slab(home)).cpu().numpy()
+        assert np.array_equal(got_home, got_dev)
+        assert torch.equal(home, dv)                               # (the product reads the slab, it does not change it)
         sec.close()
         return lo, hi, got_host, got_dev, n_ex
 
