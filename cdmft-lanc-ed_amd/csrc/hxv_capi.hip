@@ -495,6 +495,10 @@ int hxv_set_option(hxv_handle* h, const char* name, int64_t value) {
     h->plan.opt.passes = (int)value;
     return HXV_OK;
   }
+  if (!strcmp(name, "lanczos_inplace")) {  // split sectors: Lanczos vectors in their slot of a gather buffer (no slab copy per product)
+    h->lz_inplace = value ? 1 : 0;
+    return HXV_OK;
+  }
   if (!strcmp(name, "fold_nd")) {  // spH0nd inside pass A (default) or as its own pass over hv
     h->dev.nd.fold = h->host.nd.fold = value ? 1 : 0;
     return HXV_OK;
@@ -541,6 +545,8 @@ int64_t hxv_get_option(const hxv_handle* h, const char* name) {
   if (!strcmp(name, "eigh_last_full_passes")) return h->eigh_last_full;
   if (!strcmp(name, "eigh_last_local_passes")) return h->eigh_last_local;
   if (!strcmp(name, "lanczos_real_last")) return h->last_real;
+  if (!strcmp(name, "slab_copies")) return h->n_slab_copy;  // exchanges whose vector was not at home in a gather buffer
+  if (!strcmp(name, "lanczos_inplace")) return h->lz_inplace;
   if (!strcmp(name, "kernel")) return h->kernel;
   if (!strcmp(name, "tile_bits_up")) return h->plan.up.lowbits;
   if (!strcmp(name, "tile_bits_dw")) return h->plan.dw.lowbits;

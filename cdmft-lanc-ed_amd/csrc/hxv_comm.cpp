@@ -181,13 +181,24 @@ int exchange(hxv_handle* h, const void* d_v_local, bool real, hipStream_t st) {
   int rc = ensure_gather(h, st);
   if (rc) return rc;
   const size_t cb = col_bytes(h, real);
+  // A vector that already sits at the slab's place of one of the handle's gather buffers (hxv_slab_home; the Lanczos vectors of a split
+  // sector) is exchanged where it is; anything else is copied into the first buffer.
+  const size_t home_off = s.exchange == 1 ? 0 : (size_t)s.rank * s.cmax * cb;
   char* gather = reinterpret_cast<char*>(h->d_gather);
+  bool at_home = false;
+  for (double2* cand : {h->d_gather, h->d_gather_x[0], h->d_gather_x[1]})
+    if (cand && reinterpret_cast<const char*>(cand) + home_off == reinterpret_cast<const char*>(d_v_local)) {
+      gather = reinterpret_cast<char*>(cand);
+      at_home = true;
+    }
+  h->gather_cur = reinterpret_cast<double2*>(gather);
+  if (!at_home) h->n_slab_copy++;
   LocalGroup* G = lg(h);
   if (s.exchange == 1) {
     // HALO exchange: only the columns H_dw couples to another rank's rows travel -- packed per destination; they land
     // behind the local slab, where the column -> slot table of this layout expects them
     // (a caller that keeps its slab where the exchange wants it -- hxv_slab_home -- saves this copy)
-    if ((const void*)gather != d_v_local) HIPCHK(hipMemcpyAsync(gather, d_v_local, (size_t)s.qdw * cb, hipMemcpyDeviceToDevice, st));
+    if (!at_home) HIPCHK(hipMemcpyAsync(gather, d_v_local, (size_t)s.qdw * cb, hipMemcpyDeviceToDevice, st));
     hipError_t pe = launch_pack_columns((const double2*)d_v_local, h->d_send, h->d_send_cols, (int)s.send_cols.size(), (int)(cb / sizeof(double2)), st);
     if (pe != hipSuccess) return fail(HXV_ERR_HIP, std::string("pack kernel: ") + hipGetErrorString(pe));
     rc = comm_sendrecv_cols(h, h->d_send, s.send_ptr.data(), gather + (size_t)s.qdw * cb, s.halo_ptr.data(), cb, st);
@@ -199,14 +210,14 @@ int exchange(hxv_handle* h, const void* d_v_local, bool real, hipStream_t st) {
   // column less leave their last column unused)
   const size_t slot = (size_t)s.cmax * cb;
   char* mine = gather + (size_t)s.rank * slot;
-  if ((const void*)mine != d_v_local) HIPCHK(hipMemcpyAsync(mine, d_v_local, (size_t)s.qdw * cb, hipMemcpyDeviceToDevice, st));
+  if (!at_home) HIPCHK(hipMemcpyAsync(mine, d_v_local, (size_t)s.qdw * cb, hipMemcpyDeviceToDevice, st));
   if (G) {
     HIPCHK(hipEventRecord(G->ready[s.rank], st));
     G->barrier();
     for (int p = 0; p < s.nranks; ++p) {
       if (p == s.rank) continue;
       HIPCHK(hipStreamWaitEvent(st, G->ready[p], 0));
-      HIPCHK(hipMemcpyAsync(gather + (size_t)p * slot, reinterpret_cast<const char*>(G->member[p]->d_gather) + (size_t)p * slot, slot, hipMemcpyDefault, st));
+      HIPCHK(hipMemcpyAsync(gather + (size_t)p * slot, reinterpret_cast<const char*>(G->member[p]->gather_cur) + (size_t)p * slot, slot, hipMemcpyDefault, st));
     }
     HIPCHK(hipEventRecord(G->done[s.rank], st));
     G->barrier();
@@ -224,6 +235,36 @@ int exchange(hxv_handle* h, const void* d_v_local, bool real, hipStream_t st) {
 namespace hxv {
 
 bool comm_ready(const hxv_handle* h) { return h->comm != nullptr || h->lgroup != nullptr; }
+
+// Three places for the slab of a split sector's Lanczos vectors: its slot in the handle's gather buffer and in two more of the same
+// size, so that every vector of the three-term recurrence is exchanged where it lies (no slab copy per product).  The slab regions
+// are zeroed (pad rows must be zero; `real`: layout of the coming run).  HXV_OK with out[] set, or an error (the caller falls back to
+// slab buffers of its own on HXV_ERR_HIP from the allocation).
+int comm_lz_homes(hxv_handle* h, bool real, double2* out[3]) {
+  const SectorHost& s = h->host;
+  HIPCHK(hipSetDevice(h->device));
+  int rc = ensure_gather(h, h->stream);
+  if (rc) return rc;
+  const size_t cbc = col_bytes(h, false);
+  const size_t bytes = s.exchange == 1 ? std::max<size_t>((size_t)s.qdw + s.halo_cols.size(), 1) * cbc : std::max<size_t>((size_t)s.cmax * s.nranks * cbc, 1);
+  for (auto& p : h->d_gather_x)
+    if (!p) {
+      hipError_t e = pool_alloc(h->device, bytes, (void**)&p);
+      if (e != hipSuccess) {
+        p = nullptr;
+        return fail(HXV_ERR_HIP, std::string("gather buffers of the device Lanczos: ") + hipGetErrorString(e));
+      }
+      h->device_bytes += (int64_t)bytes;
+    }
+  const size_t cb = col_bytes(h, real);
+  const size_t home_off = s.exchange == 1 ? 0 : (size_t)s.rank * s.cmax * cb;
+  double2* base[3] = {h->d_gather, h->d_gather_x[0], h->d_gather_x[1]};
+  for (int i = 0; i < 3; ++i) {
+    out[i] = reinterpret_cast<double2*>(reinterpret_cast<char*>(base[i]) + home_off);
+    HIPCHK(hipMemsetAsync(out[i], 0, (size_t)std::max(s.qdw, 1) * col_bytes(h, false), h->stream));  // (the complex slab's extent covers the real one's)
+  }
+  return HXV_OK;
+}
 
 int comm_allreduce_sum(hxv_handle* h, double* d_buf, size_t count, hipStream_t st) {
   if (LocalGroup* G = lg(h)) {
@@ -283,7 +324,7 @@ int apply_slab(hxv_handle* h, const double2* d_v_local, double2* d_hv_local, hip
     if (!comm_ready(h)) return fail(HXV_ERR_STATE, "split sector without a communicator: call hxv_comm_init after opening the sector");
     int rc = exchange(h, d_v_local, false, st);
     if (rc) return rc;
-    vfull = h->d_gather;
+    vfull = h->gather_cur;
   }
   if (!ep) return hxv_apply_device(h, vfull, d_hv_local, st);
   int rcw = ensure_wt(h);
@@ -302,7 +343,7 @@ int apply_slab_real(hxv_handle* h, const double* d_v_local, double* d_hv_local, 
     if (!comm_ready(h)) return fail(HXV_ERR_STATE, "split sector without a communicator: call hxv_comm_init after opening the sector");
     int rc = exchange(h, d_v_local, true, st);
     if (rc) return rc;
-    vfull = reinterpret_cast<const double*>(h->d_gather);
+    vfull = reinterpret_cast<const double*>(h->gather_cur);
   }
   int rcw = ensure_wt(h);
   if (rcw) return rcw;
@@ -329,6 +370,13 @@ void comm_release(hxv_handle* h) {
     pool_free(h->device, h->d_gather);
     h->d_gather = nullptr;
   }
+  for (auto& p : h->d_gather_x)
+    if (p) {
+      pool_free(h->device, p);
+      p = nullptr;
+    }
+  h->gather_cur = nullptr;
+  for (auto& p : h->lz_vec) p = nullptr;
   if (h->d_send) {
     pool_free(h->device, h->d_send);
     h->d_send = nullptr;

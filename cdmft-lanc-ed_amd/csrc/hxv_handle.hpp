@@ -35,6 +35,7 @@ void launch_to_complex(const hxv_handle* h, const double* src, double2* dst, hip
 // deterministic start vector, real part of the complex one (imaginary part dropped)
 void launch_init_real(const hxv_handle* h, double* q, uint64_t seed, hipStream_t st);
 // one Lanczos step on normalised vectors through the fused product (hxv_lanczos.hip): w = H q - beta*qm, alpha = <q,w>, w -= alpha*q, |w|
+int comm_lz_homes(hxv_handle* h, bool real, double2* out[3]);
 bool lanczos_local_step_available(const hxv_handle* h);
 int lanczos_local_step(hxv_handle* h, bool real, const double2* q, double sq, const double2* qm, double sqm, double beta, double2* w,
                        bool sub_alpha, double* alpha, double* nrm_w);
@@ -63,6 +64,8 @@ struct hxv_handle {
   double* d_partials = nullptr;  // [2][RED_BLOCKS]
   double* d_scalars = nullptr;   // [8]
   double2* d_lz[3] = {nullptr, nullptr, nullptr};
+  double2* lz_vec[3] = {nullptr, nullptr, nullptr};  // what the drivers use: d_lz[], or (split sector) the slab's home in three gather buffers
+  int lz_inplace = 1;              // option "lanczos_inplace": on a split sector the Lanczos vectors live in their slot of a gather buffer (no slab copy per product)
   double* d_lz_partial = nullptr;  // per-workgroup partial sums of the fused Lanczos epilogue
   int64_t lz_partial_n = 0;
   int lz_fused = 1;                // option "lanczos_fused"
@@ -80,6 +83,9 @@ struct hxv_handle {
   const char* xfer_send = nullptr;         // thread ranks: what this rank offers in the column exchange under way (comm_sendrecv_cols)
   const int32_t* xfer_send_ptr = nullptr;  //               and its per-destination offsets
   double2* d_gather = nullptr;   // nranks * cmax * pitch elements (all-gather layout) / (qdw + halo) * pitch (halo layout)
+  double2* d_gather_x[2] = {nullptr, nullptr};  // two more of the same for the device Lanczos on a split sector (three vectors rotate)
+  double2* gather_cur = nullptr; // the gather buffer the exchange under way / last done runs on (peers of a thread group read it)
+  int64_t n_slab_copy = 0;       // slab copies into a gather buffer (exchange with a vector that is not at home)
   double2* d_send = nullptr;     // halo exchange: packed columns, grouped by destination rank
   int32_t* d_send_cols = nullptr;
   int64_t n_exchange = 0;

@@ -563,6 +563,16 @@ int ensure_lz(hxv_handle* h, bool real) {
     return fail(HXV_ERR_STATE, "device Lanczos on a split sector needs the communicator: call hxv_comm_init after opening the sector");
   HIPCHK(hipSetDevice(h->device));
   const size_t bytes = (size_t)h->host.pitch * std::max(h->host.qdw, 1) * sizeof(double2);
+  if (comm_ready(h) && h->host.nranks > 1 && h->lz_inplace) {
+    // split sector: the three vectors live where the exchange wants the slab, in three gather buffers (hxv_comm.cpp); when the memory for
+    // them is not there the slab buffers below serve, with one slab copy per product
+    int rc = comm_lz_homes(h, real, h->lz_vec);
+    if (rc == HXV_OK) {
+      h->lz_buf_mode = real ? 1 : 0;
+      return HXV_OK;
+    }
+    if (rc != HXV_ERR_HIP) return rc;
+  }
   for (auto& p : h->d_lz)
     if (!p) {
       HIPCHK(pool_alloc(h->device, bytes, (void**)&p));
@@ -575,6 +585,7 @@ int ensure_lz(hxv_handle* h, bool real) {
     for (auto& p : h->d_lz) HIPCHK(hipMemsetAsync(p, 0, bytes, h->stream));
     h->lz_buf_mode = real ? 1 : 0;
   }
+  for (int i = 0; i < 3; ++i) h->lz_vec[i] = h->d_lz[i];
   return HXV_OK;
 }
 
@@ -672,7 +683,7 @@ int hxv_lanczos_tridiag(hxv_handle* h, const void* d_vin, int32_t nlanc, double*
   }
   int rc = comm_agree(h, ensure_lz(h, real));  // (a rank that could not allocate tells its peers before the first all-reduce)
   if (rc) return rc;
-  LzRunner lz(h, h->d_lz[0], h->d_lz[1], h->d_lz[2], real);
+  LzRunner lz(h, h->lz_vec[0], h->lz_vec[1], h->lz_vec[2], real);
   if (real)
     launch_to_real(h, (const double2*)d_vin, (double*)lz.b.q, h->stream);
   else
@@ -793,7 +804,7 @@ int hxv_lanczos_eigh(hxv_handle* h, int32_t nitermax, double threshold, double* 
     hipLaunchKernelGGL(lz_scale, dim3(g), dim3(256), 0, h->stream, n, lz.b.q, lz.b.w, h->d_scalars, 1);
     return lz.begin(1.0);
   };
-  LzRunner lz(h, h->d_lz[0], h->d_lz[1], h->d_lz[2], real);
+  LzRunner lz(h, h->lz_vec[0], h->lz_vec[1], h->lz_vec[2], real);
   rc = start(lz);
   if (rc) return rc;
   std::vector<double> al, be(1, 0.0);
@@ -845,7 +856,7 @@ int hxv_lanczos_eigh(hxv_handle* h, int32_t nitermax, double threshold, double* 
     int jmin = (int)(std::min_element(d.begin(), d.end()) - d.begin());
     const double* y = &z[(size_t)jmin * m];
     double2* out = (double2*)d_vect;
-    LzRunner lz2(h, h->d_lz[0], h->d_lz[1], h->d_lz[2], real);
+    LzRunner lz2(h, h->lz_vec[0], h->lz_vec[1], h->lz_vec[2], real);
     rc = start(lz2);
     if (rc) return rc;
     HIPCHK(hipMemsetAsync(out, 0, (size_t)n * sizeof(double2), h->stream));
@@ -865,8 +876,8 @@ int hxv_lanczos_eigh(hxv_handle* h, int32_t nitermax, double threshold, double* 
     hipLaunchKernelGGL(lz_scale, dim3(g), dim3(256), 0, h->stream, n, out, out, h->d_scalars, 1);
     if (real) {
       // the Ritz vector was accumulated as a real vector in d_vect's memory: expand it to the complex layout of the API
-      HIPCHK(hipMemcpyAsync(h->d_lz[2], out, (size_t)n * sizeof(double2), hipMemcpyDeviceToDevice, h->stream));
-      launch_to_complex(h, (const double*)h->d_lz[2], out, h->stream);
+      HIPCHK(hipMemcpyAsync(h->lz_vec[2], out, (size_t)n * sizeof(double2), hipMemcpyDeviceToDevice, h->stream));
+      launch_to_complex(h, (const double*)h->lz_vec[2], out, h->stream);
     }
     HIPCHK(hipStreamSynchronize(h->stream));
   }
@@ -912,7 +923,7 @@ int hxv_lanczos_tridiag_pair(hxv_handle* h, const void* d_vin_a, const void* d_v
   double* d_p1 = d_p0 + RED_BLOCKS;
   double* d_p2 = d_p1 + RED_BLOCKS;
   HIPCHK(hipMemsetAsync(d_sc, 0, 16 * sizeof(double), h->stream));
-  double2 *q = h->d_lz[0], *qm = h->d_lz[1], *w = h->d_lz[2];
+  double2 *q = h->lz_vec[0], *qm = h->lz_vec[1], *w = h->lz_vec[2];
   hipLaunchKernelGGL(lz_pack_pair, dim3(g), dim3(256), 0, h->stream, n, (const double2*)d_vin_a, (const double2*)d_vin_b, q, d_p0, d_p1, d_p2);
   hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, d_p0, g, d_sc, 5, 0);
   hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, d_p1, g, d_sc, 6, 1);

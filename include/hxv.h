@@ -321,6 +321,9 @@ int hxv_get_diag(const hxv_handle *h, double *diag);
  *   "cols_per_tile" 2|4|8 [4; complex vectors use at most 4 per tile], "rows_per_tile" 0|2|4|8 [0 = 4, or 8 for sectors whose row panels exceed the L2], "lds_budget_kb[_up|_dw]" 8..144 [64], "threads_up|_dw"
  *   256|512|1024 [1024], "sort_mode" 0..2 [0], "sort_mode_dw" 0|1 [1], "wt_cols" 2|4|8|16 [4], "tile_bits_up|_dw" (force the block bits),
  *   "lds_min_kb_up|_dw".
+ * "lanczos_inplace" 0|1 [1]: on a split sector the device Lanczos vectors live in their slot of a gather buffer (three full-size
+ *   buffers per rank instead of one plus three slabs; no slab copy per product; same numbers bit for bit); get "slab_copies" counts
+ *   the exchanges that had to copy.
  * Scheduling knobs (results unchanged): "pair_rows" -1|0|1 [-1 = by sector size: pass B runs the two row groups of a 128-byte line
  *   back to back], "job_max_blocks" [32: pass A as jobs only up to this many blocks per spin], "fold_nd" 0|1 [1: spH0nd inside pass A].
  * Timing experiments (results are wrong or partial when set; refused unless HXV_EXPERIMENTS=1 is in the environment):

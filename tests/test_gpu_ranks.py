@@ -104,6 +104,13 @@ def test_lanczos_drivers_on_split_sector_equal_the_serial_ones(built, name, nran
         lo, hi = sec.mpiIshift, sec.mpiIshift + sec.vecDim
         a, b, n = sec.lanczos_tridiag(torch.from_numpy(v[lo:hi].copy()).cuda(), nl)
         was_real = sec.get_option("lanczos_real_last")
+        # the Lanczos vectors of a split sector live in their slot of a gather buffer: no slab copy in any of the nl exchanges ...
+        assert sec.get_option("slab_copies") == 0 and sec.exchange_count >= n
+        # ... and the same numbers, bit for bit, when they live in slab buffers and are copied before every exchange
+        sec.set_option("lanczos_inplace", 0)
+        a_c, b_c, n_c = sec.lanczos_tridiag(torch.from_numpy(v[lo:hi].copy()).cuda(), nl)
+        assert n_c == n and np.array_equal(a_c, a) and np.array_equal(b_c, b) and sec.get_option("slab_copies") >= n
+        sec.set_option("lanczos_inplace", 1)
         e, vec, _ = sec.lanczos_eigh(400, 1e-14)
         ev, vecs, nc, _ = sec.eigh_lowest(2, 16, 200, 0.0)
         out = (lo, hi, a, b, n, e, vec.cpu().numpy(), ev, nc, was_real, vecs[0].cpu().numpy())
