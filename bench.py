@@ -126,6 +126,10 @@ def main():
                     help="N>1: dimdw = ONE sector split along DimDw with an exchange per product (BASELINE's scheme, strong scaling, default); "
                          "sectors = every GPU runs its own whole sector, no exchange (how independent sectors / Green's-function channels "
                          "of one ED solve spread over a node; weak scaling)")
+    ap.add_argument("--rehearse-capi", action="store_true",
+                    help="one GPU, launched through torch.distributed.run with ONE rank: run exactly the calls of the N>1 path "
+                         "(process group on RCCL, hxv_comm_unique_id -> broadcast -> hxv_comm_init -> hxv_slab_home -> hxv_apply_device_slab, "
+                         "barrier, max over ranks) on a one-rank communicator")
     ap.add_argument("--check", action="store_true", help="N>1 rehearsal: verify the sharded product against the unsharded one on rank 0")
     args = ap.parse_args()
 
@@ -144,8 +148,12 @@ def main():
     local_rank = local_rank % max(torch.cuda.device_count(), 1)   # (rehearsals put several ranks on one GPU)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    multi = world > 1 or args.rehearse_capi   # the distributed code path (a rehearsal runs it with one rank)
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -182,7 +190,7 @@ def main():
     sh = hxv.ShardedHxv(sec.DimUp, sec.DimDw, 0 if by_sector else rank, 1 if by_sector else world, sec.apply_device, pitch=sec.pitch)
     # N>1 on RCCL: the exchange runs behind the C-ABI, exactly what a Fortran rank of the reference would call
     # (hxv_comm_unique_id on rank 0 -> the host program's own broadcast -> hxv_comm_init -> hxv_apply_device_slab)
-    capi_exchange = world > 1 and not by_sector and args.backend == "nccl" and args.exchange in ("allgather", "halo")
+    capi_exchange = multi and not by_sector and args.backend == "nccl" and args.exchange in ("allgather", "halo")
     if capi_exchange:
         ident = [hxv.HxvSector.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ident, src=0)
@@ -226,17 +234,17 @@ def main():
         del vg, ref
     for _ in range(args.warmup):
         step()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -283,12 +291,12 @@ def main():
         out["config"]["exchange"] = args.exchange
         out["config"]["exchange_ingest_bytes_per_gpu"] = ((world - 1) * slab if args.exchange == "allgather" else
                                                           16 * sec.pitch * hx.ingest_columns if halo else 2 * (world - 1) * slab // world)
-    if world == 1:
+    if world == 1 and not args.rehearse_capi:
         # what each of the three exchanges would move into one GPU per product at 8 ranks
         rp, cols, _ = sec.csr("dw")
         need8, _ = hxv.halo_plan(rp, cols - 1, sec.DimDw, 8)
         out["config"]["exchange_ingest_bytes_per_gpu_at_8_ranks"] = hxv.exchange_ingest_bytes(sec.DimUp, sec.DimDw, 8, need8)
-    if not args.no_lanczos and world == 1:
+    if not args.no_lanczos and world == 1 and not args.rehearse_capi:
         # full iterations: product + fused recurrence + 2 reductions, vectors in HBM.  Headline = complex(8) vectors, the
         # reference's data type; when H is real (C2, C3) the device drivers also run on real vectors (half the bytes).
         sec.set_option("real_vectors", 0)
@@ -320,7 +328,7 @@ def main():
             out["config"]["lanczos_paired_real_ms_per_iter_per_channel"] = round(pair_ms / 2, 4)
             out["config"]["lanczos_paired_real_matvecs_per_s"] = round(2e3 / pair_ms, 2)
             del va, vb
-    if world == 1 and args.workload == "C3" and not args.no_other_workloads:
+    if world == 1 and args.workload == "C3" and not args.no_other_workloads and not args.rehearse_capi:
         # the other full-size configs, driver-timed on the same GPU (parity-test sizes of BASELINE.json, not the headline)
         sec.close()
         del vfull, v_local, hv_local, sh
@@ -328,7 +336,7 @@ def main():
         hxv.pool_trim(local_rank)
         out["config"]["other_workloads"] = {w: time_other_workload(w, dev, 10 if w == "C4" else 3) for w in ("C4", "C5")}
         vfull = v_local = hv_local = sh = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.rehearse_capi:
         sec.close()
         vfull = v_local = hv_local = sh = None
         torch.cuda.empty_cache()
@@ -338,7 +346,7 @@ def main():
             out["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

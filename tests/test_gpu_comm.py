@@ -165,3 +165,20 @@ def test_halo_layout_rehearsal_one_gpu(built, world):
                 sec.close()
     finally:
         hxv.set_exchange_default("allgather")
+
+
+def test_bench_rehearses_the_multi_gpu_calls_with_one_rank(built):
+    """`bench.py --gpus N` (N > 1) cannot run on a one-GPU box; `--rehearse-capi` runs exactly its calls -- process group on RCCL,
+    hxv_comm_unique_id -> broadcast -> hxv_comm_init -> hxv_slab_home -> hxv_apply_device_slab, barrier, max over ranks -- with one rank."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--rehearse-capi", "--workload", "C2", "--steps", "3",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["roofline"]["achieved"] > 0
