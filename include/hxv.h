@@ -119,7 +119,8 @@ int hxv_comm_local_destroy(void *group);
 int hxv_apply_device_slab(hxv_handle *h, const void *d_v_local, void *d_hv_local, void *stream);
 /* Where the exchange wants this rank's slab (its slot of the gather buffer): a caller that builds its vector there and hands
  * THAT pointer to hxv_apply_device_slab saves the slab copy of every product.  [qdw columns][pitch] complex elements; allocated on
- * first use; valid until hxv_comm_free / hxv_destroy.  The reference allocates the gathered vector per call and copies
+ * first use; valid until hxv_comm_free / hxv_destroy; the device Lanczos drivers of a split sector keep their own vectors at the same
+ * place, so a vector left there does not survive a driver call.  The reference allocates the gathered vector per call and copies
  * (ED_HAMILTONIAN_SPARSE_HxV.f90:277-296).                                                                                */
 int hxv_slab_home(hxv_handle *h, void **d_slab);
 int64_t hxv_exchange_count(const hxv_handle *h); /* exchanges since creation */
