@@ -8,9 +8,9 @@ A "step" = one full product Hv = H v of the BASELINE C3 sector (cdn_hm_2dsquare:
 3 replica baths, Ns=16, sector (8,8), Dim = 165 636 900, complex fp64), vectors resident in HBM.
 With N>1 ranks the sector is split along DimDw exactly like the reference (ED_HAMILTONIAN.f90:93-105):
 each step exchanges the slabs over RCCL THROUGH THE C-ABI (hxv_comm_unique_id -> broadcast -> hxv_comm_init ->
-hxv_apply_device_slab: what a Fortran rank of the reference would run; --exchange allgather [default] | halo) and every
-rank computes its slab (strong scaling: the sector is fixed).  --exchange alltoall and --backend gloo go through
-torch.distributed instead (hxv/distributed.py).  value = algorithmic GB/s of the whole job = 32 B x Dim / step time
+hxv_apply_device_slab: what a Fortran rank of the reference would run; --exchange allgather [default] | halo | alltoall = the
+reference's own two transposes) and every rank computes its slab (strong scaling: the sector is fixed).  --backend gloo goes
+through torch.distributed instead (hxv/distributed.py).  value = algorithmic GB/s of the whole job = 32 B x Dim / step time
 (read v once + write Hv once per basis state).
 
 Rank 0 prints ONE JSON line.  It also carries
@@ -170,8 +170,11 @@ def main():
 
     by_sector = world > 1 and args.parallelism == "sectors"
     halo = world > 1 and args.exchange == "halo" and not by_sector
+    a2a_capi = world > 1 and args.exchange == "alltoall" and not by_sector and args.backend == "nccl"
     if halo:
         hxv.set_exchange_default("halo")          # the handle's gathered-vector layout is chosen when the sector is opened
+    if a2a_capi:
+        hxv.set_exchange_default("alltoall")      # the reference's two transposes, inside the engine (hxv_apply_device_slab)
     if by_sector:
         sec = hxv.HxvSector.from_model(model, nup, ndw, device=local_rank)      # the whole sector on every GPU
     else:
@@ -190,21 +193,25 @@ def main():
     sh = hxv.ShardedHxv(sec.DimUp, sec.DimDw, 0 if by_sector else rank, 1 if by_sector else world, sec.apply_device, pitch=sec.pitch)
     # N>1 on RCCL: the exchange runs behind the C-ABI, exactly what a Fortran rank of the reference would call
     # (hxv_comm_unique_id on rank 0 -> the host program's own broadcast -> hxv_comm_init -> hxv_apply_device_slab)
-    capi_exchange = multi and not by_sector and args.backend == "nccl" and args.exchange in ("allgather", "halo")
+    if a2a_capi and sec.exchange_mode != "alltoall":   # (e.g. the spH0nd block keeps the all-gather exchange)
+        a2a_capi = False
+        args.exchange = "allgather"
+    capi_exchange = multi and not by_sector and args.backend == "nccl" and (args.exchange in ("allgather", "halo") or a2a_capi)
     if capi_exchange:
         ident = [hxv.HxvSector.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ident, src=0)
         sec.comm_init(ident[0])
         # the slab lives where the exchange wants it (hxv_slab_home), as a device-resident Lanczos vector can: no slab copy per product
-        home = sec.slab_home()
-        home.copy_(v_local)
-        v_local = home
+        if not a2a_capi:
+            home = sec.slab_home()
+            home.copy_(v_local)
+            v_local = home
     hx = None
     if halo:
         rp, cols, _ = sec.csr("dw")
         need, send = hxv.halo_plan(rp, cols - 1, sec.DimDw, world)
         hx = hxv.HaloHxv(sec.DimUp, sec.DimDw, rank, world, need, send, sec.apply_device, pitch=sec.pitch, stage_on_host=(args.backend != "nccl"))
-    if world > 1 and args.exchange == "alltoall" and not by_sector:
+    if world > 1 and args.exchange == "alltoall" and not by_sector and not a2a_capi:
         nrows = hxv.dw_split(sec.DimUp, rank, world)[0]
         panel = hxv.HxvSector.dw_panel(model, nup, ndw, nrows, device=local_rank)
         th = hxv.TransposedHxv(sec.DimUp, sec.DimDw, rank, world, panel.apply_dw_panel, sec.apply_up_add, pitch=sec.pitch,
@@ -213,7 +220,7 @@ def main():
     def step():
         if capi_exchange:
             sec.apply_device_slab(v_local, hv_local)
-        elif world > 1 and args.exchange == "alltoall" and not by_sector:
+        elif world > 1 and args.exchange == "alltoall" and not by_sector and not a2a_capi:
             th(Nloc, v_local, hv_local)
         elif halo:
             hx(Nloc, v_local, hv_local)

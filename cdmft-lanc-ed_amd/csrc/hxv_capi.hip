@@ -43,9 +43,10 @@ int ensure_wt(hxv_handle* h) {
 }
 }  // namespace hxv
 
-namespace {
-
-int finish_create(hxv_handle* h, int device, hxv_handle** out) {
+namespace hxv {
+int finish_create(hxv_handle* h, int device, hxv_handle** out);
+}
+int hxv::finish_create(hxv_handle* h, int device, hxv_handle** out) {
   int ndev = 0;
   hipError_t e0 = hipGetDeviceCount(&ndev);
   if (e0 != hipSuccess || ndev == 0) {
@@ -135,8 +136,6 @@ int finish_create(hxv_handle* h, int device, hxv_handle** out) {
   return HXV_OK;
 }
 
-}  // namespace
-
 namespace hxv {
 // REAL-vector mode: available when every amplitude of H is real, the tiled kernels run and there is
 // no spH0nd block.  Vectors are double[qdw local columns][pitch_real], pitch_real = roundup16(DimUp); on a split sector the
@@ -146,6 +145,7 @@ const char* real_mode_blocker(const hxv_handle* h) {
   if (h->kernel != 1 || !h->plan.usable) return "the tiled kernels are not in use";
   if (h->dev.nd.active) return "the spH0nd block (Jx/Jp) is active";
   if (h->host.panel_rows > 0) return "panel handle";
+  if (h->host.exchange == 2) return "the all-to-all exchange moves complex slabs";
   if (h->plan.opt.passes != 3 || h->plan.opt.debug != 0) return "debug options are set";
   return nullptr;
 }
@@ -279,7 +279,7 @@ int hxv_halo_lists(const hxv_handle* h, int32_t* recv_cols, int32_t* send_cols) 
   return HXV_OK;
 }
 int hxv_set_exchange_default(int32_t mode) {
-  if (mode < 0 || mode > 1) return fail(HXV_ERR_ARG, "exchange mode must be 0 (all-gather) or 1 (halo)");
+  if (mode < 0 || mode > 2) return fail(HXV_ERR_ARG, "exchange mode must be 0 (all-gather), 1 (halo) or 2 (two all-to-all transposes)");
   set_default_exchange(mode);
   return HXV_OK;
 }

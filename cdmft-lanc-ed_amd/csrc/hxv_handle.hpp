@@ -36,6 +36,7 @@ void launch_to_complex(const hxv_handle* h, const double* src, double2* dst, hip
 void launch_init_real(const hxv_handle* h, double* q, uint64_t seed, hipStream_t st);
 // one Lanczos step on normalised vectors through the fused product (hxv_lanczos.hip): w = H q - beta*qm, alpha = <q,w>, w -= alpha*q, |w|
 int comm_lz_homes(hxv_handle* h, bool real, double2* out[3]);
+int finish_create(hxv_handle* h, int device, hxv_handle** out);  // uploads h->host, builds the tile plan (hxv_capi.hip); deletes h on failure
 bool lanczos_local_step_available(const hxv_handle* h);
 int lanczos_local_step(hxv_handle* h, bool real, const double2* q, double sq, const double2* qm, double sqm, double beta, double2* w,
                        bool sub_alpha, double* alpha, double* nrm_w);
@@ -85,6 +86,7 @@ struct hxv_handle {
   double2* d_gather = nullptr;   // nranks * cmax * pitch elements (all-gather layout) / (qdw + halo) * pitch (halo layout)
   double2* d_gather_x[2] = {nullptr, nullptr};  // two more of the same for the device Lanczos on a split sector (three vectors rotate)
   double2* gather_cur = nullptr; // the gather buffer the exchange under way / last done runs on (peers of a thread group read it)
+  void* a2a = nullptr;           // exchange 2 (two all-to-all transposes): panel handle, staging buffers, per-peer offsets (hxv_comm.cpp)
   int64_t n_slab_copy = 0;       // slab copies into a gather buffer (exchange with a vector that is not at home)
   double2* d_send = nullptr;     // halo exchange: packed columns, grouped by destination rank
   int32_t* d_send_cols = nullptr;

@@ -66,7 +66,7 @@ struct SectorHost {
   std::vector<uint32_t> vcol;       // [dimdw] column -> column slot in the padded layout
   // HALO exchange (exchange == 1): the gathered vector holds this rank's qdw columns (slots 0..qdw-1) followed by only
   // those columns of other ranks that H_dw couples to its rows, ascending (= grouped by owner rank)
-  int exchange = 0;                 // 0 all-gather layout, 1 halo layout
+  int exchange = 0;                 // 0 all-gather layout, 1 halo layout, 2 all-gather layout with the two-transposes exchange
   std::vector<int32_t> halo_cols;   // global columns received, in slot order
   std::vector<int32_t> halo_ptr;    // [nranks+1] offsets into halo_cols by owner rank
   std::vector<int32_t> send_cols;   // LOCAL column indices to send, grouped by destination rank
@@ -93,6 +93,7 @@ std::string build_sector_from_csr(int dimup, int dimdw, const int64_t* up_rp, co
 std::string build_ell(SpinOp& op);
 void dw_split(int dimdw, int rank, int nranks, int& qdw, int& dw0);
 void make_vcol(SectorHost& s);
+std::string make_panel_host(const SectorHost& main, int nrows, SectorHost& panel);  // the row panel of the all-to-all exchange
 void make_halo(SectorHost& s);     // needs s.dw (CSR); replaces the all-gather layout by the halo layout
 int default_exchange();            // hxv_set_exchange_default / HXV_EXCHANGE=halo
 void set_default_exchange(int mode);

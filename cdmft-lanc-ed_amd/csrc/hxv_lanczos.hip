@@ -563,7 +563,7 @@ int ensure_lz(hxv_handle* h, bool real) {
     return fail(HXV_ERR_STATE, "device Lanczos on a split sector needs the communicator: call hxv_comm_init after opening the sector");
   HIPCHK(hipSetDevice(h->device));
   const size_t bytes = (size_t)h->host.pitch * std::max(h->host.qdw, 1) * sizeof(double2);
-  if (comm_ready(h) && h->host.nranks > 1 && h->lz_inplace) {
+  if (comm_ready(h) && h->host.nranks > 1 && h->lz_inplace && h->host.exchange != 2) {
     // split sector: the three vectors live where the exchange wants the slab, in three gather buffers (hxv_comm.cpp); when the memory for
     // them is not there the slab buffers below serve, with one slab copy per product
     int rc = comm_lz_homes(h, real, h->lz_vec);

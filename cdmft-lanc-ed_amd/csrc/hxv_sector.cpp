@@ -186,9 +186,43 @@ int g_exchange_default = -1;
 int default_exchange() {
   if (g_exchange_default >= 0) return g_exchange_default;
   const char* e = std::getenv("HXV_EXCHANGE");
+  if (e && std::string(e) == "alltoall") return 2;
   return (e && std::string(e) == "halo") ? 1 : 0;
 }
 void set_default_exchange(int mode) { g_exchange_default = mode; }
+
+// The dw-only row panel [nrows x DimDw] that goes with an open sector (all-to-all exchange, ED_HAMILTONIAN_SPARSE_HxV.f90:272-296: the
+// dw hops act on the transposed vector): same one-spin matrix H_dw, no basis of its own, no H_up, no diagonal.
+std::string make_panel_host(const SectorHost& m, int nrows, SectorHost& p) {
+  if (nrows < 1 || nrows > m.dimup) return "panel rows outside 1..DimUp";
+  p = SectorHost();
+  p.ns = m.ns;
+  p.nup = m.nup;
+  p.ndw = m.ndw;
+  p.dimdw = m.dimdw;
+  p.map_dw = m.map_dw;
+  p.panel_rows = nrows;
+  p.dimup = nrows;
+  p.dim = (int64_t)nrows * m.dimdw;
+  p.rank = 0;
+  p.nranks = 1;
+  dw_split(p.dimdw, 0, 1, p.qdw, p.dw0);
+  p.ishift = 0;
+  make_vcol(p);
+  p.map_up.assign(nrows, 0u);
+  p.up = SpinOp();
+  p.up.dim = nrows;
+  p.up.rowptr.assign(nrows + 1, 0);
+  std::string e = build_ell(p.up);
+  if (!e.empty()) return e;
+  p.dw = m.dw;
+  p.separable_diag = true;
+  p.a_up.assign(nrows, 0.0);
+  p.a_dw.assign(m.dimdw, 0.0);
+  p.cross = m.cross;
+  p.nd = NonLocalParams();
+  return "";
+}
 
 // Halo layout: which columns of the other ranks do the rows of H_dw owned by each rank reference?  Every rank knows the
 // whole one-spin matrix, so it derives its own receive list and what every other rank expects from it without talking.
@@ -324,6 +358,8 @@ std::string build_sector_from_model(const hxv_model& m, int nup, int ndw, int ra
   apply_hops(s.map_dw, hops_dw, s.dw);
   // (the spH0nd block reaches columns that H_dw does not: it keeps the all-gather layout)
   if (nranks > 1 && panel_rows == 0 && default_exchange() == 1 && !(m.norb > 1 && (m.jx != 0.0 || m.jp != 0.0))) make_halo(s);
+  // (exchange 2 = the reference's two transposes: the all-gather layout stays, only the product's exchange differs)
+  if (nranks > 1 && panel_rows == 0 && default_exchange() == 2 && !(m.norb > 1 && (m.jx != 0.0 || m.jp != 0.0))) s.exchange = 2;
   e = build_ell(s.up);
   if (!e.empty()) return e;
   e = build_ell(s.dw);

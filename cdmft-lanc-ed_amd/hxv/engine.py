@@ -135,8 +135,9 @@ def load_library():
 
 
 def set_exchange_default(mode: str | int):
-    """Exchange of the split sectors created from now on: "allgather" / 0 [default] or "halo" / 1 (include/hxv.h)."""
-    m = {"allgather": 0, "halo": 1}.get(mode, mode)
+    """Exchange of the split sectors created from now on: "allgather" / 0 [default], "halo" / 1 or "alltoall" / 2 (the reference's two
+    transposes) (include/hxv.h)."""
+    m = {"allgather": 0, "halo": 1, "alltoall": 2}.get(mode, mode)
     _chk(load_library().hxv_set_exchange_default(int(m)), "hxv_set_exchange_default")
 
 
@@ -456,7 +457,7 @@ class HxvSector:
 
     @property
     def exchange_mode(self) -> str:
-        return "halo" if load_library().hxv_exchange_mode(self._h) == 1 else "allgather"
+        return {0: "allgather", 1: "halo", 2: "alltoall"}[load_library().hxv_exchange_mode(self._h)]
 
     def halo_lists(self, nranks: int):
         """(recv_counts[nranks], send_counts[nranks], recv_cols (global, slot order), send_cols (local, by destination))."""

@@ -123,6 +123,11 @@ int hxv_apply_device_slab(hxv_handle *h, const void *d_v_local, void *d_hv_local
  * place, so a vector left there does not survive a driver call.  The reference allocates the gathered vector per call and copies
  * (ED_HAMILTONIAN_SPARSE_HxV.f90:277-296).                                                                                */
 int hxv_slab_home(hxv_handle *h, void **d_slab);
+/* Exchange mode 2 (hxv_set_exchange_default(2) / HXV_EXCHANGE=alltoall before the sector is opened; not with the spH0nd block): the
+ * reference's own two transposes (vector_transpose_MPI, ED_HAMILTONIAN_COMMON.f90:30-94; spMatVec_mpi_main :272-296) inside the
+ * engine -- slab -> row panels (rows split like the columns, :274-275), dw hops on the panel, back, then diagonal + up hops on the slab.
+ * Moves (P-1)/P of one slab per rank and transpose instead of P-1 slabs: the lowest-traffic exchange.  hxv_apply_host,
+ * hxv_apply_device_slab and the device drivers use it transparently; complex slabs only; hxv_slab_home does not apply.            */
 int64_t hxv_exchange_count(const hxv_handle *h); /* exchanges since creation */
 /* HALO exchange (the lower-traffic alternative, replaces the transposes of ED_HAMILTONIAN_COMMON.f90:30-94 differently): with
  * the reference's own DimDw split a rank's rows of H_dw reference only a subset of the other ranks' columns (C3, 8 ranks:
@@ -132,7 +137,7 @@ int64_t hxv_exchange_count(const hxv_handle *h); /* exchanges since creation */
  * hxv_fullvec_elems() reports the length.  hxv_apply_host / hxv_apply_device_slab / the drivers then exchange exactly
  * those columns (grouped ncclSend/ncclRecv).  recv_counts/send_counts: columns per peer rank; recv_cols: global column
  * indices in slot order; send_cols: LOCAL column indices grouped by destination rank.                                */
-int hxv_set_exchange_default(int32_t mode); /* 0 all-gather [default], 1 halo; applies to handles created afterwards */
+int hxv_set_exchange_default(int32_t mode); /* 0 all-gather [default], 1 halo, 2 two all-to-all transposes; applies to handles created afterwards */
 int32_t hxv_exchange_mode(const hxv_handle *h);
 int hxv_halo_counts(const hxv_handle *h, int32_t *recv_counts, int32_t *send_counts);
 int hxv_halo_lists(const hxv_handle *h, int32_t *recv_cols, int32_t *send_cols);

@@ -28,7 +28,8 @@ def _model(name):
 
 
 @pytest.mark.parametrize("name,nranks,exchange", [("chain", 2, "allgather"), ("chain", 3, "allgather"), ("chain", 3, "halo"), ("C2", 4, "halo"),
-                                                  ("C2", 3, "allgather"), ("bhz", 3, "allgather"), ("bhz", 4, "halo")])
+                                                  ("C2", 3, "allgather"), ("bhz", 3, "allgather"), ("bhz", 4, "halo"),
+                                                  ("chain", 3, "alltoall"), ("C2", 4, "alltoall"), ("bhz", 3, "alltoall"), ("chain", 2, "alltoall")])
 def test_product_of_every_rank_through_the_exchange(built, name, nranks, exchange):
     import torch
     import hxv
@@ -51,13 +52,18 @@ def test_product_of_every_rank_through_the_exchange(built, name, nranks, exchang
         dv = sec.pad(torch.from_numpy(v[lo:hi].copy()).cuda(), sec.mpiQdw)
         got_dev = sec.unpad(sec.apply_device_slab(dv)).cpu().numpy()
         n_ex = sec.exchange_count
-        # the slab built where the exchange wants it (hxv_slab_home): same product, no slab copy
-        home = sec.slab_home()
-        assert home.numel() == sec.localElems
-        home.copy_(dv)
-        got_home = sec.unpad(sec.apply_device_slab(home)).cpu().numpy()
-        assert np.array_equal(got_home, got_dev)
-        assert torch.equal(home, dv)                               # (the product reads the slab, it does not change it)
+        if exchange != "alltoall":
+            # the slab built where the exchange wants it (hxv_slab_home): same product, no slab copy
+            home = sec.slab_home()
+            assert home.numel() == sec.localElems
+            home.copy_(dv)
+            got_home = sec.unpad(sec.apply_device_slab(home)).cpu().numpy()
+            assert np.array_equal(got_home, got_dev)
+            assert torch.equal(home, dv)                           # (the product reads the slab, it does not change it)
+        else:
+            assert not sec.real_vectors_available                  # (the two transposes move complex slabs)
+            with pytest.raises(hxv.HxvError, match="no gathered vector"):
+                sec.slab_home()
         sec.close()
         return lo, hi, got_host, got_dev, n_ex
 
@@ -68,11 +74,12 @@ def test_product_of_every_rank_through_the_exchange(built, name, nranks, exchang
     scale = np.abs(ref).max()
     for lo, hi, gh, gd, n_ex in res:
         assert np.abs(gh - ref[lo:hi]).max() <= TOL * scale and np.abs(gd - ref[lo:hi]).max() <= TOL * scale
-        assert n_ex == 2
+        assert n_ex == (4 if exchange == "alltoall" else 2)      # (two transposes per product)
 
 
 @pytest.mark.parametrize("name,nranks,exchange,real_vectors,fused", [("C2", 3, "allgather", 0, 1), ("C2", 3, "halo", 1, 1), ("C2", 2, "allgather", 1, 0),
-                                                                     ("chain", 3, "halo", 0, 0), ("bhz", 3, "allgather", 0, 1)])
+                                                                     ("chain", 3, "halo", 0, 0), ("bhz", 3, "allgather", 0, 1),
+                                                                     ("C2", 3, "alltoall", 0, 1), ("bhz", 2, "alltoall", 0, 0)])
 def test_lanczos_drivers_on_split_sector_equal_the_serial_ones(built, name, nranks, exchange, real_vectors, fused):
     """tridiag, eigh and eigh_lowest with slabs per rank: the same Krylov space as the unsplit sector (the start vectors hash the
     GLOBAL index), alpha/beta/E equal to rounding; every rank returns the same numbers; real vectors and the fused recurrence run
@@ -105,11 +112,13 @@ def test_lanczos_drivers_on_split_sector_equal_the_serial_ones(built, name, nran
         a, b, n = sec.lanczos_tridiag(torch.from_numpy(v[lo:hi].copy()).cuda(), nl)
         was_real = sec.get_option("lanczos_real_last")
         # the Lanczos vectors of a split sector live in their slot of a gather buffer: no slab copy in any of the nl exchanges ...
+        # (the all-to-all exchange has no gathered vector at all)
         assert sec.get_option("slab_copies") == 0 and sec.exchange_count >= n
         # ... and the same numbers, bit for bit, when they live in slab buffers and are copied before every exchange
         sec.set_option("lanczos_inplace", 0)
         a_c, b_c, n_c = sec.lanczos_tridiag(torch.from_numpy(v[lo:hi].copy()).cuda(), nl)
-        assert n_c == n and np.array_equal(a_c, a) and np.array_equal(b_c, b) and sec.get_option("slab_copies") >= n
+        assert n_c == n and np.array_equal(a_c, a) and np.array_equal(b_c, b)
+        assert sec.get_option("slab_copies") >= (0 if exchange == "alltoall" else n)
         sec.set_option("lanczos_inplace", 1)
         e, vec, _ = sec.lanczos_eigh(400, 1e-14)
         ev, vecs, nc, _ = sec.eigh_lowest(2, 16, 200, 0.0)
