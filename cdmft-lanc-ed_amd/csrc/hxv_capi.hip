@@ -145,7 +145,6 @@ const char* real_mode_blocker(const hxv_handle* h) {
   if (h->kernel != 1 || !h->plan.usable) return "the tiled kernels are not in use";
   if (h->dev.nd.active) return "the spH0nd block (Jx/Jp) is active";
   if (h->host.panel_rows > 0) return "panel handle";
-  if (h->host.exchange == 2) return "the all-to-all exchange moves complex slabs";
   if (h->plan.opt.passes != 3 || h->plan.opt.debug != 0) return "debug options are set";
   return nullptr;
 }

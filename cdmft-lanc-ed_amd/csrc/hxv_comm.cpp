@@ -329,7 +329,8 @@ struct A2A {
   std::vector<int> rn, ru0, cq, cc0;         // per rank: its rows (count, first) and columns (count, first)
   std::vector<int32_t> sp1, rp1, sp2, rp2;   // [P+1] element offsets of the per-peer blocks in the send / receive buffers, both transposes
   double2 *d_send = nullptr, *d_recv = nullptr, *d_x = nullptr, *d_y = nullptr, *d_w = nullptr;
-  int pp = 0;                                // panel pitch
+  int pp = 0;                                // panel pitch (complex layout)
+  int mode = 0;                              // layout the panel / dw-part buffers were last used in (0 complex, 1 real): the pad rows differ
 };
 
 static void a2a_release(hxv_handle* h) {
@@ -399,13 +400,14 @@ static int ensure_a2a(hxv_handle* h, hipStream_t st) {
   return HXV_OK;
 }
 
-// (rows [u0,u0+n) of `ncols` columns of pitch `pitch`) <-> contiguous [ncols][n]
-static hipError_t copy_block(double2* dst, size_t dpitch, const double2* src, size_t spitch, int n, int ncols, hipStream_t st) {
+// (rows [u0,u0+n) of `ncols` columns of pitch `pitch`) <-> contiguous [ncols][n]; esz = bytes per element (16 complex, 8 real)
+static hipError_t copy_block(void* dst, size_t dpitch, const void* src, size_t spitch, int n, int ncols, size_t esz, hipStream_t st) {
   if (n <= 0 || ncols <= 0) return hipSuccess;
-  return hipMemcpy2DAsync(dst, dpitch * sizeof(double2), src, spitch * sizeof(double2), (size_t)n * sizeof(double2), (size_t)ncols, hipMemcpyDeviceToDevice, st);
+  return hipMemcpy2DAsync(dst, dpitch * esz, src, spitch * esz, (size_t)n * esz, (size_t)ncols, hipMemcpyDeviceToDevice, st);
 }
 
-static int apply_slab_a2a(hxv_handle* h, const double2* v, double2* hv, hipStream_t st, const LzEpilogue* ep) {
+// `real`: the slabs are double[qdw][pitch_real] (REAL-vector mode of the drivers: half the bytes in every step below)
+static int apply_slab_a2a(hxv_handle* h, const void* v_, void* hv_, bool real, hipStream_t st, const LzEpilogue* ep) {
   const SectorHost& s = h->host;
   if (!comm_ready(h)) return fail(HXV_ERR_STATE, "split sector without a communicator: call hxv_comm_init after opening the sector");
   HIPCHK(hipSetDevice(h->device));
@@ -413,35 +415,63 @@ static int apply_slab_a2a(hxv_handle* h, const double2* v, double2* hv, hipStrea
   if (rc) return rc;
   A2A& a = *static_cast<A2A*>(h->a2a);
   const int P = s.nranks, me = s.rank, nme = a.rn[me], q = s.qdw;
+  const size_t esz = real ? sizeof(double) : sizeof(double2);
+  const size_t pit = real ? (size_t)pitch_real_of(h) : (size_t)s.pitch;          // slab pitch
+  const size_t pp = real ? (size_t)pitch_real_of(a.panel) : (size_t)a.pp;         // panel pitch
+  if (a.mode != (real ? 1 : 0)) {
+    // the pad rows of the two layouts sit at different places and the unpack copies never write pads
+    HIPCHK(hipMemsetAsync(a.d_x, 0, (size_t)s.dimdw * a.pp * sizeof(double2), st));
+    HIPCHK(hipMemsetAsync(a.d_w, 0, (size_t)std::max(s.qdw, 1) * s.pitch * sizeof(double2), st));
+    a.mode = real ? 1 : 0;
+  }
+  const char* v = static_cast<const char*>(v_);
+  char *send = reinterpret_cast<char*>(a.d_send), *recv = reinterpret_cast<char*>(a.d_recv), *x = reinterpret_cast<char*>(a.d_x),
+       *y = reinterpret_cast<char*>(a.d_y), *w = reinterpret_cast<char*>(a.d_w);
   // 1. my slab cut by the receivers' row ranges; my own block goes straight into the panel
   for (int p = 0; p < P; ++p) {
     if (p == me)
-      HIPCHK(copy_block(a.d_x + (size_t)a.cc0[me] * a.pp, a.pp, v + a.ru0[me], s.pitch, nme, q, st));
+      HIPCHK(copy_block(x + (size_t)a.cc0[me] * pp * esz, pp, v + (size_t)a.ru0[me] * esz, pit, nme, q, esz, st));
     else
-      HIPCHK(copy_block(a.d_send + a.sp1[p], a.rn[p], v + a.ru0[p], s.pitch, a.rn[p], q, st));
+      HIPCHK(copy_block(send + (size_t)a.sp1[p] * esz, a.rn[p], v + (size_t)a.ru0[p] * esz, pit, a.rn[p], q, esz, st));
   }
-  rc = comm_sendrecv_cols(h, a.d_send, a.sp1.data(), a.d_recv, a.rp1.data(), sizeof(double2), st);
+  rc = comm_sendrecv_cols(h, send, a.sp1.data(), recv, a.rp1.data(), esz, st);
   if (rc) return rc;
   for (int p = 0; p < P; ++p)
-    if (p != me) HIPCHK(copy_block(a.d_x + (size_t)a.cc0[p] * a.pp, a.pp, a.d_recv + a.rp1[p], nme, nme, a.cq[p], st));
+    if (p != me) HIPCHK(copy_block(x + (size_t)a.cc0[p] * pp * esz, pp, recv + (size_t)a.rp1[p] * esz, nme, nme, a.cq[p], esz, st));
   // 2. dw hops on the row panel [my rows] x [all columns]
-  rc = hxv_apply_dw_panel(a.panel, a.d_x, a.d_y, st);
-  if (rc) return rc;
+  if (real) {
+    if (!a.panel->plan.usable) return fail(HXV_ERR_UNSUPPORTED, "all-to-all exchange: tiled kernels unavailable on the panel");
+    DevSector d = a.panel->dev;
+    d.pitch = (int)pp;
+    hipError_t e = launch_hxv_tiled_real(d, a.panel->plan, reinterpret_cast<const double*>(x), reinterpret_cast<double*>(y), nullptr, st, nullptr, 2, true);
+    if (e != hipSuccess) return fail(HXV_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+  } else {
+    rc = hxv_apply_dw_panel(a.panel, a.d_x, a.d_y, st);
+    if (rc) return rc;
+  }
   // 3. back to the column owners
   for (int p = 0; p < P; ++p) {
     if (p == me)
-      HIPCHK(copy_block(a.d_w + a.ru0[me], s.pitch, a.d_y + (size_t)a.cc0[me] * a.pp, a.pp, nme, q, st));
+      HIPCHK(copy_block(w + (size_t)a.ru0[me] * esz, pit, y + (size_t)a.cc0[me] * pp * esz, pp, nme, q, esz, st));
     else
-      HIPCHK(copy_block(a.d_send + a.sp2[p], nme, a.d_y + (size_t)a.cc0[p] * a.pp, a.pp, nme, a.cq[p], st));
+      HIPCHK(copy_block(send + (size_t)a.sp2[p] * esz, nme, y + (size_t)a.cc0[p] * pp * esz, pp, nme, a.cq[p], esz, st));
   }
-  rc = comm_sendrecv_cols(h, a.d_send, a.sp2.data(), a.d_recv, a.rp2.data(), sizeof(double2), st);
+  rc = comm_sendrecv_cols(h, send, a.sp2.data(), recv, a.rp2.data(), esz, st);
   if (rc) return rc;
   for (int p = 0; p < P; ++p)
-    if (p != me) HIPCHK(copy_block(a.d_w + a.ru0[p], s.pitch, a.d_recv + a.rp2[p], a.rn[p], a.rn[p], q, st));
+    if (p != me) HIPCHK(copy_block(w + (size_t)a.ru0[p] * esz, pit, recv + (size_t)a.rp2[p] * esz, a.rn[p], a.rn[p], q, esz, st));
   // 4. diagonal + up hops + the assembled dw part on the slab (pass A alone, with the Lanczos epilogue when asked for)
   if (!h->plan.usable) return fail(HXV_ERR_UNSUPPORTED, "all-to-all exchange: tiled kernels unavailable (too many distinct amplitudes)");
-  const double2* vbase = v - (int64_t)h->dev.slab0 * h->dev.pitch;  // (pass A addresses its slab as column slots slab0.. of a gathered vector)
-  hipError_t e = launch_hxv_tiled(h->dev, h->plan, vbase, a.d_w, hv, st, ep, 1, true);
+  hipError_t e;
+  if (real) {
+    DevSector d = h->dev;
+    d.pitch = (int)pit;
+    const double* vbase = reinterpret_cast<const double*>(v) - (int64_t)d.slab0 * d.pitch;  // (pass A addresses its slab as column slots slab0..)
+    e = launch_hxv_tiled_real(d, h->plan, vbase, reinterpret_cast<double*>(w), static_cast<double*>(hv_), st, ep, 1, true);
+  } else {
+    const double2* vbase = reinterpret_cast<const double2*>(v) - (int64_t)h->dev.slab0 * h->dev.pitch;
+    e = launch_hxv_tiled(h->dev, h->plan, vbase, a.d_w, static_cast<double2*>(hv_), st, ep, 1, true);
+  }
   if (e != hipSuccess) return fail(HXV_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
   h->n_apply++;
   h->n_exchange += 2;
@@ -450,7 +480,7 @@ static int apply_slab_a2a(hxv_handle* h, const double2* v, double2* hv, hipStrea
 
 int apply_slab(hxv_handle* h, const double2* d_v_local, double2* d_hv_local, hipStream_t st, const LzEpilogue* ep) {
   const SectorHost& s = h->host;
-  if (s.exchange == 2 && s.nranks > 1) return apply_slab_a2a(h, d_v_local, d_hv_local, st, ep);
+  if (s.exchange == 2 && s.nranks > 1) return apply_slab_a2a(h, d_v_local, d_hv_local, false, st, ep);
   const double2* vfull = d_v_local;
   if (s.nranks != 1 || comm_ready(h)) {
     if (!comm_ready(h)) return fail(HXV_ERR_STATE, "split sector without a communicator: call hxv_comm_init after opening the sector");
@@ -470,6 +500,7 @@ int apply_slab(hxv_handle* h, const double2* d_v_local, double2* d_hv_local, hip
 // the same on REAL vectors (double[qdw][pitch_real] slabs; half the bytes on the links)
 int apply_slab_real(hxv_handle* h, const double* d_v_local, double* d_hv_local, hipStream_t st, const LzEpilogue* ep) {
   const SectorHost& s = h->host;
+  if (s.exchange == 2 && s.nranks > 1) return apply_slab_a2a(h, d_v_local, d_hv_local, true, st, ep);
   const double* vfull = d_v_local;
   if (s.nranks != 1 || comm_ready(h)) {
     if (!comm_ready(h)) return fail(HXV_ERR_STATE, "split sector without a communicator: call hxv_comm_init after opening the sector");

@@ -1255,11 +1255,11 @@ hipError_t launch_hxv_tiled(const DevSector& s, const TilePlan& plan, const doub
 }
 
 hipError_t launch_hxv_tiled_real(const DevSector& s, const TilePlan& plan, const double* v, double* wt, double* hv, hipStream_t st,
-                                 const LzEpilogue* lz) {
+                                 const LzEpilogue* lz, int only_pass, bool wt_natural) {
   // REAL vectors (H real; s.pitch must be the real pitch, a multiple of 16): wt needs no more bytes than in complex mode
   if (s.qdw == 0) return hipSuccess;
   if (!s.real_h) return hipErrorInvalidValue;
-  return launch_tiled_vt<double>(s, plan, v, wt, hv, st, lz, 0, false);
+  return launch_tiled_vt<double>(s, plan, v, wt, hv, st, lz, only_pass, wt_natural);
 }
 
 }  // namespace hxv

@@ -126,6 +126,6 @@ hipError_t launch_hxv_tiled(const DevSector& s, const TilePlan& plan, const doub
                             hipStream_t st, const LzEpilogue* lz = nullptr, int only_pass = 0, bool wt_natural = false);
 // Same product on REAL vectors (double elements; H must be real, nranks == 1): s.pitch = real pitch (multiple of 16).
 hipError_t launch_hxv_tiled_real(const DevSector& s, const TilePlan& plan, const double* v, double* wt_scratch, double* hv, hipStream_t st,
-                                 const LzEpilogue* lz = nullptr);
+                                 const LzEpilogue* lz = nullptr, int only_pass = 0, bool wt_natural = false);
 
 }  // namespace hxv

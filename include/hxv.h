@@ -127,7 +127,7 @@ int hxv_slab_home(hxv_handle *h, void **d_slab);
  * reference's own two transposes (vector_transpose_MPI, ED_HAMILTONIAN_COMMON.f90:30-94; spMatVec_mpi_main :272-296) inside the
  * engine -- slab -> row panels (rows split like the columns, :274-275), dw hops on the panel, back, then diagonal + up hops on the slab.
  * Moves (P-1)/P of one slab per rank and transpose instead of P-1 slabs: the lowest-traffic exchange.  hxv_apply_host,
- * hxv_apply_device_slab and the device drivers use it transparently; complex slabs only; hxv_slab_home does not apply.            */
+ * hxv_apply_device_slab and the device drivers (REAL-vector mode included) use it transparently; hxv_slab_home does not apply.   */
 int64_t hxv_exchange_count(const hxv_handle *h); /* exchanges since creation */
 /* HALO exchange (the lower-traffic alternative, replaces the transposes of ED_HAMILTONIAN_COMMON.f90:30-94 differently): with
  * the reference's own DimDw split a rank's rows of H_dw reference only a subset of the other ranks' columns (C3, 8 ranks:
