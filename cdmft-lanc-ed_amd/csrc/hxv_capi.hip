@@ -202,7 +202,7 @@ int hxv_set_nonlocal_csr(hxv_handle* h, const int64_t* rowptr, const int32_t* co
   if (!h || !rowptr) return fail(HXV_ERR_ARG, "hxv_set_nonlocal_csr: NULL argument");
   if (h->host.panel_rows > 0) return fail(HXV_ERR_STATE, "hxv_set_nonlocal_csr: not on a panel handle");
   if (h->host.nd.active) return fail(HXV_ERR_STATE, "hxv_set_nonlocal_csr: the handle already has an spH0nd block");
-  if (h->host.exchange == 1) return fail(HXV_ERR_UNSUPPORTED, "hxv_set_nonlocal_csr: the spH0nd block needs the whole vector (all-gather exchange), not the halo");
+  if (h->host.exchange != 0) return fail(HXV_ERR_UNSUPPORTED, "hxv_set_nonlocal_csr: the spH0nd block needs the whole gathered vector (all-gather exchange)");
   const int64_t nloc = (int64_t)h->host.qdw * h->host.dimup;
   if (rowptr[0] != 0) return fail(HXV_ERR_ARG, "hxv_set_nonlocal_csr: rowptr[0] must be 0");
   for (int64_t i = 0; i < nloc; ++i)

@@ -496,6 +496,10 @@ std::string build_sector_from_csr(int dimup, int dimdw, const int64_t* up_rp, co
     if (diag[2 * i + 1] != 0.0) return "complex diagonal element: not Hermitian";
     s.diag_stored[i] = diag[2 * i];
   }
+  // (the exchange of a split sector is chosen like for sectors opened from a model; a stored spH0nd block -- hxv_set_nonlocal_csr --
+  //  needs the whole gathered vector and is refused on the other two)
+  if (nranks > 1 && default_exchange() == 1) make_halo(s);
+  if (nranks > 1 && default_exchange() == 2) s.exchange = 2;
   return "";
 }
 

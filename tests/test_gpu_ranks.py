@@ -230,3 +230,45 @@ def test_ladder_operators_on_split_sectors(built, nranks, spin, create):
         assert abs(m1 - n1) < 1e-13 and abs(m2 - n2) < 1e-13      # the GLOBAL norms, on every rank
     sa.close()
     sb.close()
+
+
+@pytest.mark.parametrize("exchange", ["allgather", "halo", "alltoall"])
+def test_sectors_opened_from_stored_matrices_on_three_ranks(built, exchange):
+    """hxv_create_from_csr handles (the reference's own spH0ups / spH0dws / spH0d, ED_VARS_GLOBAL.f90:142-144) of a split sector with each
+    of the three exchanges: every rank's slab of the product against the oracle; a stored spH0nd block needs the all-gather."""
+    import torch
+    import hxv
+    from hxv import models
+    from oracle.oracle import OracleSector
+
+    m, (nup, ndw) = models.hm_1dchain(Nlat=2, Nbath=2, eps_bath=[0.3, 0.6]), (3, 2)
+    nranks = 3
+    full = OracleSector(m, nup, ndw)
+    v = models.deterministic_vector(full.Dim)
+    ref = full.spMatVec_main(v)
+    hxv.set_exchange_default(exchange)
+
+    def rank(r, group):
+        orc = OracleSector(m, nup, ndw, r, nranks)
+        sec = hxv.HxvSector.from_csr(orc.DimUp, orc.DimDw, orc.csr("up"), orc.csr("dw"), orc.diag(), rank=r, nranks=nranks)
+        assert sec.exchange_mode == exchange
+        sec.comm_init_local(group)
+        lo, hi = sec.mpiIshift, sec.mpiIshift + sec.vecDim
+        got = sec.unpad(sec.apply_device_slab(sec.pad(torch.from_numpy(v[lo:hi].copy()).cuda(), sec.mpiQdw))).cpu().numpy()
+        refused = None
+        if exchange != "allgather":
+            try:
+                sec.set_nonlocal_csr(np.zeros(sec.vecDim + 1, dtype=np.int64), np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.complex128))
+                refused = False
+            except hxv.HxvError:
+                refused = True
+        sec.close()
+        return lo, hi, got, refused
+
+    try:
+        res = hxv.run_ranks(nranks, rank)
+    finally:
+        hxv.set_exchange_default("allgather")
+    for lo, hi, got, refused in res:
+        assert np.abs(got - ref[lo:hi]).max() <= TOL * np.abs(ref).max()
+        assert refused in (None, True)
