@@ -62,7 +62,8 @@ int hxv_create_from_model(const hxv_model *model, int32_t nup, int32_t ndw, int3
 /* Same, from the reference's own stored matrices (spH0ups(1), spH0dws(1), spH0d of
  * ED_VARS_GLOBAL.f90:142-144) flattened to CSR: rowptr[n+1] (0-based offsets), cols (1-based,
  * as stored by sp_insert_element ED_SPARSE_MATRIX.f90:254-322), vals interleaved complex.
- * diag = the local rows of spH0d (qdw*DimUp complex values, one per row).                */
+ * diag = the local rows of spH0d (qdw*DimUp complex values, one per row).  A split sector (nranks > 1) takes the exchange chosen
+ * by hxv_set_exchange_default like a sector opened from a model.                         */
 int hxv_create_from_csr(int32_t dimup, int32_t dimdw, const int64_t *up_rowptr, const int32_t *up_cols, const double *up_vals,
                         const int64_t *dw_rowptr, const int32_t *dw_cols, const double *dw_vals, const double *diag,
                         int32_t rank, int32_t nranks, int32_t device, hxv_handle **out);
