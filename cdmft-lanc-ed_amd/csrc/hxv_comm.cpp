@@ -328,6 +328,7 @@ struct A2A {
   hxv_handle* panel = nullptr;
   std::vector<int> rn, ru0, cq, cc0;         // per rank: its rows (count, first) and columns (count, first)
   std::vector<int32_t> sp1, rp1, sp2, rp2;   // [P+1] element offsets of the per-peer blocks in the send / receive buffers, both transposes
+  std::vector<int32_t> pan;                  // [P+1] element offsets of the ranks' column ranges in an UNPADDED panel (direct receive / send)
   double2 *d_send = nullptr, *d_recv = nullptr, *d_x = nullptr, *d_y = nullptr, *d_w = nullptr;
   int pp = 0;                                // panel pitch (complex layout)
   int mode = 0;                              // layout the panel / dw-part buffers were last used in (0 complex, 1 real): the pad rows differ
@@ -352,8 +353,19 @@ static int ensure_a2a(hxv_handle* h, hipStream_t st) {
   a->ru0.resize(P);
   a->cq.resize(P);
   a->cc0.resize(P);
+  // Rows are dealt in units of 16 where every rank still gets some: a rank whose row count is a multiple of the panel's pitch granularity
+  // (8 complex / 16 real elements) has an UNPADDED panel, receives its blocks of the first transpose straight into it and sends the
+  // blocks of the second straight out of it -- two of the four strided copies per product go away.
+  const int units = (s.dimup + 15) / 16;
   for (int p = 0; p < P; ++p) {
-    dw_split(s.dimup, p, P, a->rn[p], a->ru0[p]);
+    if (units >= P) {
+      int nu, u0;
+      dw_split(units, p, P, nu, u0);
+      a->ru0[p] = std::min(16 * u0, s.dimup);
+      a->rn[p] = std::min(16 * (u0 + nu), s.dimup) - a->ru0[p];
+    } else {
+      dw_split(s.dimup, p, P, a->rn[p], a->ru0[p]);
+    }
     dw_split(s.dimdw, p, P, a->cq[p], a->cc0[p]);
   }
   const int nme = a->rn[s.rank], qme = s.qdw;
@@ -369,6 +381,8 @@ static int ensure_a2a(hxv_handle* h, hipStream_t st) {
     a->sp2[p + 1] = a->sp2[p] + (self ? 0 : a->cq[p] * nme);   // (the way back: the same blocks, roles swapped)
     a->rp2[p + 1] = a->rp2[p] + (self ? 0 : qme * a->rn[p]);
   }
+  a->pan.assign(P + 1, 0);
+  for (int p = 0; p < P; ++p) a->pan[p + 1] = a->pan[p] + a->cq[p] * nme;
   HIPCHK(hipSetDevice(h->device));
   hxv_handle* ph = new hxv_handle();
   std::string e = make_panel_host(s, nme, ph->host);
@@ -434,10 +448,12 @@ static int apply_slab_a2a(hxv_handle* h, const void* v_, void* hv_, bool real, h
     else
       HIPCHK(copy_block(send + (size_t)a.sp1[p] * esz, a.rn[p], v + (size_t)a.ru0[p] * esz, pit, a.rn[p], q, esz, st));
   }
-  rc = comm_sendrecv_cols(h, send, a.sp1.data(), recv, a.rp1.data(), esz, st);
+  const bool direct = pp == (size_t)nme;  // unpadded panel: a peer's block IS its column range of the panel
+  rc = direct ? comm_sendrecv_cols(h, send, a.sp1.data(), x, a.pan.data(), esz, st) : comm_sendrecv_cols(h, send, a.sp1.data(), recv, a.rp1.data(), esz, st);
   if (rc) return rc;
-  for (int p = 0; p < P; ++p)
-    if (p != me) HIPCHK(copy_block(x + (size_t)a.cc0[p] * pp * esz, pp, recv + (size_t)a.rp1[p] * esz, nme, nme, a.cq[p], esz, st));
+  if (!direct)
+    for (int p = 0; p < P; ++p)
+      if (p != me) HIPCHK(copy_block(x + (size_t)a.cc0[p] * pp * esz, pp, recv + (size_t)a.rp1[p] * esz, nme, nme, a.cq[p], esz, st));
   // 2. dw hops on the row panel [my rows] x [all columns]
   if (real) {
     if (!a.panel->plan.usable) return fail(HXV_ERR_UNSUPPORTED, "all-to-all exchange: tiled kernels unavailable on the panel");
@@ -453,10 +469,10 @@ static int apply_slab_a2a(hxv_handle* h, const void* v_, void* hv_, bool real, h
   for (int p = 0; p < P; ++p) {
     if (p == me)
       HIPCHK(copy_block(w + (size_t)a.ru0[me] * esz, pit, y + (size_t)a.cc0[me] * pp * esz, pp, nme, q, esz, st));
-    else
+    else if (!direct)
       HIPCHK(copy_block(send + (size_t)a.sp2[p] * esz, nme, y + (size_t)a.cc0[p] * pp * esz, pp, nme, a.cq[p], esz, st));
   }
-  rc = comm_sendrecv_cols(h, send, a.sp2.data(), recv, a.rp2.data(), esz, st);
+  rc = direct ? comm_sendrecv_cols(h, y, a.pan.data(), recv, a.rp2.data(), esz, st) : comm_sendrecv_cols(h, send, a.sp2.data(), recv, a.rp2.data(), esz, st);
   if (rc) return rc;
   for (int p = 0; p < P; ++p)
     if (p != me) HIPCHK(copy_block(w + (size_t)a.ru0[p] * esz, pit, recv + (size_t)a.rp2[p] * esz, a.rn[p], a.rn[p], q, esz, st));
