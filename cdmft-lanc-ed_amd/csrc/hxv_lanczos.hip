@@ -894,22 +894,25 @@ int hxv_lanczos_tridiag_pair(hxv_handle* h, const void* d_vin_a, const void* d_v
   if (!h || !d_vin_a || !d_vin_b || nlanc < 1 || !alanc_a || !blanc_a || !alanc_b || !blanc_b)
     return fail(HXV_ERR_ARG, "hxv_lanczos_tridiag_pair: bad argument");
   if (const char* why = real_mode_blocker(h)) return fail(HXV_ERR_UNSUPPORTED, std::string("hxv_lanczos_tridiag_pair: unavailable: ") + why);
-  if (h->host.nranks != 1 || comm_ready(h)) return fail(HXV_ERR_UNSUPPORTED, "hxv_lanczos_tridiag_pair: unsplit sectors only");
+  if (h->host.nranks != 1 && !comm_ready(h))
+    return fail(HXV_ERR_STATE, "device Lanczos on a split sector needs the communicator: call hxv_comm_init after opening the sector");
   if (!h->lz_fused) return fail(HXV_ERR_UNSUPPORTED, "hxv_lanczos_tridiag_pair needs the fused recurrence (option lanczos_fused)");
   if (std::min(4, h->plan.opt.cols_per_tile) > 4) return fail(HXV_ERR_UNSUPPORTED, "hxv_lanczos_tridiag_pair: tile shape");
   HIPCHK(hipSetDevice(h->device));
-  int rc = ensure_lz(h, false);
+  int rc = comm_agree(h, ensure_lz(h, false));  // (split sector: vectors are this rank's slab, every sum below is all-reduced)
   if (rc) return rc;
   rc = ensure_wt(h);
   if (rc) return rc;
+  const bool dist = comm_ready(h);
   const int64_t n = (int64_t)h->host.pitch * h->host.qdw;
   const int g = grid_for(n);
-  const int64_t nwg = tiled_pass_up_workgroups(h->dev, h->plan, false, true);
+  const int64_t nwg = std::max<int64_t>(1, tiled_pass_up_workgroups(h->dev, h->plan, false, true));
   if (2 * nwg > h->lz_partial_n) {
     if (h->d_lz_partial) (void)hipFree(h->d_lz_partial);
     h->d_lz_partial = nullptr;
     h->lz_partial_n = 0;
     HIPCHK(hipMalloc((void**)&h->d_lz_partial, (size_t)2 * nwg * sizeof(double)));
+    HIPCHK(hipMemsetAsync(h->d_lz_partial, 0, (size_t)2 * nwg * sizeof(double), h->stream));  // (a rank without columns launches nothing)
     h->lz_partial_n = 2 * nwg;
   }
   // scalars: [0] alpha_a [1] beta_a [2] s_a [3] c_a [4] alpha_a*s_a ; [8..12] the same for b ; block partials behind them
@@ -923,11 +926,18 @@ int hxv_lanczos_tridiag_pair(hxv_handle* h, const void* d_vin_a, const void* d_v
   double* d_p1 = d_p0 + RED_BLOCKS;
   double* d_p2 = d_p1 + RED_BLOCKS;
   HIPCHK(hipMemsetAsync(d_sc, 0, 16 * sizeof(double), h->stream));
+  // d_sc[slot] = sum (op 0) or 2-norm (op 1) of `np` partial sums -- over all ranks on a split sector
+  auto reduce = [&](const double* part, int np, int slot, int op) -> int {
+    hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, part, np, d_sc, slot, dist ? 0 : op);
+    if (dist) {
+      if (int rca = comm_allreduce_sum(h, d_sc + slot, 1, h->stream)) return rca;
+      if (op) hipLaunchKernelGGL(lz_sqrt, dim3(1), dim3(1), 0, h->stream, d_sc, slot);
+    }
+    return HXV_OK;
+  };
   double2 *q = h->lz_vec[0], *qm = h->lz_vec[1], *w = h->lz_vec[2];
   hipLaunchKernelGGL(lz_pack_pair, dim3(g), dim3(256), 0, h->stream, n, (const double2*)d_vin_a, (const double2*)d_vin_b, q, d_p0, d_p1, d_p2);
-  hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, d_p0, g, d_sc, 5, 0);
-  hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, d_p1, g, d_sc, 6, 1);
-  hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, d_p2, g, d_sc, 7, 1);
+  if ((rc = reduce(d_p0, g, 5, 0)) || (rc = reduce(d_p1, g, 6, 1)) || (rc = reduce(d_p2, g, 7, 1))) return rc;
   double head[3];
   HIPCHK(hipMemcpyAsync(head, d_sc + 5, 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -965,16 +975,18 @@ int hxv_lanczos_tridiag_pair(hxv_handle* h, const void* d_vin_a, const void* d_v
     ep.i_c2 = 11;
     ep.partial = h->d_lz_partial;
     ep.partial2 = h->d_lz_partial + nwg;
-    hipError_t e = launch_hxv_tiled(h->dev, h->plan, q, h->d_wt, w, h->stream, &ep);
-    if (e != hipSuccess) return fail(HXV_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
-    h->n_apply++;
-    hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_lz_partial, (int)nwg, d_sc, 0, 0);
-    hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, h->d_lz_partial + nwg, (int)nwg, d_sc, 8, 0);
+    if (dist) {  // exchange + product (every rank takes this branch together)
+      if ((rc = apply_slab(h, q, w, h->stream, &ep))) return rc;
+    } else {
+      hipError_t e = launch_hxv_tiled(h->dev, h->plan, q, h->d_wt, w, h->stream, &ep);
+      if (e != hipSuccess) return fail(HXV_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+      h->n_apply++;
+    }
+    if ((rc = reduce(h->d_lz_partial, (int)nwg, 0, 0)) || (rc = reduce(h->d_lz_partial + nwg, (int)nwg, 8, 0))) return rc;
     hipLaunchKernelGGL(lz_mul, dim3(1), dim3(1), 0, h->stream, d_sc, 4, 0, 2);
     hipLaunchKernelGGL(lz_mul, dim3(1), dim3(1), 0, h->stream, d_sc, 12, 8, 10);
     hipLaunchKernelGGL(lz_sub_nrm_pair, dim3(g), dim3(256), 0, h->stream, n, w, q, d_sc, 4, 12, d_p0, d_p1);
-    hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, d_p0, g, d_sc, 1, 1);
-    hipLaunchKernelGGL(lz_final, dim3(1), dim3(256), 0, h->stream, d_p1, g, d_sc, 9, 1);
+    if ((rc = reduce(d_p0, g, 1, 1)) || (rc = reduce(d_p1, g, 9, 1))) return rc;
     double host[16];
     HIPCHK(hipMemcpyAsync(host, d_sc, 16 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));

@@ -241,7 +241,8 @@ int hxv_lanczos_eigh_host(hxv_handle *h, int32_t nitermax, double threshold, dou
  * complex Lanczos vector; every scalar of the recurrence, every dot product and both early exits exist once per component.
  * alanc_x/blanc_x[nlanc], *nsteps_x as in hxv_lanczos_tridiag.  Each component's numbers are bit-identical to
  * hxv_lanczos_tridiag on that start vector through the same kernels (option real_vectors = 0; any job_up).
- * nranks == 1.  The _host form takes the start vectors in the reference's contiguous host layout.                        */
+ * Split sectors: slabs per rank, every sum all-reduced (any exchange).  The _host form takes the start vectors in the reference's
+ * contiguous host layout.                                                                                                 */
 int hxv_lanczos_tridiag_pair(hxv_handle *h, const void *d_vin_a, const void *d_vin_b, int32_t nlanc, double *alanc_a, double *blanc_a,
                              double *alanc_b, double *blanc_b, double threshold, int32_t *nsteps_a, int32_t *nsteps_b);
 int hxv_lanczos_tridiag_pair_host(hxv_handle *h, const void *vin_a_host, const void *vin_b_host, int32_t nlanc, double *alanc_a,

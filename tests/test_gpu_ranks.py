@@ -272,3 +272,41 @@ def test_sectors_opened_from_stored_matrices_on_three_ranks(built, exchange):
     for lo, hi, got, refused in res:
         assert np.abs(got - ref[lo:hi]).max() <= TOL * np.abs(ref).max()
         assert refused in (None, True)
+
+
+@pytest.mark.parametrize("nranks,exchange", [(3, "allgather"), (2, "alltoall"), (4, "halo")])
+def test_paired_tridiagonalisation_on_a_split_sector(built, nranks, exchange):
+    """hxv_lanczos_tridiag_pair with slabs per rank: two Green's-function channels on one product of a split sector -- the same numbers
+    as the serial paired run to rounding, identical on every rank."""
+    import torch
+    import hxv
+
+    m, (nup, ndw) = _model("C2")
+    ser = hxv.HxvSector.from_model(m, nup, ndw)
+    rng = np.random.default_rng(11)
+    va = rng.standard_normal(ser.Dim).astype(np.complex128)
+    vb = rng.standard_normal(ser.Dim).astype(np.complex128)
+    va /= np.linalg.norm(va)
+    vb *= 2.5 / np.linalg.norm(vb)          # (not normalised: the driver carries the norm)
+    nl = 30
+    (a0, b0, n0), (a1, b1, n1) = ser.lanczos_tridiag_pair(torch.from_numpy(va).cuda(), torch.from_numpy(vb).cuda(), nl)
+    ser.close()
+    hxv.set_exchange_default(exchange)
+
+    def rank(r, group):
+        sec = hxv.HxvSector.from_model(m, nup, ndw, rank=r, nranks=nranks)
+        sec.comm_init_local(group)
+        lo, hi = sec.mpiIshift, sec.mpiIshift + sec.vecDim
+        out = sec.lanczos_tridiag_pair(torch.from_numpy(va[lo:hi].copy()).cuda(), torch.from_numpy(vb[lo:hi].copy()).cuda(), nl)
+        sec.close()
+        return out
+
+    try:
+        res = hxv.run_ranks(nranks, rank)
+    finally:
+        hxv.set_exchange_default("allgather")
+    for (a, b, n), (a2, b2, n2) in res:
+        assert n == n0 and n2 == n1
+        assert np.abs(a[:12] - a0[:12]).max() < 1e-10 and np.abs(b[:12] - b0[:12]).max() < 1e-10
+        assert np.abs(a2[:12] - a1[:12]).max() < 1e-10 and np.abs(b2[:12] - b1[:12]).max() < 1e-10
+        assert np.array_equal(a, res[0][0][0]) and np.array_equal(b2, res[0][1][1])      # every rank holds the same numbers
