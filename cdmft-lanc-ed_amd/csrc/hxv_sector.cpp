@@ -359,7 +359,8 @@ std::string build_sector_from_model(const hxv_model& m, int nup, int ndw, int ra
   // (the spH0nd block reaches columns that H_dw does not: it keeps the all-gather layout)
   if (nranks > 1 && panel_rows == 0 && default_exchange() == 1 && !(m.norb > 1 && (m.jx != 0.0 || m.jp != 0.0))) make_halo(s);
   // (exchange 2 = the reference's two transposes: the all-gather layout stays, only the product's exchange differs)
-  if (nranks > 1 && panel_rows == 0 && default_exchange() == 2 && !(m.norb > 1 && (m.jx != 0.0 || m.jp != 0.0))) s.exchange = 2;
+  // (its row panels need a row for every rank: tiny sectors keep the all-gather)
+  if (nranks > 1 && nranks <= s.dimup && panel_rows == 0 && default_exchange() == 2 && !(m.norb > 1 && (m.jx != 0.0 || m.jp != 0.0))) s.exchange = 2;
   e = build_ell(s.up);
   if (!e.empty()) return e;
   e = build_ell(s.dw);
@@ -499,7 +500,7 @@ std::string build_sector_from_csr(int dimup, int dimdw, const int64_t* up_rp, co
   // (the exchange of a split sector is chosen like for sectors opened from a model; a stored spH0nd block -- hxv_set_nonlocal_csr --
   //  needs the whole gathered vector and is refused on the other two)
   if (nranks > 1 && default_exchange() == 1) make_halo(s);
-  if (nranks > 1 && default_exchange() == 2) s.exchange = 2;
+  if (nranks > 1 && nranks <= dimup && default_exchange() == 2) s.exchange = 2;
   return "";
 }
 
