@@ -207,6 +207,9 @@ def main():
             home.copy_(v_local)
             v_local = home
     hx = None
+    if halo and not capi_exchange and model.Norb > 1 and (model.Jx != 0 or model.Jp != 0):
+        # (the torch twin's halo plan covers the hopping part only; the engine's own lists -- HxvSector.halo_lists -- also hold the spH0nd partners)
+        raise SystemExit("bench.py: --exchange halo with Jx / Jp runs through the C-ABI only (--backend nccl)")
     if halo:
         rp, cols, _ = sec.csr("dw")
         need, send = hxv.halo_plan(rp, cols - 1, sec.DimDw, world)

@@ -94,7 +94,8 @@ std::string build_ell(SpinOp& op);
 void dw_split(int dimdw, int rank, int nranks, int& qdw, int& dw0);
 void make_vcol(SectorHost& s);
 std::string make_panel_host(const SectorHost& main, int nrows, SectorHost& panel);  // the row panel of the all-to-all exchange
-void make_halo(SectorHost& s);     // needs s.dw (CSR); replaces the all-gather layout by the halo layout
+// needs s.dw (CSR); replaces the all-gather layout by the halo layout (more_*: further referenced columns per column, CSR-like)
+void make_halo(SectorHost& s, const std::vector<int64_t>* more_ptr = nullptr, const std::vector<int32_t>* more_cols = nullptr);
 int default_exchange();            // hxv_set_exchange_default / HXV_EXCHANGE=halo
 void set_default_exchange(int mode);
 std::vector<uint32_t> translate_ell_src(const std::vector<uint32_t>& ell, const std::vector<uint32_t>& vcol);

@@ -226,7 +226,8 @@ std::string make_panel_host(const SectorHost& m, int nrows, SectorHost& p) {
 
 // Halo layout: which columns of the other ranks do the rows of H_dw owned by each rank reference?  Every rank knows the
 // whole one-spin matrix, so it derives its own receive list and what every other rank expects from it without talking.
-void make_halo(SectorHost& s) {
+void make_halo(SectorHost& s, const std::vector<int64_t>* more_ptr, const std::vector<int32_t>* more_cols) {
+  // (more_ptr / more_cols: further columns each column's rows reference besides those of H_dw -- the dw moves of the spH0nd block)
   const int P = s.nranks;
   std::vector<int> owner(s.dimdw), first(P + 1, 0);
   for (int r = 0; r < P; ++r) {
@@ -238,9 +239,13 @@ void make_halo(SectorHost& s) {
   first[P] = s.dimdw;
   auto needed_by = [&](int r) {
     std::vector<char> mark(s.dimdw, 0);
-    for (int c = first[r]; c < first[r + 1]; ++c)
+    for (int c = first[r]; c < first[r + 1]; ++c) {
       for (int64_t p = s.dw.rowptr[c]; p < s.dw.rowptr[c + 1]; ++p)
         if (owner[s.dw.cols[p]] != r) mark[s.dw.cols[p]] = 1;
+      if (more_ptr)
+        for (int64_t p = (*more_ptr)[c]; p < (*more_ptr)[c + 1]; ++p)
+          if (owner[(*more_cols)[p]] != r) mark[(*more_cols)[p]] = 1;
+    }
     std::vector<int32_t> out;
     for (int c = 0; c < s.dimdw; ++c)
       if (mark[c]) out.push_back(c);
@@ -357,7 +362,29 @@ std::string build_sector_from_model(const hxv_model& m, int nup, int ndw, int ra
   }
   apply_hops(s.map_dw, hops_dw, s.dw);
   // (the spH0nd block reaches columns that H_dw does not: it keeps the all-gather layout)
-  if (nranks > 1 && panel_rows == 0 && default_exchange() == 1 && !(m.norb > 1 && (m.jx != 0.0 || m.jp != 0.0))) make_halo(s);
+  if (nranks > 1 && panel_rows == 0 && default_exchange() == 1) {
+    if (m.norb > 1 && (m.jx != 0.0 || m.jp != 0.0)) {
+      // the spH0nd block (sparse/H_non_local.f90:23-98) moves a dw electron between two orbitals of a site: its partner columns join the halo
+      std::vector<int64_t> xp(s.dimdw + 1, 0);
+      std::vector<int32_t> xc;
+      for (int c = 0; c < s.dimdw; ++c) {
+        const uint32_t m0 = s.map_dw[c];
+        for (int il = 0; il < m.nlat; ++il)
+          for (int x = 0; x < m.norb; ++x)
+            for (int y = 0; y < m.norb; ++y) {
+              if (x == y) continue;
+              const int a = mv.imp(il, x), b = mv.imp(il, y);
+              if (!((m0 >> a) & 1u) || ((m0 >> b) & 1u)) continue;
+              const uint32_t m2 = (m0 & ~(1u << a)) | (1u << b);
+              xc.push_back((int32_t)(std::lower_bound(s.map_dw.begin(), s.map_dw.end(), m2) - s.map_dw.begin()));
+            }
+        xp[c + 1] = (int64_t)xc.size();
+      }
+      make_halo(s, &xp, &xc);
+    } else {
+      make_halo(s);
+    }
+  }
   // (exchange 2 = the reference's two transposes: the all-gather layout stays, only the product's exchange differs)
   // (its row panels need a row for every rank: tiny sectors keep the all-gather)
   if (nranks > 1 && nranks <= s.dimup && panel_rows == 0 && default_exchange() == 2 && !(m.norb > 1 && (m.jx != 0.0 || m.jp != 0.0))) s.exchange = 2;

@@ -133,7 +133,7 @@ int64_t hxv_exchange_count(const hxv_handle *h); /* exchanges since creation */
 /* HALO exchange (the lower-traffic alternative, replaces the transposes of ED_HAMILTONIAN_COMMON.f90:30-94 differently): with
  * the reference's own DimDw split a rank's rows of H_dw reference only a subset of the other ranks' columns (C3, 8 ranks:
  * 4.2 slabs instead of the 7 an all-gather moves).  A handle created in halo mode (hxv_set_exchange_default(1) or
- * HXV_EXCHANGE=halo before the create call; not with the spH0nd block) expects d_v_full of hxv_apply_device in the HALO
+ * HXV_EXCHANGE=halo before the create call; with Jx / Jp the partner columns of the spH0nd block's dw moves join the list) expects d_v_full of hxv_apply_device in the HALO
  * LAYOUT: its own qdw columns first, then the columns listed by hxv_halo_lists (ascending = grouped by owner rank);
  * hxv_fullvec_elems() reports the length.  hxv_apply_host / hxv_apply_device_slab / the drivers then exchange exactly
  * those columns (grouped ncclSend/ncclRecv).  recv_counts/send_counts: columns per peer rank; recv_cols: global column

@@ -24,12 +24,15 @@ def _model(name):
         return models.hm_1dchain(eps_bath=[0.3, 0.6]), (6, 6)                         # DimDw = 924
     if name == "bhz":
         return models.bhz_2d(Nbath=0), (4, 4)                                         # complex H, DimDw = 70
+    if name == "kanamori":
+        return models.bhz_2d(Nbath=0, Ust=0.7, Jh=0.2, Jx=0.2, Jp=0.15), (4, 4)       # + the spH0nd block (Jx, Jp)
     raise KeyError(name)
 
 
 @pytest.mark.parametrize("name,nranks,exchange", [("chain", 2, "allgather"), ("chain", 3, "allgather"), ("chain", 3, "halo"), ("C2", 4, "halo"),
                                                   ("C2", 3, "allgather"), ("bhz", 3, "allgather"), ("bhz", 4, "halo"),
-                                                  ("chain", 3, "alltoall"), ("C2", 4, "alltoall"), ("bhz", 3, "alltoall"), ("chain", 2, "alltoall")])
+                                                  ("chain", 3, "alltoall"), ("C2", 4, "alltoall"), ("bhz", 3, "alltoall"), ("chain", 2, "alltoall"),
+                                                  ("kanamori", 3, "allgather"), ("kanamori", 3, "halo"), ("kanamori", 4, "halo")])
 def test_product_of_every_rank_through_the_exchange(built, name, nranks, exchange):
     import torch
     import hxv
@@ -79,7 +82,8 @@ def test_product_of_every_rank_through_the_exchange(built, name, nranks, exchang
 @pytest.mark.parametrize("name,nranks,exchange,real_vectors,fused", [("C2", 3, "allgather", 0, 1), ("C2", 3, "halo", 1, 1), ("C2", 2, "allgather", 1, 0),
                                                                      ("chain", 3, "halo", 0, 0), ("bhz", 3, "allgather", 0, 1),
                                                                      ("C2", 3, "alltoall", 0, 1), ("bhz", 2, "alltoall", 0, 0),
-                                                                     ("C2", 4, "alltoall", 1, 1), ("chain", 3, "alltoall", 1, 0)])
+                                                                     ("C2", 4, "alltoall", 1, 1), ("chain", 3, "alltoall", 1, 0),
+                                                                     ("kanamori", 3, "halo", 0, 1)])
 def test_lanczos_drivers_on_split_sector_equal_the_serial_ones(built, name, nranks, exchange, real_vectors, fused):
     """tridiag, eigh and eigh_lowest with slabs per rank: the same Krylov space as the unsplit sector (the start vectors hash the
     GLOBAL index), alpha/beta/E equal to rounding; every rank returns the same numbers; real vectors and the fused recurrence run
