@@ -145,7 +145,8 @@ int hxv_halo_lists(const hxv_handle *h, int32_t *recv_cols, int32_t *send_cols);
 /* The halo PLAN of any rank of any split, computed from H_dw alone (CSR as hxv_get_csr returns it / as spH0dws(1) stores it:
  * 1-based columns) -- no handle, no device, no communicator: counts[nranks] columns per peer; recv_cols (slot order) and send_cols
  * (grouped by destination) as GLOBAL 0-based column indices, *n_recv / *n_send their lengths (call once with NULL lists to size
- * them).  What one process needs to check that rank p's send list towards q IS rank q's receive list from p, for every pair. */
+ * them).  What one process needs to check that rank p's send list towards q IS rank q's receive list from p, for every pair.
+ * (The hopping part only: a sector with Jx / Jp adds the spH0nd partners -- hxv_halo_lists of its handle is the full list.)      */
 int hxv_halo_plan_from_csr(int32_t dimdw, const int64_t *dw_rowptr, const int32_t *dw_cols, int32_t rank, int32_t nranks,
                            int32_t *recv_counts, int32_t *send_counts, int32_t *recv_cols, int32_t *send_cols, int32_t *n_recv,
                            int32_t *n_send);
