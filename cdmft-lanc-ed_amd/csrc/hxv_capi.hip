@@ -485,6 +485,11 @@ int hxv_set_option(hxv_handle* h, const char* name, int64_t value) {
     h->plan.opt.pair_rows = (int)value;
     return HXV_OK;
   }
+  if (!strcmp(name, "block_order")) {
+    if (value < -1 || value > 2) return fail(HXV_ERR_ARG, "block_order must be -1, 0, 1 or 2");
+    h->plan.opt.block_order = (int)value;
+    return HXV_OK;
+  }
   if (!strcmp(name, "job_max_blocks")) {
     h->plan.opt.job_max_blocks = (int)value;
     return HXV_OK;

@@ -19,7 +19,10 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <condition_variable>
+#include <cstdlib>
+#include <map>
 #include <memory>
 #include <mutex>
 
@@ -42,21 +45,35 @@ struct Rccl {
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
   std::string err;
 };
+// One symbol table per library.  HXV_RCCL_LIB (read at every hxv_comm_unique_id / hxv_comm_init) names the library to use instead of the
+// system's librccl: the test suite points it at tests/rccl_double (thread ranks of ONE process behind RCCL's ten entry points), which is
+// how the RCCL branches below execute with several ranks on a one-GPU box.  A communicator keeps the table it was created with
+// (hxv_handle::comm_api), so handles of both kinds can live in one process.
 Rccl* rccl() {
-  static Rccl r;
-  static std::once_flag once;
-  std::call_once(once, [] {
+  static std::mutex mu;
+  static std::map<std::string, std::unique_ptr<Rccl>> tables;
+  const char* over = getenv("HXV_RCCL_LIB");
+  const std::string key = over && over[0] ? over : "";
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = tables.find(key);
+  if (it != tables.end()) return it->second.get();
+  std::unique_ptr<Rccl> t(new Rccl());
+  Rccl& r = *t;
+  if (!key.empty()) {
+    r.lib = dlopen(key.c_str(), RTLD_NOW | RTLD_LOCAL);
+  } else {
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
       r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
       if (r.lib) break;
     }
-    if (!r.lib) {
-      r.err = std::string("cannot load librccl: ") + dlerror();
-      return;
-    }
+  }
+  if (!r.lib) {
+    const char* de = dlerror();
+    r.err = std::string("cannot load ") + (key.empty() ? "librccl" : key) + ": " + (de ? de : "?");
+  } else {
 #define SYM(field, sym)                                           \
   r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.lib, #sym)); \
-  if (!r.field) r.err = "librccl lacks " #sym;
+  if (!r.field) r.err = "the RCCL library lacks " #sym;
     SYM(GetUniqueId, ncclGetUniqueId)
     SYM(CommInitRank, ncclCommInitRank)
     SYM(CommDestroy, ncclCommDestroy)
@@ -68,12 +85,12 @@ Rccl* rccl() {
     SYM(GroupStart, ncclGroupStart)
     SYM(GroupEnd, ncclGroupEnd)
 #undef SYM
-  });
-  return &r;
+  }
+  return tables.emplace(key, std::move(t)).first->second.get();
 }
-int nccl_fail(const char* what, ncclResult_t e) {
-  Rccl* r = rccl();
-  return fail(HXV_ERR_HIP, std::string(what) + ": " + (r->GetErrorString ? r->GetErrorString(e) : "RCCL error"));
+Rccl* api(const hxv_handle* h) { return static_cast<Rccl*>(h->comm_api); }
+int nccl_fail(const Rccl* r, const char* what, ncclResult_t e) {
+  return fail(HXV_ERR_HIP, std::string(what) + ": " + (r && r->GetErrorString ? r->GetErrorString(e) : "RCCL error"));
 }
 
 // ---- thread ranks: the ranks of a sector are host threads of this process -----------------------------------------
@@ -87,19 +104,37 @@ struct LocalGroup {
   std::vector<hipEvent_t> ready, done;   // by rank: "what I send is in place" / "I have read what the others sent"
   std::vector<std::vector<double>> red;  // by rank: contribution to the running all-reduce
   std::vector<int> flag;                 // by rank: comm_agree
-  // every rank calls it; returns when all have (the ranks issue their collectives in the same order, like MPI ranks)
-  void barrier() {
+  bool broken = false;                   // a rank dropped out (hxv_comm_local_abort) or a barrier timed out: every wait returns an error
+  double timeout_s = 300.0;              // HXV_LOCAL_TIMEOUT_S
+  // Every rank calls it; returns 0 when all have (the ranks issue their collectives in the same order, like MPI ranks), non-zero when the
+  // group is broken: a peer was aborted, or did not arrive in time (then this rank breaks the group for everybody else).
+  int barrier() {
     std::unique_lock<std::mutex> lk(mu);
+    if (broken) return 1;
     const uint64_t g = gen;
     if (++arrived == n) {
       arrived = 0;
       ++gen;
       cv.notify_all();
-    } else {
-      cv.wait(lk, [&] { return gen != g; });
+      return 0;
     }
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(timeout_s);
+    while (gen == g && !broken)
+      if (cv.wait_until(lk, deadline) == std::cv_status::timeout && gen == g) {
+        broken = true;
+        cv.notify_all();
+      }
+    return gen == g ? 1 : 0;
   }
 };
+int broken_group() { return fail(HXV_ERR_STATE, "thread-rank group: a peer rank dropped out (aborted, failed or did not arrive in time); the group is unusable"); }
+// a HIP call inside a collective of the thread-rank transport: the error is remembered, the rank still takes part in the collective's
+// barriers (its peers must not be left waiting) and reports after the last one
+#define HIPREC(expr)                                                                                        \
+  do {                                                                                                      \
+    hipError_t _e = (expr);                                                                                 \
+    if (_e != hipSuccess && rc == HXV_OK) rc = fail(HXV_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
 LocalGroup* lg(const hxv_handle* h) { return reinterpret_cast<LocalGroup*>(h->lgroup); }
 
 // bytes of one column of a Lanczos / product vector: complex(8) columns of `pitch` elements or real ones of pitch_real
@@ -132,34 +167,36 @@ namespace hxv {
 // Columns of `cb` bytes between the ranks of h's communicator: rank r sends send[send_ptr[p] .. send_ptr[p+1]) to every peer p and
 // receives recv[recv_ptr[p] .. recv_ptr[p+1]) from it (offsets in columns; both buffers on the device; asynchronous on st).  The
 // halo exchange of the product and the column moves of the spin-dw ladder operators are this one step.
-int comm_sendrecv_cols(hxv_handle* h, const void* send_v, const int32_t* send_ptr, void* recv_v, const int32_t* recv_ptr, size_t cb, hipStream_t st) {
+int comm_sendrecv_cols(hxv_handle* h, const void* send_v, const int64_t* send_ptr, void* recv_v, const int64_t* recv_ptr, size_t cb, hipStream_t st) {
   const SectorHost& s = h->host;
   const char* send = reinterpret_cast<const char*>(send_v);
   char* recv = reinterpret_cast<char*>(recv_v);
   if (LocalGroup* G = lg(h)) {
+    int rc = HXV_OK;
     h->xfer_send = send;
     h->xfer_send_ptr = send_ptr;
-    HIPCHK(hipEventRecord(G->ready[s.rank], st));
-    G->barrier();
+    HIPREC(hipEventRecord(G->ready[s.rank], st));
+    if (G->barrier()) return broken_group();
     int bad = 0;
     for (int p = 0; p < s.nranks; ++p) {
       if (p == s.rank) continue;
       const hxv_handle* o = G->member[p];
       const size_t nr = (size_t)(recv_ptr[p + 1] - recv_ptr[p]);
       if ((size_t)(o->xfer_send_ptr[s.rank + 1] - o->xfer_send_ptr[s.rank]) != nr) bad = 1;  // the two ranks' plans disagree
-      if (!nr || bad) continue;
-      HIPCHK(hipStreamWaitEvent(st, G->ready[p], 0));
-      HIPCHK(hipMemcpyAsync(recv + (size_t)recv_ptr[p] * cb, o->xfer_send + (size_t)o->xfer_send_ptr[s.rank] * cb, nr * cb, hipMemcpyDefault, st));
+      if (!nr || bad || rc) continue;
+      HIPREC(hipStreamWaitEvent(st, G->ready[p], 0));
+      HIPREC(hipMemcpyAsync(recv + (size_t)recv_ptr[p] * cb, o->xfer_send + (size_t)o->xfer_send_ptr[s.rank] * cb, nr * cb, hipMemcpyDefault, st));
     }
-    HIPCHK(hipEventRecord(G->done[s.rank], st));
-    G->barrier();
+    HIPREC(hipEventRecord(G->done[s.rank], st));
+    if (G->barrier()) return broken_group();
     for (int p = 0; p < s.nranks; ++p)
-      if (p != s.rank) HIPCHK(hipStreamWaitEvent(st, G->done[p], 0));  // my send buffer is free again once they have read it
+      if (p != s.rank) HIPREC(hipStreamWaitEvent(st, G->done[p], 0));  // my send buffer is free again once they have read it
+    if (rc) return rc;
     if (bad) return fail(HXV_ERR_STATE, "column exchange: a peer's send list does not match this rank's receive list");
     return HXV_OK;
   }
   if (!h->comm) return fail(HXV_ERR_STATE, "column exchange without a communicator");
-  Rccl* r = rccl();
+  Rccl* r = api(h);
   ncclResult_t e = r->GroupStart();
   for (int p = 0; p < s.nranks && e == ncclSuccess; ++p) {
     if (p == s.rank) continue;
@@ -168,7 +205,7 @@ int comm_sendrecv_cols(hxv_handle* h, const void* send_v, const int32_t* send_pt
     if (nr && e == ncclSuccess) e = r->Recv(recv + (size_t)recv_ptr[p] * cb, nr, ncclFloat64, p, (ncclComm_t)h->comm, st);
   }
   ncclResult_t e2 = r->GroupEnd();
-  if (e != ncclSuccess || e2 != ncclSuccess) return nccl_fail("grouped send/recv", e != ncclSuccess ? e : e2);
+  if (e != ncclSuccess || e2 != ncclSuccess) return nccl_fail(r, "grouped send/recv", e != ncclSuccess ? e : e2);
   return HXV_OK;
 }
 }  // namespace hxv
@@ -202,7 +239,8 @@ int exchange(hxv_handle* h, const void* d_v_local, bool real, hipStream_t st) {
     if (!at_home) HIPCHK(hipMemcpyAsync(gather, d_v_local, (size_t)s.qdw * cb, hipMemcpyDeviceToDevice, st));
     hipError_t pe = launch_pack_columns((const double2*)d_v_local, h->d_send, h->d_send_cols, (int)s.send_cols.size(), (int)(cb / sizeof(double2)), st);
     if (pe != hipSuccess) return fail(HXV_ERR_HIP, std::string("pack kernel: ") + hipGetErrorString(pe));
-    rc = comm_sendrecv_cols(h, h->d_send, s.send_ptr.data(), gather + (size_t)s.qdw * cb, s.halo_ptr.data(), cb, st);
+    const std::vector<int64_t> sp(s.send_ptr.begin(), s.send_ptr.end()), hp(s.halo_ptr.begin(), s.halo_ptr.end());
+    rc = comm_sendrecv_cols(h, h->d_send, sp.data(), gather + (size_t)s.qdw * cb, hp.data(), cb, st);
     if (rc) return rc;
     h->n_exchange++;
     return HXV_OK;
@@ -213,20 +251,22 @@ int exchange(hxv_handle* h, const void* d_v_local, bool real, hipStream_t st) {
   char* mine = gather + (size_t)s.rank * slot;
   if (!at_home) HIPCHK(hipMemcpyAsync(mine, d_v_local, (size_t)s.qdw * cb, hipMemcpyDeviceToDevice, st));
   if (G) {
-    HIPCHK(hipEventRecord(G->ready[s.rank], st));
-    G->barrier();
+    rc = HXV_OK;
+    HIPREC(hipEventRecord(G->ready[s.rank], st));
+    if (G->barrier()) return broken_group();
     for (int p = 0; p < s.nranks; ++p) {
-      if (p == s.rank) continue;
-      HIPCHK(hipStreamWaitEvent(st, G->ready[p], 0));
-      HIPCHK(hipMemcpyAsync(gather + (size_t)p * slot, reinterpret_cast<const char*>(G->member[p]->gather_cur) + (size_t)p * slot, slot, hipMemcpyDefault, st));
+      if (p == s.rank || rc) continue;
+      HIPREC(hipStreamWaitEvent(st, G->ready[p], 0));
+      HIPREC(hipMemcpyAsync(gather + (size_t)p * slot, reinterpret_cast<const char*>(G->member[p]->gather_cur) + (size_t)p * slot, slot, hipMemcpyDefault, st));
     }
-    HIPCHK(hipEventRecord(G->done[s.rank], st));
-    G->barrier();
+    HIPREC(hipEventRecord(G->done[s.rank], st));
+    if (G->barrier()) return broken_group();
     for (int p = 0; p < s.nranks; ++p)
-      if (p != s.rank) HIPCHK(hipStreamWaitEvent(st, G->done[p], 0));
+      if (p != s.rank) HIPREC(hipStreamWaitEvent(st, G->done[p], 0));
+    if (rc) return rc;
   } else {
-    ncclResult_t e = rccl()->AllGather(mine, gather, slot / sizeof(double), ncclFloat64, (ncclComm_t)h->comm, st);
-    if (e != ncclSuccess) return nccl_fail("ncclAllGather", e);
+    ncclResult_t e = api(h)->AllGather(mine, gather, slot / sizeof(double), ncclFloat64, (ncclComm_t)h->comm, st);
+    if (e != ncclSuccess) return nccl_fail(api(h), "ncclAllGather", e);
   }
   h->n_exchange++;
   return HXV_OK;
@@ -236,6 +276,17 @@ int exchange(hxv_handle* h, const void* d_v_local, bool real, hipStream_t st) {
 namespace hxv {
 
 bool comm_ready(const hxv_handle* h) { return h->comm != nullptr || h->lgroup != nullptr; }
+
+// Does p point into one of the handle's gather buffers (hxv_slab_home hands out a slot of the first)?  The device Lanczos drivers zero
+// the slab's place in all three before they read their start vector: a start vector that lives there is staged first.
+bool comm_in_gather(const hxv_handle* h, const void* p) {
+  const SectorHost& s = h->host;
+  const size_t cbc = col_bytes(h, false);
+  const size_t bytes = s.exchange == 1 ? std::max<size_t>((size_t)s.qdw + s.halo_cols.size(), 1) * cbc : std::max<size_t>((size_t)s.cmax * s.nranks * cbc, 1);
+  for (const double2* b : {h->d_gather, h->d_gather_x[0], h->d_gather_x[1]})
+    if (b && reinterpret_cast<const char*>(p) >= reinterpret_cast<const char*>(b) && reinterpret_cast<const char*>(p) < reinterpret_cast<const char*>(b) + bytes) return true;
+  return false;
+}
 
 // Three places for the slab of a split sector's Lanczos vectors: its slot in the handle's gather buffer and in two more of the same
 // size, so that every vector of the three-term recurrence is exchanged where it lies (no slab copy per product).  The slab regions
@@ -248,11 +299,35 @@ int comm_lz_homes(hxv_handle* h, bool real, double2* out[3]) {
   if (rc) return rc;
   const size_t cbc = col_bytes(h, false);
   const size_t bytes = s.exchange == 1 ? std::max<size_t>((size_t)s.qdw + s.halo_cols.size(), 1) * cbc : std::max<size_t>((size_t)s.cmax * s.nranks * cbc, 1);
+  {
+    // Three whole gather buffers are the right trade only where they fit comfortably (in all-gather layout each is a whole-Dim vector,
+    // and the sectors that get split are the large ones): with less than the missing buffers + 1/16 of the device free (the engine's
+    // cache counted as free) the caller's fall-back runs -- three SLAB buffers, one slab copy per product.
+    size_t need = 0;
+    for (const double2* p : h->d_gather_x)
+      if (!p) need += bytes;
+    if (need) {
+      size_t fr = 0, tot = 0;
+      int64_t cached = 0;
+      HIPCHK(hipMemGetInfo(&fr, &tot));
+      (void)hxv_pool_stats(h->device, &cached, nullptr, nullptr);
+      if (fr + (size_t)cached < need + tot / 16) return fail(HXV_ERR_HIP, "gather buffers of the device Lanczos: not enough free device memory for the in-place layout");
+    }
+  }
   for (auto& p : h->d_gather_x)
     if (!p) {
       hipError_t e = pool_alloc(h->device, bytes, (void**)&p);
       if (e != hipSuccess) {
+        // not enough memory for three whole gather buffers (the sectors that get split are the large ones): give back what this call
+        // obtained, so that the caller's fall-back -- three SLAB buffers and one slab copy per product -- starts from a clean slate
         p = nullptr;
+        (void)hipGetLastError();
+        for (auto& q : h->d_gather_x)
+          if (q) {
+            pool_free(h->device, q);
+            q = nullptr;
+            h->device_bytes -= (int64_t)bytes;
+          }
         return fail(HXV_ERR_HIP, std::string("gather buffers of the device Lanczos: ") + hipGetErrorString(e));
       }
       h->device_bytes += (int64_t)bytes;
@@ -270,23 +345,24 @@ int comm_lz_homes(hxv_handle* h, bool real, double2* out[3]) {
 int comm_allreduce_sum(hxv_handle* h, double* d_buf, size_t count, hipStream_t st) {
   if (LocalGroup* G = lg(h)) {
     // through host memory, summed in rank order on every rank: the same bits everywhere
+    int rc = HXV_OK;
     const int r = h->host.rank;
-    std::vector<double> mine(count);
-    HIPCHK(hipMemcpyAsync(mine.data(), d_buf, count * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    std::vector<double> mine(count, 0.0);
+    HIPREC(hipMemcpyAsync(mine.data(), d_buf, count * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPREC(hipStreamSynchronize(st));
     G->red[r] = mine;
-    G->barrier();
+    if (G->barrier()) return broken_group();
     std::vector<double> tot(count, 0.0);
     for (int p = 0; p < G->n; ++p)
-      for (size_t i = 0; i < count; ++i) tot[i] += G->red[p][i];
-    G->barrier();  // (everybody has read every contribution before anybody overwrites its own)
-    HIPCHK(hipMemcpyAsync(d_buf, tot.data(), count * sizeof(double), hipMemcpyHostToDevice, st));
-    HIPCHK(hipStreamSynchronize(st));
-    return HXV_OK;
+      for (size_t i = 0; i < count && i < G->red[p].size(); ++i) tot[i] += G->red[p][i];
+    if (G->barrier()) return broken_group();  // (everybody has read every contribution before anybody overwrites its own)
+    HIPREC(hipMemcpyAsync(d_buf, tot.data(), count * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPREC(hipStreamSynchronize(st));
+    return rc;
   }
   if (!h->comm) return HXV_OK;  // serial: nothing to add
-  ncclResult_t e = rccl()->AllReduce(d_buf, d_buf, count, ncclFloat64, ncclSum, (ncclComm_t)h->comm, st);
-  if (e != ncclSuccess) return nccl_fail("ncclAllReduce", e);
+  ncclResult_t e = api(h)->AllReduce(d_buf, d_buf, count, ncclFloat64, ncclSum, (ncclComm_t)h->comm, st);
+  if (e != ncclSuccess) return nccl_fail(api(h), "ncclAllReduce", e);
   return HXV_OK;
 }
 
@@ -298,15 +374,15 @@ int comm_agree(hxv_handle* h, int rc_local) {
   int worst = rc_local;
   if (LocalGroup* G = lg(h)) {
     G->flag[h->host.rank] = rc_local;
-    G->barrier();
+    if (G->barrier()) return rc_local ? rc_local : broken_group();
     for (int p = 0; p < G->n; ++p)
       if (G->flag[p] != 0 && worst == 0) worst = G->flag[p];
-    G->barrier();
+    if (G->barrier()) return rc_local ? rc_local : broken_group();
   } else {
     double v = rc_local ? 1.0 : 0.0;
     hipError_t e = hipMemcpyAsync(h->d_scalars + 7, &v, sizeof(double), hipMemcpyHostToDevice, h->stream);
     ncclResult_t ne = ncclSuccess;
-    if (e == hipSuccess) ne = rccl()->AllReduce(h->d_scalars + 7, h->d_scalars + 7, 1, ncclFloat64, ncclMax, (ncclComm_t)h->comm, h->stream);
+    if (e == hipSuccess) ne = api(h)->AllReduce(h->d_scalars + 7, h->d_scalars + 7, 1, ncclFloat64, ncclMax, (ncclComm_t)h->comm, h->stream);
     if (e == hipSuccess && ne == ncclSuccess) e = hipMemcpyAsync(&v, h->d_scalars + 7, sizeof(double), hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess && ne == ncclSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess || ne != ncclSuccess) return fail(HXV_ERR_HIP, "comm_agree: the status all-reduce failed");
@@ -327,8 +403,8 @@ int comm_agree(hxv_handle* h, int rc_local) {
 struct A2A {
   hxv_handle* panel = nullptr;
   std::vector<int> rn, ru0, cq, cc0;         // per rank: its rows (count, first) and columns (count, first)
-  std::vector<int32_t> sp1, rp1, sp2, rp2;   // [P+1] element offsets of the per-peer blocks in the send / receive buffers, both transposes
-  std::vector<int32_t> pan;                  // [P+1] element offsets of the ranks' column ranges in an UNPADDED panel (direct receive / send)
+  std::vector<int64_t> sp1, rp1, sp2, rp2;   // [P+1] element offsets of the per-peer blocks in the send / receive buffers, both transposes
+  std::vector<int64_t> pan;                  // [P+1] element offsets of the ranks' column ranges in an UNPADDED panel (direct receive / send)
   double2 *d_send = nullptr, *d_recv = nullptr, *d_x = nullptr, *d_y = nullptr, *d_w = nullptr;
   int pp = 0;                                // panel pitch (complex layout)
   int mode = 0;                              // layout the panel / dw-part buffers were last used in (0 complex, 1 real): the pad rows differ
@@ -376,13 +452,13 @@ static int ensure_a2a(hxv_handle* h, hipStream_t st) {
   a->rp2.assign(P + 1, 0);
   for (int p = 0; p < P; ++p) {
     const bool self = p == s.rank;
-    a->sp1[p + 1] = a->sp1[p] + (self ? 0 : qme * a->rn[p]);   // my columns, p's rows
-    a->rp1[p + 1] = a->rp1[p] + (self ? 0 : a->cq[p] * nme);   // p's columns, my rows
-    a->sp2[p + 1] = a->sp2[p] + (self ? 0 : a->cq[p] * nme);   // (the way back: the same blocks, roles swapped)
-    a->rp2[p + 1] = a->rp2[p] + (self ? 0 : qme * a->rn[p]);
+    a->sp1[p + 1] = a->sp1[p] + (self ? 0 : (int64_t)qme * a->rn[p]);   // my columns, p's rows
+    a->rp1[p + 1] = a->rp1[p] + (self ? 0 : (int64_t)a->cq[p] * nme);   // p's columns, my rows
+    a->sp2[p + 1] = a->sp2[p] + (self ? 0 : (int64_t)a->cq[p] * nme);   // (the way back: the same blocks, roles swapped)
+    a->rp2[p + 1] = a->rp2[p] + (self ? 0 : (int64_t)qme * a->rn[p]);
   }
   a->pan.assign(P + 1, 0);
-  for (int p = 0; p < P; ++p) a->pan[p + 1] = a->pan[p] + a->cq[p] * nme;
+  for (int p = 0; p < P; ++p) a->pan[p + 1] = a->pan[p] + (int64_t)a->cq[p] * nme;
   HIPCHK(hipSetDevice(h->device));
   hxv_handle* ph = new hxv_handle();
   std::string e = make_panel_host(s, nme, ph->host);
@@ -395,7 +471,7 @@ static int ensure_a2a(hxv_handle* h, hipStream_t st) {
   if (rc) return rc;
   a->panel = out;
   a->pp = out->host.pitch;
-  const size_t nsend = (size_t)std::max(std::max(a->sp1[P], a->sp2[P]), 1), nrecv = (size_t)std::max(std::max(a->rp1[P], a->rp2[P]), 1);
+  const size_t nsend = (size_t)std::max<int64_t>(std::max(a->sp1[P], a->sp2[P]), 1), nrecv = (size_t)std::max<int64_t>(std::max(a->rp1[P], a->rp2[P]), 1);
   const size_t npanel = (size_t)s.dimdw * a->pp, nslab = (size_t)std::max(s.qdw, 1) * s.pitch;
   struct { double2** p; size_t n; } bufs[5] = {{&a->d_send, nsend}, {&a->d_recv, nrecv}, {&a->d_x, npanel}, {&a->d_y, npanel}, {&a->d_w, nslab}};
   for (auto& b : bufs) {
@@ -536,8 +612,9 @@ int apply_slab_real(hxv_handle* h, const double* d_v_local, double* d_hv_local, 
 
 void comm_release(hxv_handle* h) {
   if (h->comm) {
-    (void)rccl()->CommDestroy((ncclComm_t)h->comm);
+    (void)api(h)->CommDestroy((ncclComm_t)h->comm);
     h->comm = nullptr;
+    h->comm_api = nullptr;
   }
   if (LocalGroup* G = lg(h)) {
     // (the group object itself belongs to whoever created it: hxv_comm_local_destroy)
@@ -577,7 +654,7 @@ int hxv_comm_unique_id(void* id128) {
   if (!r->err.empty()) return fail(HXV_ERR_UNSUPPORTED, r->err);
   ncclUniqueId id;
   ncclResult_t e = r->GetUniqueId(&id);
-  if (e != ncclSuccess) return nccl_fail("ncclGetUniqueId", e);
+  if (e != ncclSuccess) return nccl_fail(r, "ncclGetUniqueId", e);
   static_assert(sizeof(id) == HXV_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
   std::memcpy(id128, &id, sizeof(id));
   return HXV_OK;
@@ -594,8 +671,9 @@ int hxv_comm_init(hxv_handle* h, const void* id128) {
   std::memcpy(&id, id128, sizeof(id));
   ncclComm_t c = nullptr;
   ncclResult_t e = r->CommInitRank(&c, h->host.nranks, id, h->host.rank);
-  if (e != ncclSuccess) return nccl_fail("ncclCommInitRank", e);
+  if (e != ncclSuccess) return nccl_fail(r, "ncclCommInitRank", e);
   h->comm = c;
+  h->comm_api = r;
   return HXV_OK;
 }
 
@@ -608,7 +686,22 @@ int hxv_comm_local_create(int32_t nranks, void** group) {
   G->done.assign(nranks, nullptr);
   G->red.resize(nranks);
   G->flag.assign(nranks, 0);
+  if (const char* t = getenv("HXV_LOCAL_TIMEOUT_S")) {
+    const double v = atof(t);
+    if (v > 0.0) G->timeout_s = v;
+  }
   *group = G;
+  return HXV_OK;
+}
+
+// A rank of the group cannot go on (its host thread failed outside the library): wake every peer that waits in a collective and make
+// every later collective of the group return HXV_ERR_STATE.  Callable from any thread, any number of times.
+int hxv_comm_local_abort(void* group) {
+  LocalGroup* G = reinterpret_cast<LocalGroup*>(group);
+  if (!G) return fail(HXV_ERR_ARG, "hxv_comm_local_abort: NULL");
+  std::lock_guard<std::mutex> lk(G->mu);
+  G->broken = true;
+  G->cv.notify_all();
   return HXV_OK;
 }
 
@@ -641,7 +734,7 @@ int hxv_comm_init_local(hxv_handle* h, void* group) {
   if (!G->ready[r]) HIPCHK(hipEventCreateWithFlags(&G->ready[r], hipEventDisableTiming));
   if (!G->done[r]) HIPCHK(hipEventCreateWithFlags(&G->done[r], hipEventDisableTiming));
   h->lgroup = G;
-  G->barrier();  // collective: every rank has joined (one host thread per rank)
+  if (G->barrier()) return broken_group();  // collective: every rank has joined (one host thread per rank)
   return HXV_OK;
 }
 
@@ -685,6 +778,9 @@ int64_t hxv_exchange_count(const hxv_handle* h) { return h ? h->n_exchange : -1;
 int hxv_halo_plan_from_csr(int32_t dimdw, const int64_t* dw_rowptr, const int32_t* dw_cols, int32_t rank, int32_t nranks, int32_t* recv_counts,
                            int32_t* send_counts, int32_t* recv_cols, int32_t* send_cols, int32_t* n_recv, int32_t* n_send) {
   if (dimdw < 1 || !dw_rowptr || !dw_cols || rank < 0 || nranks < 1 || rank >= nranks) return fail(HXV_ERR_ARG, "hxv_halo_plan_from_csr: bad argument");
+  if (dw_rowptr[0] != 0) return fail(HXV_ERR_ARG, "hxv_halo_plan_from_csr: rowptr[0] must be 0");
+  for (int32_t i = 0; i < dimdw; ++i)
+    if (dw_rowptr[i + 1] < dw_rowptr[i]) return fail(HXV_ERR_ARG, "hxv_halo_plan_from_csr: rowptr must be non-decreasing");
   SectorHost s;
   s.dimdw = dimdw;
   s.dw.rowptr.assign(dw_rowptr, dw_rowptr + dimdw + 1);

@@ -19,8 +19,9 @@ void pool_free(int device, void* ptr);
 int ensure_wt(hxv_handle* h);                // (re)allocates the dw-hop scratch of the tiled kernels (hxv_capi.hip)
 // slab exchange of a split sector (hxv_comm.cpp)
 bool comm_ready(const hxv_handle* h);
+bool comm_in_gather(const hxv_handle* h, const void* p);  // p lies in one of the handle's gather buffers (hxv_slab_home)
 int comm_allreduce_sum(hxv_handle* h, double* d_buf, size_t count, hipStream_t st);  // no-op without a communicator
-int comm_sendrecv_cols(hxv_handle* h, const void* send, const int32_t* send_ptr, void* recv, const int32_t* recv_ptr, size_t col_bytes, hipStream_t st);
+int comm_sendrecv_cols(hxv_handle* h, const void* send, const int64_t* send_ptr, void* recv, const int64_t* recv_ptr, size_t col_bytes, hipStream_t st);
 int comm_agree(hxv_handle* h, int rc_local);  // collective: non-zero on every rank if any rank passes non-zero (no-op without a communicator)
 // (H v)|slab from this rank's slab: exchange + product; `ep`: optional Lanczos epilogue of pass A (its partial sums are this rank's share)
 int apply_slab(hxv_handle* h, const double2* d_v_local, double2* d_hv_local, hipStream_t st, const LzEpilogue* ep = nullptr);
@@ -80,9 +81,10 @@ struct hxv_handle {
   int kernel = 1;
   // split sector: RCCL communicator over the nranks handles (hxv_comm_init) and the gathered vector
   void* comm = nullptr;          // ncclComm_t
+  void* comm_api = nullptr;      // the RCCL entry points that communicator was created with (hxv_comm.cpp: the system's librccl, or HXV_RCCL_LIB)
   void* lgroup = nullptr;        // thread ranks of one process (hxv_comm_init_local): the group object, see hxv_comm.cpp
   const char* xfer_send = nullptr;         // thread ranks: what this rank offers in the column exchange under way (comm_sendrecv_cols)
-  const int32_t* xfer_send_ptr = nullptr;  //               and its per-destination offsets
+  const int64_t* xfer_send_ptr = nullptr;  //               and its per-destination offsets
   double2* d_gather = nullptr;   // nranks * cmax * pitch elements (all-gather layout) / (qdw + halo) * pitch (halo layout)
   double2* d_gather_x[2] = {nullptr, nullptr};  // two more of the same for the device Lanczos on a split sector (three vectors rotate)
   double2* gather_cur = nullptr; // the gather buffer the exchange under way / last done runs on (peers of a thread group read it)

@@ -589,6 +589,30 @@ int ensure_lz(hxv_handle* h, bool real) {
   return HXV_OK;
 }
 
+// A start vector that lives in one of the handle's gather buffers (built at hxv_slab_home) would be zeroed by ensure_lz, which clears the
+// slab's place in all three before the driver reads its input: such a vector is copied to a staging slab first (one slab copy per RUN).
+// *tmp is the staging buffer to pool_free after the run, or null.
+int stage_start_vector(hxv_handle* h, const void*& d_vin, double2** tmp) {
+  *tmp = nullptr;
+  if (!comm_ready(h) || !comm_in_gather(h, d_vin)) return HXV_OK;
+  const size_t bytes = (size_t)h->host.pitch * std::max(h->host.qdw, 1) * sizeof(double2);
+  HIPCHK(pool_alloc(h->device, bytes, (void**)tmp));
+  HIPCHK(hipMemcpyAsync(*tmp, d_vin, bytes, hipMemcpyDeviceToDevice, h->stream));
+  d_vin = *tmp;
+  return HXV_OK;
+}
+struct StageFree {
+  hxv_handle* h;
+  double2* p[2];
+  ~StageFree() {
+    for (double2* q : p)
+      if (q) {
+        (void)hipStreamSynchronize(h->stream);
+        pool_free(h->device, q);
+      }
+  }
+};
+
 }  // namespace
 
 namespace hxv {
@@ -661,9 +685,12 @@ extern "C" {
 
 int hxv_lanczos_tridiag(hxv_handle* h, const void* d_vin, int32_t nlanc, double* alanc, double* blanc, double threshold,
                         int32_t* nsteps) {
-  if (!h || !d_vin || nlanc < 1 || !alanc || !blanc) return fail(HXV_ERR_ARG, "hxv_lanczos_tridiag: bad argument");
+  if (!h) return fail(HXV_ERR_ARG, "hxv_lanczos_tridiag: NULL handle");
+  // (split sector: a rank whose arguments are bad tells its peers instead of leaving them in the first all-reduce)
+  if (int rca = comm_agree(h, (!d_vin || nlanc < 1 || !alanc || !blanc) ? fail(HXV_ERR_ARG, "hxv_lanczos_tridiag: bad argument") : HXV_OK)) return rca;
   HIPCHK(hipSetDevice(h->device));
   const int64_t n = (int64_t)h->host.pitch * h->host.qdw;  // this rank's slab
+  StageFree staged{h, {nullptr, nullptr}};
   // REAL-vector mode: H real and the start vector purely real (c / c^dagger applied to a real ground state is) ->
   // the whole recurrence stays real; alanc/blanc are the same numbers at half the bytes per pass
   bool real = want_real(h);
@@ -681,7 +708,8 @@ int hxv_lanczos_tridiag(hxv_handle* h, const void* d_vin, int32_t nlanc, double*
     HIPCHK(hipStreamSynchronize(h->stream));
     real = im2 == 0.0;
   }
-  int rc = comm_agree(h, ensure_lz(h, real));  // (a rank that could not allocate tells its peers before the first all-reduce)
+  int rc = stage_start_vector(h, d_vin, &staged.p[0]);  // (a start vector at hxv_slab_home: staged before its home is cleared)
+  rc = comm_agree(h, rc ? rc : ensure_lz(h, real));  // (a rank that could not allocate tells its peers before the first all-reduce)
   if (rc) return rc;
   LzRunner lz(h, h->lz_vec[0], h->lz_vec[1], h->lz_vec[2], real);
   if (real)
@@ -897,31 +925,40 @@ int hxv_lanczos_tridiag_pair(hxv_handle* h, const void* d_vin_a, const void* d_v
   if (h->host.nranks != 1 && !comm_ready(h))
     return fail(HXV_ERR_STATE, "device Lanczos on a split sector needs the communicator: call hxv_comm_init after opening the sector");
   if (!h->lz_fused) return fail(HXV_ERR_UNSUPPORTED, "hxv_lanczos_tridiag_pair needs the fused recurrence (option lanczos_fused)");
-  if (std::min(4, h->plan.opt.cols_per_tile) > 4) return fail(HXV_ERR_UNSUPPORTED, "hxv_lanczos_tridiag_pair: tile shape");
   HIPCHK(hipSetDevice(h->device));
-  int rc = comm_agree(h, ensure_lz(h, false));  // (split sector: vectors are this rank's slab, every sum below is all-reduced)
-  if (rc) return rc;
-  rc = ensure_wt(h);
-  if (rc) return rc;
+  StageFree staged{h, {nullptr, nullptr}};
   const bool dist = comm_ready(h);
   const int64_t n = (int64_t)h->host.pitch * h->host.qdw;
   const int g = grid_for(n);
   const int64_t nwg = std::max<int64_t>(1, tiled_pass_up_workgroups(h->dev, h->plan, false, true));
-  if (2 * nwg > h->lz_partial_n) {
-    if (h->d_lz_partial) (void)hipFree(h->d_lz_partial);
-    h->d_lz_partial = nullptr;
-    h->lz_partial_n = 0;
-    HIPCHK(hipMalloc((void**)&h->d_lz_partial, (size_t)2 * nwg * sizeof(double)));
-    HIPCHK(hipMemsetAsync(h->d_lz_partial, 0, (size_t)2 * nwg * sizeof(double), h->stream));  // (a rank without columns launches nothing)
-    h->lz_partial_n = 2 * nwg;
-  }
   // scalars: [0] alpha_a [1] beta_a [2] s_a [3] c_a [4] alpha_a*s_a ; [8..12] the same for b ; block partials behind them
   double* d_sc = nullptr;
-  HIPCHK(hipMalloc((void**)&d_sc, (size_t)(16 + 3 * RED_BLOCKS) * sizeof(double)));
+  // every rank-local preparation that can fail comes BEFORE the agreement: a rank that cannot go on makes all ranks return
+  auto prepare = [&]() -> int {
+    int r = stage_start_vector(h, d_vin_a, &staged.p[0]);  // (start vectors at hxv_slab_home: staged before their home is cleared)
+    if (!r) r = stage_start_vector(h, d_vin_b, &staged.p[1]);
+    if (!r) r = ensure_lz(h, false);  // (split sector: vectors are this rank's slab, every sum below is all-reduced)
+    if (!r) r = ensure_wt(h);
+    if (r) return r;
+    if (2 * nwg > h->lz_partial_n) {
+      if (h->d_lz_partial) (void)hipFree(h->d_lz_partial);
+      h->d_lz_partial = nullptr;
+      h->lz_partial_n = 0;
+      HIPCHK(hipMalloc((void**)&h->d_lz_partial, (size_t)2 * nwg * sizeof(double)));
+      HIPCHK(hipMemsetAsync(h->d_lz_partial, 0, (size_t)2 * nwg * sizeof(double), h->stream));  // (a rank without columns launches nothing)
+      h->lz_partial_n = 2 * nwg;
+    }
+    HIPCHK(hipMalloc((void**)&d_sc, (size_t)(16 + 3 * RED_BLOCKS) * sizeof(double)));
+    return HXV_OK;
+  };
+  int rc = comm_agree(h, prepare());
   struct Free {
-    double* p;
-    ~Free() { (void)hipFree(p); }
+    double*& p;
+    ~Free() {
+      if (p) (void)hipFree(p);
+    }
   } guard{d_sc};
+  if (rc) return rc;
   double* d_p0 = d_sc + 16;
   double* d_p1 = d_p0 + RED_BLOCKS;
   double* d_p2 = d_p1 + RED_BLOCKS;
@@ -1167,7 +1204,8 @@ int hxv_apply_ladder_axpy(hxv_handle* from, hxv_handle* to, int32_t orbital, int
     first_b[P] = b.dimdw;
     auto owner_a = [&](int ja) { return (int)(std::upper_bound(first_a.begin(), first_a.end(), ja) - first_a.begin()) - 1; };
     // what I receive: my target columns in order, grouped by the source's owner; what I send: every peer's target columns in ITS order
-    std::vector<int32_t> slot(std::max(b.qdw, 1), 0), sgn(std::max(b.qdw, 1), 0), recv_ptr(P + 1, 0), send_ptr(P + 1, 0), send_cols;
+    std::vector<int32_t> slot(std::max(b.qdw, 1), 0), sgn(std::max(b.qdw, 1), 0), send_cols;
+    std::vector<int64_t> recv_ptr(P + 1, 0), send_ptr(P + 1, 0);
     std::vector<std::vector<int>> want(P);  // per owner: my local target columns whose source it holds, ascending
     for (int c = 0; c < b.qdw; ++c) {
       int sg = 0;
@@ -1187,7 +1225,7 @@ int hxv_apply_ladder_axpy(hxv_handle* from, hxv_handle* to, int32_t orbital, int
     }
     recv_ptr[P] = nrecv;
     for (int p = 0; p < P; ++p) {
-      send_ptr[p] = (int32_t)send_cols.size();
+      send_ptr[p] = (int64_t)send_cols.size();
       if (p == r) continue;
       for (int jb = first_b[p]; jb < first_b[p + 1]; ++jb) {
         int sg = 0;
@@ -1195,7 +1233,7 @@ int hxv_apply_ladder_axpy(hxv_handle* from, hxv_handle* to, int32_t orbital, int
         if (ja >= 0 && owner_a(ja) == r) send_cols.push_back(ja - a.dw0);
       }
     }
-    send_ptr[P] = (int32_t)send_cols.size();
+    send_ptr[P] = (int64_t)send_cols.size();
     const size_t cb = (size_t)a.pitch * sizeof(double2);
     double2 *d_sendbuf = nullptr, *d_recvbuf = nullptr;
     int32_t* d_lists = nullptr;

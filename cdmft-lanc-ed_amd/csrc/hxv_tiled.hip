@@ -153,7 +153,9 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
       }
       // row slots: one table word per row and (block, source block) pair -- or, packed, per TWO such pairs (P16)
       const uint32_t rs1 = t.rs_ptr[kb + 1];
-      if (P16 && t.rs16) {
+      // (eight-column tiles -- real vectors -- keep one word per slot: with the packed words the fused real-vector pass A went from
+      //  1.67 to 1.88 ms at C3, the whole round-3 regression of the real Lanczos iteration, 3.77 -> 3.96 ms; profiles/r04_bisect_real.log)
+      if (P16 && C < 8 && t.rs16) {
         const uint32_t empty16 = (uint32_t)(t.nscoef - 1) << t.p16_bits;
         for (uint32_t sl = t.rs_ptr[kb]; sl < rs1; sl += 2) {
           const uint32_t w = t.rs16[t.rs16_off[sl] + r];
@@ -589,7 +591,7 @@ int choose_lowbits(int ns, int npart, int width, int budget_bytes, int max_block
 
 struct HostTiles {
   std::vector<uint32_t> start, perm, gstart, gmax, ell_in, ell16, tstart;
-  std::vector<uint32_t> bh_ptr, bh, rs_ptr, rs_off, rs_tab, rs_base, rs_neg, order, rs16, rs16_off;
+  std::vector<uint32_t> bh_ptr, bh, rs_ptr, rs_off, rs_tab, rs_base, rs_neg, order, order_pc, rs16, rs16_off;
 };
 
 // sorted_out: outer table indexed by sorted position (pass A) or by natural index (pass B)
@@ -978,6 +980,16 @@ void build_spin_tiles(const SpinOp& op, const std::vector<uint32_t>& map, int lo
   std::iota(h.order.begin(), h.order.end(), 0u);
   std::stable_sort(h.order.begin(), h.order.end(),
                    [&](uint32_t a, uint32_t b) { return h.start[a + 1] - h.start[a] > h.start[b + 1] - h.start[b]; });
+  // Dispatch order of the tile kernels for LARGE sectors (TileOptions::block_order): blocks by the particle number of their high
+  // orbitals, natural order inside.  Two blocks are coupled when their high patterns differ by one hop among the high orbitals (same
+  // particle number) or by one particle (a hop between a low and a high orbital): sorting the patterns of a hypercube by weight, then by
+  // value, is the order that keeps every such pair closest (Harper), and blocks of one weight share their in-block tables anyway.
+  h.order_pc.resize(t.nblocks);
+  std::iota(h.order_pc.begin(), h.order_pc.end(), 0u);
+  if (!map.empty() && lowbits < 32)
+    std::stable_sort(h.order_pc.begin(), h.order_pc.end(), [&](uint32_t a, uint32_t b) {
+      return __builtin_popcount(map[h.start[a]] >> lowbits) < __builtin_popcount(map[h.start[b]] >> lowbits);
+    });
 }
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel and size, not per launch (small sectors are launch-bound)
@@ -1132,7 +1144,7 @@ std::string make_tile_plan(const SectorHost& s, TilePlan& plan, const PlanUpload
         (!h.ell16.empty() && up.u32(h.ell16, &t.d_ell16) != hipSuccess) ||
         up.u32(h.bh_ptr, &t.d_bh_ptr) != hipSuccess || up.u32(h.bh, &t.d_bh) != hipSuccess ||
         up.u32(h.rs_ptr, &t.d_rs_ptr) != hipSuccess || up.u32(h.rs_off, &t.d_rs_off) != hipSuccess ||
-        up.u32(h.rs_tab, &t.d_rs_tab) != hipSuccess || up.u32(h.order, &t.d_order) != hipSuccess ||
+        up.u32(h.rs_tab, &t.d_rs_tab) != hipSuccess || up.u32(h.order, &t.d_order) != hipSuccess || up.u32(h.order_pc, &t.d_order_pc) != hipSuccess ||
         up.u32(h.rs_base, &t.d_rs_base) != hipSuccess || up.u32(h.rs_neg, &t.d_rs_neg) != hipSuccess ||
         up.u32(h.rs16, &t.d_rs16) != hipSuccess || up.u32(h.rs16_off, &t.d_rs16_off) != hipSuccess)
       return "upload of tile tables failed";
@@ -1197,12 +1209,21 @@ template <typename VT>
 static hipError_t launch_tiled_vt(const DevSector& s, const TilePlan& plan, const VT* v, VT* wt, VT* hv, hipStream_t st, const LzEpilogue* lz,
                                   int only_pass, bool wt_natural) {
   constexpr bool RV = std::is_same<VT, double>::value;
+  // dispatch order of a group's blocks (TileOptions::block_order).  Automatic: by the particle number of the high orbitals where table
+  // classes are few (it IS a class order there, and it keeps coupled blocks close: Ns=18 fabric traffic 330 -> 261 GB per product,
+  // 73.1 -> 70.1 ms; Ns=16 -0.8 %; profiles/r04_ab_block_order.log), natural otherwise (11 table sets for 16 blocks, C4: 2.6 % faster).
+  auto pick_order = [&](const SpinTiles& t) -> const uint32_t* {
+    int bo = plan.opt.block_order;
+    if (plan.opt.debug & 32) bo = 2;
+    if (bo < 0) bo = 2 * t.table_classes <= t.nblocks ? 1 : 2;
+    return bo == 0 ? t.d_order : (bo == 1 ? t.d_order_pc : nullptr);
+  };
   DevTiles tu{plan.up.d_start, plan.up.d_tstart, plan.up.d_perm, plan.up.d_gstart, plan.up.d_gmax, plan.up.d_ell_in, plan.up.d_ell16,
               plan.d_scoef_up, plan.up.d_bh_ptr, plan.up.d_bh, plan.up.d_rs_ptr, plan.up.d_rs_off, plan.up.d_rs_tab, plan.up.d_rs_base, plan.up.d_rs_neg,
-              plan.up.nblocks, 2 * plan.ncoef_up + 1, plan.opt.debug, 0, (2 * plan.up.table_classes <= plan.up.nblocks && !(plan.opt.debug & 32)) ? plan.up.d_order : nullptr, plan.up.p16_bits, (plan.up.rs16_on && !(plan.opt.debug & 64)) ? plan.up.d_rs16 : nullptr, plan.up.d_rs16_off};
+              plan.up.nblocks, 2 * plan.ncoef_up + 1, plan.opt.debug, 0, pick_order(plan.up), plan.up.p16_bits, (plan.up.rs16_on && !(plan.opt.debug & 64)) ? plan.up.d_rs16 : nullptr, plan.up.d_rs16_off};
   DevTiles td{plan.dw.d_start, plan.dw.d_tstart, plan.dw.d_perm, plan.dw.d_gstart, plan.dw.d_gmax, plan.dw.d_ell_in, plan.dw.d_ell16,
               plan.d_scoef_dw, plan.dw.d_bh_ptr, plan.dw.d_bh, plan.dw.d_rs_ptr, plan.dw.d_rs_off, plan.dw.d_rs_tab, plan.dw.d_rs_base, plan.dw.d_rs_neg,
-              plan.dw.nblocks, 2 * plan.ncoef_dw + 1, plan.opt.debug, 0, (2 * plan.dw.table_classes <= plan.dw.nblocks && !(plan.opt.debug & 32)) ? plan.dw.d_order : nullptr, plan.dw.p16_bits, (plan.dw.rs16_on && !(plan.opt.debug & 64)) ? plan.dw.d_rs16 : nullptr, plan.dw.d_rs16_off};
+              plan.dw.nblocks, 2 * plan.ncoef_dw + 1, plan.opt.debug, 0, pick_order(plan.dw), plan.dw.p16_bits, (plan.dw.rs16_on && !(plan.opt.debug & 64)) ? plan.dw.d_rs16 : nullptr, plan.dw.d_rs16_off};
   // (class order only where classes are few: with 11 table sets for 16 blocks (C4) the natural order measured 2.6 % faster)
   // (decided below, once the tile's row count R is known)
   const int C = RV ? real_cols(plan) : cplx_cols(plan), R = RV ? real_rows(plan) : plan.opt.rows_per_tile;

@@ -55,6 +55,7 @@ struct SpinTiles {
   double bh_per_row = 0, rs_per_row = 0;  // statistics: block hops / row slots visited per row
   int max_outer = 0;                 // most (row slots + block hops) of any block (register tables of the job kernels)
   uint32_t* d_order = nullptr;       // [nblocks] block indices, largest block first (job order inside a chunk)
+  uint32_t* d_order_pc = nullptr;    // [nblocks] block indices by the particle number of the high orbitals (TileOptions::block_order)
 };
 
 struct TileOptions {
@@ -69,6 +70,9 @@ struct TileOptions {
   int sort_mode_dw = 1;  // pass B inner phase (LDS only): 0 natural, 1 by inner count
   int lds_min_kb_up = 0, lds_min_kb_dw = 0;  // request at least this much LDS per workgroup (limits workgroups per CU)
   int spread_banks = 1;  // in-block hop lists re-dealt per wave so that the LDS gathers of a slot spread over the bank quads (host only)
+  int block_order = -1;  // dispatch order of a group's blocks in the tile kernels: 0 largest first (= by table class), 1 by the particle
+                         // number of the high orbitals (coupled blocks close together: L2 hits of the out-of-block gathers), 2 natural,
+                         // -1 automatic
   int pair_rows = -1;  // pass B order: -1 automatic (paired row groups when two panels exceed the XCD's L2), 0 off, 1 on
   int job_max_blocks = 32;  // pass A runs as jobs only up to this many blocks per spin (beyond, one chunk's jobs no longer fit an XCD's CUs)
   int wt_cols = 4;  // columns per group of the blocked dw-hop scratch (>= cols_per_tile): R*wt_cols*16-byte write runs in pass B

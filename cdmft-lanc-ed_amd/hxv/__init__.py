@@ -3,7 +3,7 @@
 Layout: csrc/ (HIP kernels + C-ABI, built into lib/libhxv.so), fortran/ (ISO_C_BINDING glue for
 the reference's own host code), hxv/ (this Python mirror of the reference interface).
 """
-from .engine import (HxvError, HxvSector, LIB_PATH, LocalGroup, halo_plan_from_csr, load_library, EXPORTS, pool_stats, pool_trim, run_ranks,  # noqa: F401
+from .engine import (HxvError, HxvSector, LIB_PATH, LocalGroup, RcclGroup, halo_plan_from_csr, load_library, EXPORTS, pool_stats, pool_trim, run_ranks,  # noqa: F401
                      set_exchange_default)
 from .hamiltonian import EDContext  # noqa: F401
 from . import models  # noqa: F401

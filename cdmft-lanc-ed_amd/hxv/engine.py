@@ -45,7 +45,7 @@ EXPORTS = [
     "hxv_nnz", "hxv_get_csr", "hxv_get_diag", "hxv_set_option", "hxv_get_option", "hxv_get_stats", "hxv_pool_trim", "hxv_pool_stats", "hxv_last_error",
     "hxv_version", "hxv_comm_unique_id", "hxv_comm_init", "hxv_comm_free", "hxv_apply_device_slab", "hxv_exchange_count",
     "hxv_set_exchange_default", "hxv_exchange_mode", "hxv_halo_counts", "hxv_halo_lists", "hxv_halo_plan_from_csr",
-    "hxv_comm_local_create", "hxv_comm_init_local", "hxv_comm_local_destroy",
+    "hxv_comm_local_create", "hxv_comm_init_local", "hxv_comm_local_destroy", "hxv_comm_local_abort",
 ]
 
 _lib = None
@@ -130,6 +130,7 @@ def load_library():
     L.hxv_comm_local_create.argtypes = [i32, C.POINTER(vp)]
     L.hxv_comm_init_local.argtypes = [vp, vp]
     L.hxv_comm_local_destroy.argtypes = [vp]
+    L.hxv_comm_local_abort.argtypes = [vp]
     _lib = L
     return L
 
@@ -180,17 +181,47 @@ class LocalGroup:
         self._g = g
         self.nranks = nranks
 
+    def join(self, sec: "HxvSector"):
+        """Collective: the handle of this thread's rank joins the group (hxv_comm_init_local)."""
+        sec.comm_init_local(self)
+
+    def abort(self):
+        """A rank's thread failed outside the library: wake every peer that waits in a collective (hxv_comm_local_abort)."""
+        if getattr(self, "_g", None):
+            load_library().hxv_comm_local_abort(self._g)
+
     def close(self):
         if getattr(self, "_g", None):
             _chk(load_library().hxv_comm_local_destroy(self._g), "hxv_comm_local_destroy")
             self._g = None
 
 
-def run_ranks(nranks: int, fn):
-    """Run fn(rank, group) on one host thread per rank of a fresh LocalGroup; returns the list of results (re-raises the first error)."""
+class RcclGroup:
+    """The RCCL transport for ranks that are host threads: one unique id (hxv_comm_unique_id), every rank's thread calls
+    hxv_comm_init.  With the real librccl this needs one GPU per rank; the test suite points HXV_RCCL_LIB at its double
+    (tests/rccl_double) to run the engine's RCCL branches with several ranks on one GPU."""
+
+    def __init__(self, nranks: int):
+        self.nranks = nranks
+        self.id = HxvSector.comm_unique_id()
+
+    def join(self, sec: "HxvSector"):
+        sec.comm_init(self.id)
+
+    def abort(self):
+        pass  # (RCCL has no abort the engine uses; the double's waits time out)
+
+    def close(self):
+        pass
+
+
+def run_ranks(nranks: int, fn, transport: str = "local"):
+    """Run fn(rank, group) on one host thread per rank of a fresh group (transport "local": thread-rank transport; "rccl": the RCCL
+    branches, see RcclGroup); fn joins with group.join(sector).  Returns the list of results (re-raises the first error).  A rank that
+    fails aborts the group, so its peers return from their collectives instead of waiting for it."""
     import threading
 
-    group = LocalGroup(nranks)
+    group = LocalGroup(nranks) if transport == "local" else RcclGroup(nranks)
     out, err = [None] * nranks, [None] * nranks
 
     def work(r):
@@ -198,16 +229,24 @@ def run_ranks(nranks: int, fn):
             out[r] = fn(r, group)
         except BaseException as e:  # noqa: BLE001 (reported to the caller below)
             err[r] = e
+            group.abort()
 
     ts = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
-    for t in ts:
-        t.start()
-    for t in ts:
-        t.join()
-    for e in err:
-        if e is not None:
-            raise e
-    group.close()
+    try:
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+    finally:
+        try:
+            group.close()
+        except HxvError:
+            if not any(err):
+                raise
+    # the rank whose own failure started it, not a peer's "group aborted"
+    first = [e for e in err if e is not None and "thread-rank group" not in str(e)] or [e for e in err if e is not None]
+    if first:
+        raise first[0]
     return out
 
 

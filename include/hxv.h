@@ -104,16 +104,25 @@ int hxv_comm_unique_id(void *id128);
 int hxv_comm_init(hxv_handle *h, const void *id128);
 int hxv_comm_free(hxv_handle *h);
 /* STATUS of N>1 through RCCL: no round of this project has had more than one GPU, and RCCL refuses two ranks on one device, so
- * the RCCL transport has only ever run with ONE rank.  Everything around it -- slab copies, uneven splits, halo lists and
+ * librccl itself has only ever run with ONE rank.  Everything around it -- slab copies, uneven splits, halo lists and
  * offsets, the drivers' all-reduces, the collective error agreement -- is executed with several ranks by the second
- * transport below, which shares that code.
+ * transport below, which shares that code; the RCCL call sites themselves (counts, offsets and pointers of the grouped
+ * ncclSend / ncclRecv, the in-place ncclAllGather, the ncclMax agreement) run with 2-4 ranks against a TEST double of RCCL's ten entry
+ * points (tests/rccl_double, thread ranks of one process): the environment variable HXV_RCCL_LIB, read by hxv_comm_unique_id /
+ * hxv_comm_init, names the library to load instead of the system's librccl (a communicator keeps the library it was made with).
  * THREAD RANKS: the nranks handles of a sector live in ONE process, one host thread per rank (same GPU or different GPUs of
  * the node); slabs travel by device-to-device copies ordered with HIP events, scalars through host memory.  Create the group
  * once, then every rank's thread calls hxv_comm_init_local (collective: it returns when all nranks have joined); from then on
  * hxv_apply_host / hxv_apply_device_slab / the device drivers behave exactly as with hxv_comm_init, each called from its
- * rank's thread.  hxv_comm_free / hxv_destroy leave the group; destroy it afterwards.                                        */
+ * rank's thread.  hxv_comm_free / hxv_destroy leave the group; destroy it afterwards.
+ * A rank that drops out must not leave its peers waiting: a collective of the group gives up with HXV_ERR_STATE when a peer has not
+ * arrived within HXV_LOCAL_TIMEOUT_S seconds (environment, default 300; read by hxv_comm_local_create), or at once after
+ * hxv_comm_local_abort(group) -- what the host program calls when one rank's thread fails outside the library.  A broken group stays
+ * broken: free the handles, destroy it, create a new one.  A HIP error inside a collective is reported by the rank that had it
+ * AFTER the collective's last barrier (its peers complete the step).                                                              */
 int hxv_comm_local_create(int32_t nranks, void **group);
 int hxv_comm_init_local(hxv_handle *h, void *group);
+int hxv_comm_local_abort(void *group);
 int hxv_comm_local_destroy(void *group);
 /* d_hv_local = (H v)|slab from this rank's slab d_v_local (hxv_localvec_elems() elements each, padded device layout):
  * exchange + product, asynchronous on `stream`.  nranks==1 without a communicator: the plain product.              */
@@ -121,8 +130,9 @@ int hxv_apply_device_slab(hxv_handle *h, const void *d_v_local, void *d_hv_local
 /* Where the exchange wants this rank's slab (its slot of the gather buffer): a caller that builds its vector there and hands
  * THAT pointer to hxv_apply_device_slab saves the slab copy of every product.  [qdw columns][pitch] complex elements; allocated on
  * first use; valid until hxv_comm_free / hxv_destroy; the device Lanczos drivers of a split sector keep their own vectors at the same
- * place, so a vector left there does not survive a driver call.  The reference allocates the gathered vector per call and copies
- * (ED_HAMILTONIAN_SPARSE_HxV.f90:277-296).                                                                                */
+ * place, so a vector left there does not survive a driver call -- a START vector of hxv_lanczos_tridiag[_pair] built there is fine: the
+ * drivers stage it (one slab copy per run) before they clear the place.  The reference allocates the gathered vector per call and
+ * copies (ED_HAMILTONIAN_SPARSE_HxV.f90:277-296).                                                                              */
 int hxv_slab_home(hxv_handle *h, void **d_slab);
 /* Exchange mode 2 (hxv_set_exchange_default(2) / HXV_EXCHANGE=alltoall before the sector is opened; not with the spH0nd block): the
  * reference's own two transposes (vector_transpose_MPI, ED_HAMILTONIAN_COMMON.f90:30-94; spMatVec_mpi_main :272-296) inside the
@@ -334,7 +344,9 @@ int hxv_get_diag(const hxv_handle *h, double *diag);
  *   buffers per rank instead of one plus three slabs; no slab copy per product; same numbers bit for bit); get "slab_copies" counts
  *   the exchanges that had to copy.
  * Scheduling knobs (results unchanged): "pair_rows" -1|0|1 [-1 = by sector size: pass B runs the two row groups of a 128-byte line
- *   back to back], "job_max_blocks" [32: pass A as jobs only up to this many blocks per spin], "fold_nd" 0|1 [1: spH0nd inside pass A].
+ *   back to back], "job_max_blocks" [32: pass A as jobs only up to this many blocks per spin], "fold_nd" 0|1 [1: spH0nd inside pass A],
+ *   "block_order" -1|0|1|2 [-1: dispatch order of a group's blocks in the tile kernels -- 1 by the particle number of the high orbitals
+ *   (coupled blocks close together; the automatic choice where table classes are few), 0 largest block first, 2 natural].
  * Timing experiments (results are wrong or partial when set; refused unless HXV_EXPERIMENTS=1 is in the environment):
  *   "passes" 1|2|3 [3], "debug" bit mask, "job_debug" bit mask.
  * hxv_get_option additionally reports plan statistics ("tile_bits_up", "nblocks_up", "slots_in_up_x100", "max_outer_up",

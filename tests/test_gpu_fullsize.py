@@ -1,0 +1,95 @@
+"""Reference values at the HEADLINE size (BASELINE north_star: "ground-state energy within 1e-10 of the CPU reference").
+
+tests/golden/fullsize_e0.json was written in the build container by scripts/make_golden_fullsize.py: a plain three-term Lanczos in
+numpy/BLAS-1 around the CPU oracle's spMatVec_mpi_main (reference algorithm, ED_HAMILTONIAN_SPARSE_HxV.f90:230-315) for
+  C3  cdn_hm_2dsquare Ns=16 sector (8,8), Dim = 165 636 900 (real H)      E0 = -22.6243632403849
+  C4  cdn_bhz_2d      Ns=16 sector (8,8), Dim = 165 636 900 (complex H)
+from the deterministic start vector of SURVEY.md 8d, run until |dE| < 1e-12 and the Ritz residual < 1e-9.  Here the three device
+drivers run the same sectors at full size (call shapes ED_DIAG.f90:152-184, ED_GF_NORMAL.f90:215):
+  hxv_lanczos_tridiag   alanc / blanc of the first 20 steps from the same start vector        1e-10 (relative to max |alanc|)
+                        lowest Ritz value of the fixture's full run length                    1e-10 absolute
+  hxv_lanczos_eigh      E0 (its own hashed start vector)                                      1e-10 absolute
+  hxv_eigh_lowest       E0 (thick-restart Lanczos, ncv = 20)                                  1e-10 absolute
+"""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = json.loads((Path(__file__).parent / "golden" / "fullsize_e0.json").read_text())
+
+
+def _sector(name):
+    import hxv
+    from hxv import models
+
+    m = {"C3": lambda: models.hm_2dsquare(), "C4": lambda: models.bhz_2d(Nbath=1)}[name]()
+    g = GOLD[name]
+    assert m.name == g["model"]
+    hxv.pool_trim()
+    sec = hxv.HxvSector.from_model(m, *g["sector"])
+    assert sec.Dim == g["Dim"] == 165636900
+    return sec, g
+
+
+def _device_start_vector(sec, g):
+    """models.deterministic_vector(Dim) built on the device (sin / cos of the GLOBAL 0-based index), normalised."""
+    import torch
+
+    k = torch.arange(sec.Dim, dtype=torch.float64, device="cuda")
+    v = torch.complex(torch.sin(0.37 * k + 0.11), torch.cos(0.23 * k + 0.05))
+    del k
+    nrm = torch.linalg.vector_norm(v).item()
+    assert abs(nrm - g["start_norm"]) <= 1e-9 * g["start_norm"]
+    v /= nrm
+    return v
+
+
+@pytest.mark.parametrize("name", ["C3", "C4"])
+def test_tridiag_first_steps_and_ritz_value_at_headline_size(built, name):
+    import torch
+    from scipy.linalg import eigh_tridiagonal
+
+    sec, g = _sector(name)
+    v = sec.pad(_device_start_vector(sec, g))
+    a_ref, b_ref = np.array(g["alanc"]), np.array(g["blanc"])
+    n_ref = g["iterations"]
+    a, b, n = sec.lanczos_tridiag(v, n_ref)
+    assert n == n_ref
+    scale = np.abs(a_ref).max()
+    assert np.abs(a[:20] - a_ref[:20]).max() <= 1e-10 * scale, np.abs(a[:20] - a_ref[:20]).max()
+    assert np.abs(b[:20] - b_ref[:20]).max() <= 1e-10 * scale, np.abs(b[:20] - b_ref[:20]).max()
+    assert b[0] == 0.0
+    # what the consumer does with the coefficients (ED_GF_NORMAL.f90:949-953): the tridiagonal matrix's lowest eigenvalue
+    e0 = eigh_tridiagonal(a, b[1:], select="i", select_range=(0, 0))[0][0]
+    assert abs(e0 - g["E0"]) <= 1e-10, (e0, g["E0"])
+    del v
+    sec.close()
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("driver", ["lanczos_eigh", "eigh_lowest"])
+@pytest.mark.parametrize("name", ["C3", "C4"])
+def test_ground_state_energy_at_headline_size(built, name, driver):
+    import torch
+
+    sec, g = _sector(name)
+    if driver == "lanczos_eigh":
+        e0, vec, nit = sec.lanczos_eigh(nitermax=512, threshold=1e-13, native=True)
+    else:
+        ev, vecs, nconv, nmv = sec.eigh_lowest(1, 20, tol=1e-12, native=True)
+        assert nconv >= 1
+        e0, vec = ev[0], vecs[0]
+    assert abs(e0 - g["E0"]) <= 1e-10, (name, driver, e0, g["E0"])
+    # and the vector that came with it is that state: residual through the engine's own product
+    vec = vec.contiguous()
+    hv = sec.apply_device(vec)
+    torch.cuda.synchronize()
+    res = torch.linalg.vector_norm(hv - e0 * vec).item()
+    assert res < 1e-6, res
+    del vec, hv
+    sec.close()
+    torch.cuda.empty_cache()

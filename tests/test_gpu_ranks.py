@@ -1,7 +1,12 @@
 """SEVERAL ranks of a split sector on ONE GPU: the thread-rank transport of csrc/hxv_comm.cpp (hxv_comm_init_local) runs the
 multi-rank code of the C-ABI for real -- slab copies into the all-gather layout, uneven splits, halo lists and offsets, the
 drivers' all-reduces, the fused recurrence and the REAL-vector mode on slabs, the collective error agreement -- everything but
-RCCL's own transport (RCCL refuses two ranks on one device; it has run with one rank only: tests/test_gpu_comm.py).
+RCCL's own transport (RCCL refuses two ranks on one device; librccl has run with one rank only: tests/test_gpu_comm.py).
+Every test runs a second time with transport "rccl_double": the handles join through hxv_comm_unique_id / hxv_comm_init, the path
+one process per GPU takes, with HXV_RCCL_LIB pointing at tests/rccl_double (RCCL's ten entry points for thread ranks of one process),
+so the RCCL branches of hxv_comm.cpp -- the counts, offsets and pointers of the grouped ncclSend / ncclRecv in the halo exchange, both
+transposes and the ladder operators, the in-place ncclAllGather, the ncclSum all-reduces, the ncclMax error agreement -- execute
+with 2-4 ranks against the same references.
 Reference semantics: spMatVec_MPI_main (ED_HAMILTONIAN_SPARSE_HxV.f90:230-315), the DimDw split of ED_HAMILTONIAN.f90:93-105,
 sp_lanc_tridiag / sp_lanc_eigh / sp_eigh called with MpiComm (ED_GF_NORMAL.f90:215, ED_DIAG.f90:152-156,176-177)."""
 import numpy as np
@@ -9,6 +14,15 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-13
+
+
+@pytest.fixture(params=["local", "rccl_double"])
+def transport(request, built, monkeypatch):
+    """-> the `transport` argument of hxv.run_ranks"""
+    if request.param == "local":
+        return "local"
+    monkeypatch.setenv("HXV_RCCL_LIB", str(built.build_rccl_double()))
+    return "rccl"
 
 
 def _rel(a, b):
@@ -33,7 +47,7 @@ def _model(name):
                                                   ("C2", 3, "allgather"), ("bhz", 3, "allgather"), ("bhz", 4, "halo"),
                                                   ("chain", 3, "alltoall"), ("C2", 4, "alltoall"), ("bhz", 3, "alltoall"), ("chain", 2, "alltoall"),
                                                   ("kanamori", 3, "allgather"), ("kanamori", 3, "halo"), ("kanamori", 4, "halo")])
-def test_product_of_every_rank_through_the_exchange(built, name, nranks, exchange):
+def test_product_of_every_rank_through_the_exchange(built, transport, name, nranks, exchange):
     import torch
     import hxv
     from hxv import models
@@ -49,7 +63,7 @@ def test_product_of_every_rank_through_the_exchange(built, name, nranks, exchang
     def rank(r, group):
         sec = hxv.HxvSector.from_model(m, nup, ndw, rank=r, nranks=nranks)
         assert sec.exchange_mode == exchange
-        sec.comm_init_local(group)
+        group.join(sec)
         lo, hi = sec.mpiIshift, sec.mpiIshift + sec.vecDim
         got_host = sec.apply_host(v[lo:hi])                        # spMatVec_MPI_main on this rank's slab, host arrays
         dv = sec.pad(torch.from_numpy(v[lo:hi].copy()).cuda(), sec.mpiQdw)
@@ -70,7 +84,7 @@ def test_product_of_every_rank_through_the_exchange(built, name, nranks, exchang
         return lo, hi, got_host, got_dev, n_ex
 
     try:
-        res = hxv.run_ranks(nranks, rank)
+        res = hxv.run_ranks(nranks, rank, transport=transport)
     finally:
         hxv.set_exchange_default("allgather")
     scale = np.abs(ref).max()
@@ -84,7 +98,7 @@ def test_product_of_every_rank_through_the_exchange(built, name, nranks, exchang
                                                                      ("C2", 3, "alltoall", 0, 1), ("bhz", 2, "alltoall", 0, 0),
                                                                      ("C2", 4, "alltoall", 1, 1), ("chain", 3, "alltoall", 1, 0),
                                                                      ("kanamori", 3, "halo", 0, 1)])
-def test_lanczos_drivers_on_split_sector_equal_the_serial_ones(built, name, nranks, exchange, real_vectors, fused):
+def test_lanczos_drivers_on_split_sector_equal_the_serial_ones(built, transport, name, nranks, exchange, real_vectors, fused):
     """tridiag, eigh and eigh_lowest with slabs per rank: the same Krylov space as the unsplit sector (the start vectors hash the
     GLOBAL index), alpha/beta/E equal to rounding; every rank returns the same numbers; real vectors and the fused recurrence run
     on slabs as well."""
@@ -111,7 +125,7 @@ def test_lanczos_drivers_on_split_sector_equal_the_serial_ones(built, name, nran
         sec = hxv.HxvSector.from_model(m, nup, ndw, rank=r, nranks=nranks)
         sec.set_option("real_vectors", real_vectors)
         sec.set_option("lanczos_fused", fused)
-        sec.comm_init_local(group)
+        group.join(sec)
         lo, hi = sec.mpiIshift, sec.mpiIshift + sec.vecDim
         a, b, n = sec.lanczos_tridiag(torch.from_numpy(v[lo:hi].copy()).cuda(), nl)
         was_real = sec.get_option("lanczos_real_last")
@@ -131,7 +145,7 @@ def test_lanczos_drivers_on_split_sector_equal_the_serial_ones(built, name, nran
         return out
 
     try:
-        res = hxv.run_ranks(nranks, rank)
+        res = hxv.run_ranks(nranks, rank, transport=transport)
     finally:
         hxv.set_exchange_default("allgather")
     gs = np.zeros(ser.Dim, dtype=np.complex128)
@@ -156,7 +170,7 @@ def test_lanczos_drivers_on_split_sector_equal_the_serial_ones(built, name, nran
     ser.close()
 
 
-def test_a_failing_rank_stops_all_ranks_before_the_collective(built):
+def test_a_failing_rank_stops_all_ranks_before_the_collective(built, transport):
     """comm_agree: one rank is asked for more HBM than the device has; every rank returns an error instead of waiting inside an
     all-reduce for a peer that has already left (rank-local early exits)."""
     import hxv
@@ -166,7 +180,7 @@ def test_a_failing_rank_stops_all_ranks_before_the_collective(built):
 
     def rank(r, group):
         sec = hxv.HxvSector.from_model(m, nup, ndw, rank=r, nranks=2)
-        sec.comm_init_local(group)
+        group.join(sec)
         try:
             # ncv beyond the engine's limit is an argument error on every rank: harmless.  The collective one: neigen > Dim on nobody,
             # but a bad ncv only on rank 1 -> rank 0 must not hang
@@ -180,7 +194,7 @@ def test_a_failing_rank_stops_all_ranks_before_the_collective(built):
     import threading
 
     done = []
-    t = threading.Thread(target=lambda: done.append(hxv.run_ranks(2, rank)))
+    t = threading.Thread(target=lambda: done.append(hxv.run_ranks(2, rank, transport=transport)))
     t.start()
     t.join(60)
     assert not t.is_alive(), "a rank is still waiting for its peer: the failure was not made collective"
@@ -189,7 +203,7 @@ def test_a_failing_rank_stops_all_ranks_before_the_collective(built):
 
 @pytest.mark.parametrize("nranks", [2, 3])
 @pytest.mark.parametrize("spin,create", [(0, True), (0, False), (1, True), (1, False)])
-def test_ladder_operators_on_split_sectors(built, nranks, spin, create):
+def test_ladder_operators_on_split_sectors(built, transport, nranks, spin, create):
     """c / c^dagger on the slabs of a split sector (the reference: master-only loop + scatter, ED_GF_NORMAL.f90:174-214): every rank
     builds its slab of the new vector; assembled, it equals the serial device ladder, norm included; mixed channels accumulate
     ((c^dagger_i + xi c^dagger_j)|gs>, ED_GF_NORMAL.f90:746-780)."""
@@ -217,7 +231,7 @@ def test_ladder_operators_on_split_sectors(built, nranks, spin, create):
     def rank(r, group):
         fa = hxv.HxvSector.from_model(m, nup, ndw, rank=r, nranks=nranks)
         fb = hxv.HxvSector.from_model(m, tnup, tndw, rank=r, nranks=nranks)
-        fb.comm_init_local(group)
+        group.join(fb)
         slab = fa.pad(torch.from_numpy(psi[fa.mpiIshift: fa.mpiIshift + fa.vecDim].copy()).cuda(), fa.mpiQdw)
         o1, m1 = fa.apply_ladder(fb, orb_i, spin, create, slab)
         got1 = fb.unpad(o1).cpu().numpy()
@@ -228,7 +242,7 @@ def test_ladder_operators_on_split_sectors(built, nranks, spin, create):
         fb.close()
         return lo, hi, got1, m1, got2, m2
 
-    res = hxv.run_ranks(nranks, rank)
+    res = hxv.run_ranks(nranks, rank, transport=transport)
     for lo, hi, g1, m1, g2, m2 in res:
         assert np.abs(g1 - ref1[lo:hi]).max() < 1e-14 and np.abs(g2 - ref2[lo:hi]).max() < 1e-14
         assert abs(m1 - n1) < 1e-13 and abs(m2 - n2) < 1e-13      # the GLOBAL norms, on every rank
@@ -237,7 +251,7 @@ def test_ladder_operators_on_split_sectors(built, nranks, spin, create):
 
 
 @pytest.mark.parametrize("exchange", ["allgather", "halo", "alltoall"])
-def test_sectors_opened_from_stored_matrices_on_three_ranks(built, exchange):
+def test_sectors_opened_from_stored_matrices_on_three_ranks(built, transport, exchange):
     """hxv_create_from_csr handles (the reference's own spH0ups / spH0dws / spH0d, ED_VARS_GLOBAL.f90:142-144) of a split sector with each
     of the three exchanges: every rank's slab of the product against the oracle; a stored spH0nd block needs the all-gather."""
     import torch
@@ -256,7 +270,7 @@ def test_sectors_opened_from_stored_matrices_on_three_ranks(built, exchange):
         orc = OracleSector(m, nup, ndw, r, nranks)
         sec = hxv.HxvSector.from_csr(orc.DimUp, orc.DimDw, orc.csr("up"), orc.csr("dw"), orc.diag(), rank=r, nranks=nranks)
         assert sec.exchange_mode == exchange
-        sec.comm_init_local(group)
+        group.join(sec)
         lo, hi = sec.mpiIshift, sec.mpiIshift + sec.vecDim
         got = sec.unpad(sec.apply_device_slab(sec.pad(torch.from_numpy(v[lo:hi].copy()).cuda(), sec.mpiQdw))).cpu().numpy()
         refused = None
@@ -270,7 +284,7 @@ def test_sectors_opened_from_stored_matrices_on_three_ranks(built, exchange):
         return lo, hi, got, refused
 
     try:
-        res = hxv.run_ranks(nranks, rank)
+        res = hxv.run_ranks(nranks, rank, transport=transport)
     finally:
         hxv.set_exchange_default("allgather")
     for lo, hi, got, refused in res:
@@ -279,7 +293,7 @@ def test_sectors_opened_from_stored_matrices_on_three_ranks(built, exchange):
 
 
 @pytest.mark.parametrize("nranks,exchange", [(3, "allgather"), (2, "alltoall"), (4, "halo")])
-def test_paired_tridiagonalisation_on_a_split_sector(built, nranks, exchange):
+def test_paired_tridiagonalisation_on_a_split_sector(built, transport, nranks, exchange):
     """hxv_lanczos_tridiag_pair with slabs per rank: two Green's-function channels on one product of a split sector -- the same numbers
     as the serial paired run to rounding, identical on every rank."""
     import torch
@@ -299,14 +313,14 @@ def test_paired_tridiagonalisation_on_a_split_sector(built, nranks, exchange):
 
     def rank(r, group):
         sec = hxv.HxvSector.from_model(m, nup, ndw, rank=r, nranks=nranks)
-        sec.comm_init_local(group)
+        group.join(sec)
         lo, hi = sec.mpiIshift, sec.mpiIshift + sec.vecDim
         out = sec.lanczos_tridiag_pair(torch.from_numpy(va[lo:hi].copy()).cuda(), torch.from_numpy(vb[lo:hi].copy()).cuda(), nl)
         sec.close()
         return out
 
     try:
-        res = hxv.run_ranks(nranks, rank)
+        res = hxv.run_ranks(nranks, rank, transport=transport)
     finally:
         hxv.set_exchange_default("allgather")
     for (a, b, n), (a2, b2, n2) in res:
@@ -314,3 +328,82 @@ def test_paired_tridiagonalisation_on_a_split_sector(built, nranks, exchange):
         assert np.abs(a[:12] - a0[:12]).max() < 1e-10 and np.abs(b[:12] - b0[:12]).max() < 1e-10
         assert np.abs(a2[:12] - a1[:12]).max() < 1e-10 and np.abs(b2[:12] - b1[:12]).max() < 1e-10
         assert np.array_equal(a, res[0][0][0]) and np.array_equal(b2, res[0][1][1])      # every rank holds the same numbers
+
+
+def test_a_rank_thread_that_fails_outside_the_library_wakes_its_peers(built):
+    """a Python error in one rank's thread (here: before it joins) must not leave the peers inside cv.wait forever --
+    hxv.run_ranks aborts the group (hxv_comm_local_abort), the peers' collective returns HXV_ERR_STATE, the ORIGINAL error is raised."""
+    import threading
+    import hxv
+
+    m, (nup, ndw) = _model("chain")
+    seen = []
+
+    def rank(r, group):
+        sec = hxv.HxvSector.from_model(m, nup, ndw, rank=r, nranks=3)
+        try:
+            if r == 1:
+                raise RuntimeError("rank 1 failed before joining")
+            try:
+                group.join(sec)
+            except hxv.HxvError as e:
+                seen.append(str(e))
+                raise
+        finally:
+            sec.close()
+
+    out = []
+
+    def runner():
+        try:
+            hxv.run_ranks(3, rank)
+        except BaseException as e:  # noqa: BLE001
+            out.append(e)
+
+    t = threading.Thread(target=runner)
+    t.start()
+    t.join(60)
+    assert not t.is_alive(), "the peers of the failed rank are still waiting"
+    assert len(out) == 1 and isinstance(out[0], RuntimeError) and "rank 1 failed" in str(out[0]), out
+    assert len(seen) == 2 and all("dropped out" in s for s in seen), seen
+
+
+@pytest.mark.parametrize("exchange,real_vectors", [("allgather", 0), ("halo", 1)])
+def test_start_vector_built_at_the_slab_home(built, transport, exchange, real_vectors):
+    """the drivers clear the slab's place in their three gather buffers before they read their input; a start vector that
+    was built exactly there (hxv_slab_home) is staged first instead of being turned into zeros."""
+    import torch
+    import hxv
+
+    m, (nup, ndw) = _model("C2")
+    ser = hxv.HxvSector.from_model(m, nup, ndw)
+    ser.set_option("real_vectors", real_vectors)
+    rng = np.random.default_rng(3)
+    v = rng.standard_normal(ser.Dim) + (0.0 if real_vectors else 1j * rng.standard_normal(ser.Dim))
+    v = (v / np.linalg.norm(v)).astype(np.complex128)
+    a0, b0, n0 = ser.lanczos_tridiag(torch.from_numpy(v).cuda(), 30)
+    ser.close()
+    hxv.set_exchange_default(exchange)
+
+    def rank(r, group):
+        sec = hxv.HxvSector.from_model(m, nup, ndw, rank=r, nranks=3)
+        sec.set_option("real_vectors", real_vectors)
+        group.join(sec)
+        lo, hi = sec.mpiIshift, sec.mpiIshift + sec.vecDim
+        home = sec.slab_home()
+        home.copy_(sec.pad(torch.from_numpy(v[lo:hi].copy()).cuda(), sec.mpiQdw))
+        a, b, n = sec.lanczos_tridiag(home, 30)
+        (aa, ba, na), (ab, bb, nb) = ((a, b, n), (a, b, n))
+        if real_vectors:  # the paired driver reads two start vectors: both at home
+            (aa, ba, na), (ab, bb, nb) = sec.lanczos_tridiag_pair(home, home, 30)
+        sec.close()
+        return a, b, n, aa, ba, ab, bb
+
+    try:
+        res = hxv.run_ranks(3, rank, transport=transport)
+    finally:
+        hxv.set_exchange_default("allgather")
+    for a, b, n, aa, ba, ab, bb in res:
+        assert n == n0
+        for x, y in ((a, a0), (b, b0), (aa, a0), (ba, b0), (ab, a0), (bb, b0)):
+            assert np.abs(x - y).max() <= 1e-11 * max(np.abs(y).max(), 1.0)
