@@ -394,7 +394,8 @@ def test_start_vector_built_at_the_slab_home(built, transport, exchange, real_ve
         home.copy_(sec.pad(torch.from_numpy(v[lo:hi].copy()).cuda(), sec.mpiQdw))
         a, b, n = sec.lanczos_tridiag(home, 30)
         (aa, ba, na), (ab, bb, nb) = ((a, b, n), (a, b, n))
-        if real_vectors:  # the paired driver reads two start vectors: both at home
+        if real_vectors:  # the paired driver reads two start vectors: both at home (refilled: nothing left there survives a driver call)
+            home.copy_(sec.pad(torch.from_numpy(v[lo:hi].copy()).cuda(), sec.mpiQdw))
             (aa, ba, na), (ab, bb, nb) = sec.lanczos_tridiag_pair(home, home, 30)
         sec.close()
         return a, b, n, aa, ba, ab, bb
