@@ -130,7 +130,8 @@ def main():
                     help="one GPU, launched through torch.distributed.run with ONE rank: run exactly the calls of the N>1 path "
                          "(process group on RCCL, hxv_comm_unique_id -> broadcast -> hxv_comm_init -> hxv_slab_home -> hxv_apply_device_slab, "
                          "barrier, max over ranks) on a one-rank communicator")
-    ap.add_argument("--check", action="store_true", help="N>1 rehearsal: verify the sharded product against the unsharded one on rank 0")
+    ap.add_argument("--no-check", action="store_true", help="N>1: skip the one checked product before the warm-up (split vs unsplit product on every rank)")
+    ap.add_argument("--check", action="store_true", help="(kept for old command lines: the check is the default now)")
     args = ap.parse_args()
 
     import torch
@@ -169,79 +170,101 @@ def main():
         model, (nup, ndw) = models.hm_ring(6, 2), (9, 9)
 
     by_sector = world > 1 and args.parallelism == "sectors"
-    halo = world > 1 and args.exchange == "halo" and not by_sector
-    a2a_capi = world > 1 and args.exchange == "alltoall" and not by_sector and args.backend == "nccl"
-    if halo:
-        hxv.set_exchange_default("halo")          # the handle's gathered-vector layout is chosen when the sector is opened
-    if a2a_capi:
-        hxv.set_exchange_default("alltoall")      # the reference's two transposes, inside the engine (hxv_apply_device_slab)
+    # N>1 on RCCL (the default): the exchange runs behind the C-ABI, exactly what a Fortran rank of the reference would call
+    # (hxv_comm_unique_id on rank 0 -> the host program's own broadcast -> hxv_comm_init -> hxv_apply_device_slab), for all three
+    # exchanges.  --backend gloo (CPU rendezvous, rehearsals only) goes through the torch twin hxv/distributed.py instead.
+    capi_exchange = multi and not by_sector and args.backend == "nccl"
+    twin = multi and not by_sector and not capi_exchange
+    if multi and not by_sector and args.exchange != "allgather":
+        hxv.set_exchange_default(args.exchange if capi_exchange or args.exchange == "halo" else "allgather")   # layout chosen when the sector is opened
     if by_sector:
         sec = hxv.HxvSector.from_model(model, nup, ndw, device=local_rank)      # the whole sector on every GPU
     else:
         sec = hxv.HxvSector.from_model(model, nup, ndw, rank=rank, nranks=world, device=local_rank)
+    hxv.set_exchange_default("allgather")
     Dim, Nloc = sec.Dim, sec.localElems   # Nloc: local vector length in the padded device layout (include/hxv.h)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     v_local = torch.randn(Nloc, dtype=torch.float64, device=dev, generator=g) + 1j * torch.randn(Nloc, dtype=torch.float64, device=dev, generator=g)
+    torch.view_as_real(v_local).view(-1, sec.pitch, 2)[:, sec.DimUp:, :] = 0.0   # (pad rows are zero in every device vector)
     hv_local = torch.empty(Nloc, dtype=torch.complex128, device=dev)
-    hxv.set_exchange_default("allgather")
-    if halo and sec.exchange_mode != "halo":
-        # (e.g. the spH0nd block keeps the all-gather layout): never feed halo-layout vectors to an all-gather handle
+    if multi and not by_sector and world > 1 and sec.exchange_mode != args.exchange and (capi_exchange or args.exchange == "halo"):
+        # (the spH0nd block keeps the all-gather exchange in mode 2; tiny sectors keep it too): report what actually runs
         if rank == 0:
-            print("bench.py: the sector was opened in all-gather layout; --exchange halo falls back to allgather", file=sys.stderr)
-        halo = False
-        args.exchange = "allgather"
-    sh = hxv.ShardedHxv(sec.DimUp, sec.DimDw, 0 if by_sector else rank, 1 if by_sector else world, sec.apply_device, pitch=sec.pitch)
-    # N>1 on RCCL: the exchange runs behind the C-ABI, exactly what a Fortran rank of the reference would call
-    # (hxv_comm_unique_id on rank 0 -> the host program's own broadcast -> hxv_comm_init -> hxv_apply_device_slab)
-    if a2a_capi and sec.exchange_mode != "alltoall":   # (e.g. the spH0nd block keeps the all-gather exchange)
-        a2a_capi = False
-        args.exchange = "allgather"
-    capi_exchange = multi and not by_sector and args.backend == "nccl" and (args.exchange in ("allgather", "halo") or a2a_capi)
+            print(f"bench.py: the sector was opened with the {sec.exchange_mode} exchange; --exchange {args.exchange} does not apply", file=sys.stderr)
+        args.exchange = sec.exchange_mode
+    halo = twin and args.exchange == "halo"
+    sh = hx = th = None
     if capi_exchange:
         ident = [hxv.HxvSector.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ident, src=0)
         sec.comm_init(ident[0])
         # the slab lives where the exchange wants it (hxv_slab_home), as a device-resident Lanczos vector can: no slab copy per product
-        if not a2a_capi:
+        if sec.exchange_mode != "alltoall":
             home = sec.slab_home()
             home.copy_(v_local)
             v_local = home
-    hx = None
-    if halo and not capi_exchange and model.Norb > 1 and (model.Jx != 0 or model.Jp != 0):
-        # (the torch twin's halo plan covers the hopping part only; the engine's own lists -- HxvSector.halo_lists -- also hold the spH0nd partners)
-        raise SystemExit("bench.py: --exchange halo with Jx / Jp runs through the C-ABI only (--backend nccl)")
-    if halo:
-        rp, cols, _ = sec.csr("dw")
-        need, send = hxv.halo_plan(rp, cols - 1, sec.DimDw, world)
-        hx = hxv.HaloHxv(sec.DimUp, sec.DimDw, rank, world, need, send, sec.apply_device, pitch=sec.pitch, stage_on_host=(args.backend != "nccl"))
-    if world > 1 and args.exchange == "alltoall" and not by_sector and not a2a_capi:
-        nrows = hxv.dw_split(sec.DimUp, rank, world)[0]
-        panel = hxv.HxvSector.dw_panel(model, nup, ndw, nrows, device=local_rank)
-        th = hxv.TransposedHxv(sec.DimUp, sec.DimDw, rank, world, panel.apply_dw_panel, sec.apply_up_add, pitch=sec.pitch,
-                               pitch_panel=panel.pitch, stage_on_host=(args.backend != "nccl"))
+    elif twin:
+        # torch twin of the three exchanges (hxv/distributed.py): --backend gloo only
+        sh = hxv.ShardedHxv(sec.DimUp, sec.DimDw, rank, world, sec.apply_device, pitch=sec.pitch)
+        if halo:
+            if model.Norb > 1 and (model.Jx != 0 or model.Jp != 0):
+                raise SystemExit("bench.py: --exchange halo with Jx / Jp runs through the C-ABI only (--backend nccl)")
+            rp, cols, _ = sec.csr("dw")
+            need, send = hxv.halo_plan(rp, cols - 1, sec.DimDw, world)
+            hx = hxv.HaloHxv(sec.DimUp, sec.DimDw, rank, world, need, send, sec.apply_device, pitch=sec.pitch, stage_on_host=True)
+        if args.exchange == "alltoall":
+            nrows = hxv.dw_split(sec.DimUp, rank, world)[0]
+            panel = hxv.HxvSector.dw_panel(model, nup, ndw, nrows, device=local_rank)
+            th = hxv.TransposedHxv(sec.DimUp, sec.DimDw, rank, world, panel.apply_dw_panel, sec.apply_up_add, pitch=sec.pitch,
+                                   pitch_panel=panel.pitch, stage_on_host=True)
 
     def step():
         if capi_exchange:
             sec.apply_device_slab(v_local, hv_local)
-        elif world > 1 and args.exchange == "alltoall" and not by_sector and not a2a_capi:
+        elif th is not None:
             th(Nloc, v_local, hv_local)
-        elif halo:
+        elif hx is not None:
             hx(Nloc, v_local, hv_local)
-        else:
+        elif sh is not None:
             sh(Nloc, v_local, hv_local)
+        else:
+            sec.apply_device(v_local, hv_local)
 
-    if args.check and world > 1 and not by_sector:
-        # rehearsal: every rank's slab of the sharded product == the same slab of the unsharded product
+    checked, check_err = False, None
+    if multi and not by_sector and not args.no_check:
+        # ONE product before the warm-up, checked on every rank: this rank's slab of the split product == the same slab of the
+        # unsplit product of the assembled vector (the N>1 path has never met a second GPU: the first run on a node must not be blind)
         step()
+        cmax = -(-sec.DimDw // world)
+        mine = torch.zeros(cmax * sec.pitch, dtype=torch.complex128, device=dev)
+        mine[:Nloc] = v_local
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        if args.backend == "nccl":
+            dist.all_gather(parts, mine)
+        else:
+            hp = [torch.empty(mine.shape, dtype=mine.dtype) for _ in range(world)]
+            dist.all_gather(hp, mine.cpu())
+            parts = [x.to(dev) for x in hp]
+        qs = [sec.DimDw // world + (1 if r < sec.DimDw % world else 0) for r in range(world)]   # ED_HAMILTONIAN.f90:93-98
+        vg = torch.cat([parts[r][: qs[r] * sec.pitch] for r in range(world)])
+        del parts, mine
         full_sec = hxv.HxvSector.from_model(model, nup, ndw, device=local_rank)
-        vg = sh.unpad(sh.gather(v_local)).contiguous()
-        ref = full_sec.apply_device(vg)[sec.mpiIshift: sec.mpiIshift + sec.vecDim]
+        c0 = sum(qs[:rank])
+        ref = full_sec.apply_device(vg)[c0 * sec.pitch: (c0 + qs[rank]) * sec.pitch]
         torch.cuda.synchronize()
-        err = (ref - sec.unpad(hv_local)).abs().max().item() / ref.abs().max().item()
-        print(f"[rank {rank}] sharded vs unsharded slab: rel err {err:.2e}", flush=True)
-        assert err < 1e-13
+        ref, got = (x.view(-1, sec.pitch)[:, : sec.DimUp] for x in (ref, hv_local))   # (pad rows are never written by the product)
+        check_err = (ref - got).abs().max().item() / max(ref.abs().max().item(), 1e-300)
+        del got
         full_sec.close()
         del vg, ref
+        torch.cuda.empty_cache()
+        hxv.pool_trim(local_rank)
+        t = torch.tensor([check_err], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        check_err = float(t.item())
+        checked = True
+        if check_err > 1e-13:
+            raise SystemExit(f"bench.py: the split product differs from the unsplit one (max rel err over ranks {check_err:.2e}); no number reported")
     for _ in range(args.warmup):
         step()
     if multi:
@@ -262,9 +285,15 @@ def main():
     value = (world if by_sector else 1) * 32.0 * Dim / (ms_step * 1e-3) / 1e9   # sectors: every rank finished a whole product
 
     # roofline of the product's kernels on this rank: HIP events on the stream they are launched on
-    vfull = hx.exchange(v_local) if halo else sh.gather(v_local)
-    torch.cuda.synchronize()
-    k_ms = sec.time_apply(vfull, hv_local, max(5, min(args.steps, 20)))
+    nk = max(5, min(args.steps, 20))
+    if capi_exchange:
+        step_ev_ms, k_ms = sec.time_apply_slab(v_local, hv_local, nk)      # (collective: every rank runs the same nk products)
+    else:
+        vfull = hx.exchange(v_local) if hx is not None else (sh.gather(v_local) if sh is not None else v_local)
+        torch.cuda.synchronize()
+        k_ms = sec.time_apply(vfull, hv_local, nk)
+        step_ev_ms = None
+        del vfull
     achieved = 32.0 * sec.vecDim / (k_ms * 1e-3) / 1e9
     # HBM-side bytes per product come from a separate rocprofv3 --pmc collection (scripts/prof_traffic.sh ->
     # profiles/traffic.json); the figure is only quoted for the kernel build it was collected on (its `kernels` stamp)
@@ -285,6 +314,8 @@ def main():
                 "design_floor_ms": round(floor_ms, 4), "frac_of_design_floor": round(floor_ms / k_ms, 4), "copy_rate_GBs": round(copy_gbs, 1),
                 "traffic": traffic, "traffic_source": traffic_src, "kernel": ("hxv_up_job" if sec.get_option("job_up_active") else "hxv_pass_up") + " + hxv_pass_dw (one product)", "kernel_ms": round(k_ms, 4),
                 "algorithmic_bytes": 32 * sec.vecDim}
+    if step_ev_ms is not None:
+        roofline["slab_product_ms_on_stream"] = round(step_ev_ms, 4)   # exchange + kernels of this rank, HIP events (hxv_time_apply_slab)
 
     ns = {"C2": 12, "C3": 16, "C4": 16, "C5": 18}[args.workload]
     out = {"metric": f"sector-HxV achieved HBM GB/s (algorithmic 32 B x Dim per product), Ns={ns} half-filled sector", "value": round(value, 1),
@@ -295,12 +326,17 @@ def main():
                                                                   "alltoall": " + 2 RCCL all-to-all transposes per product"}[args.exchange] if world > 1 else ""),
                       "matvecs_per_s": round((world if by_sector else 1) * 1e3 / ms_step, 2)},
            "roofline": roofline}
+    if multi and not by_sector:
+        out["checked"] = checked
+        out["check_rel_err"] = check_err
+        out["config"]["transport"] = "C-ABI (hxv_comm_init + hxv_apply_device_slab over RCCL)" if capi_exchange else f"torch.distributed ({args.backend}) twin, rehearsal only"
     if world > 1 and not by_sector:
         # what the exchange moves into every GPU per product: the xGMI links, not HBM, bound the N>1 product
-        slab = 16 * sh.slab
+        slab = 16 * (-(-sec.DimDw // world)) * sec.pitch
         out["config"]["exchange"] = args.exchange
+        halo_cols = int(sec.halo_lists(world)[0].sum()) if sec.exchange_mode == "halo" else 0   # (the engine's own receive lists)
         out["config"]["exchange_ingest_bytes_per_gpu"] = ((world - 1) * slab if args.exchange == "allgather" else
-                                                          16 * sec.pitch * hx.ingest_columns if halo else 2 * (world - 1) * slab // world)
+                                                          16 * sec.pitch * halo_cols if args.exchange == "halo" else 2 * (world - 1) * slab // world)
     if world == 1 and not args.rehearse_capi:
         # what each of the three exchanges would move into one GPU per product at 8 ranks
         rp, cols, _ = sec.csr("dw")
@@ -341,14 +377,14 @@ def main():
     if world == 1 and args.workload == "C3" and not args.no_other_workloads and not args.rehearse_capi:
         # the other full-size configs, driver-timed on the same GPU (parity-test sizes of BASELINE.json, not the headline)
         sec.close()
-        del vfull, v_local, hv_local, sh
+        del v_local, hv_local
         torch.cuda.empty_cache()
         hxv.pool_trim(local_rank)
         out["config"]["other_workloads"] = {w: time_other_workload(w, dev, 10 if w == "C4" else 3) for w in ("C4", "C5")}
-        vfull = v_local = hv_local = sh = None
+        v_local = hv_local = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.rehearse_capi:
         sec.close()
-        vfull = v_local = hv_local = sh = None
+        v_local = hv_local = None
         torch.cuda.empty_cache()
         try:
             out["cpu_baseline"] = cpu_baseline(model, nup, ndw)

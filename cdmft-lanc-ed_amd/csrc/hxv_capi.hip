@@ -250,6 +250,8 @@ int hxv_destroy(hxv_handle* h) {
   for (auto& p : h->d_lz) pool_free(h->device, p);
   if (h->d_lz_partial) (void)hipFree(h->d_lz_partial);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
+  for (auto e : h->kt_ev)
+    if (e) (void)hipEventDestroy(e);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;

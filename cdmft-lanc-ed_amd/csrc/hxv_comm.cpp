@@ -400,6 +400,11 @@ int comm_agree(hxv_handle* h, int rc_local) {
 // the assembled dw part on the slab.  Each transpose moves (P-1)/P of ONE slab per rank instead of (P-1) slabs: the lowest-traffic
 // exchange (C3 at 8 ranks: 0.58 GB into a GPU per product against 2.32 GB for the all-gather).  Rows are split like the columns
 // (mpiQup rule, :274-275).  Blocks are packed / unpacked with strided device copies; the block a rank keeps never leaves its GPU.
+// hxv_time_apply_slab: events around the kernels of a slab product
+static inline void kt_mark(hxv_handle* h, int i, hipStream_t st) {
+  if (h->kt_on && h->kt_ev[i]) (void)hipEventRecord(h->kt_ev[i], st);
+}
+
 struct A2A {
   hxv_handle* panel = nullptr;
   std::vector<int> rn, ru0, cq, cc0;         // per rank: its rows (count, first) and columns (count, first)
@@ -531,6 +536,7 @@ static int apply_slab_a2a(hxv_handle* h, const void* v_, void* hv_, bool real, h
     for (int p = 0; p < P; ++p)
       if (p != me) HIPCHK(copy_block(x + (size_t)a.cc0[p] * pp * esz, pp, recv + (size_t)a.rp1[p] * esz, nme, nme, a.cq[p], esz, st));
   // 2. dw hops on the row panel [my rows] x [all columns]
+  kt_mark(h, 0, st);
   if (real) {
     if (!a.panel->plan.usable) return fail(HXV_ERR_UNSUPPORTED, "all-to-all exchange: tiled kernels unavailable on the panel");
     DevSector d = a.panel->dev;
@@ -541,6 +547,7 @@ static int apply_slab_a2a(hxv_handle* h, const void* v_, void* hv_, bool real, h
     rc = hxv_apply_dw_panel(a.panel, a.d_x, a.d_y, st);
     if (rc) return rc;
   }
+  kt_mark(h, 1, st);
   // 3. back to the column owners
   for (int p = 0; p < P; ++p) {
     if (p == me)
@@ -555,6 +562,7 @@ static int apply_slab_a2a(hxv_handle* h, const void* v_, void* hv_, bool real, h
   // 4. diagonal + up hops + the assembled dw part on the slab (pass A alone, with the Lanczos epilogue when asked for)
   if (!h->plan.usable) return fail(HXV_ERR_UNSUPPORTED, "all-to-all exchange: tiled kernels unavailable (too many distinct amplitudes)");
   hipError_t e;
+  kt_mark(h, 2, st);
   if (real) {
     DevSector d = h->dev;
     d.pitch = (int)pit;
@@ -565,6 +573,7 @@ static int apply_slab_a2a(hxv_handle* h, const void* v_, void* hv_, bool real, h
     e = launch_hxv_tiled(h->dev, h->plan, vbase, a.d_w, static_cast<double2*>(hv_), st, ep, 1, true);
   }
   if (e != hipSuccess) return fail(HXV_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+  kt_mark(h, 3, st);
   h->n_apply++;
   h->n_exchange += 2;
   return HXV_OK;
@@ -580,11 +589,17 @@ int apply_slab(hxv_handle* h, const double2* d_v_local, double2* d_hv_local, hip
     if (rc) return rc;
     vfull = h->gather_cur;
   }
-  if (!ep) return hxv_apply_device(h, vfull, d_hv_local, st);
+  kt_mark(h, 0, st);
+  if (!ep) {
+    const int rcp = hxv_apply_device(h, vfull, d_hv_local, st);
+    kt_mark(h, 1, st);
+    return rcp;
+  }
   int rcw = ensure_wt(h);
   if (rcw) return rcw;
   hipError_t e = launch_hxv_tiled(h->dev, h->plan, vfull, h->d_wt, d_hv_local, st, ep);
   if (e != hipSuccess) return fail(HXV_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+  kt_mark(h, 1, st);
   h->n_apply++;
   return HXV_OK;
 }
@@ -750,6 +765,40 @@ int hxv_apply_device_slab(hxv_handle* h, const void* d_v_local, void* d_hv_local
   if (!h || !d_v_local || !d_hv_local) return fail(HXV_ERR_ARG, "hxv_apply_device_slab: NULL argument");
   if (h->host.panel_rows > 0) return fail(HXV_ERR_STATE, "hxv_apply_device_slab: panel handles only do hxv_apply_dw_panel");
   return apply_slab(h, (const double2*)d_v_local, (double2*)d_hv_local, (hipStream_t)stream);
+}
+
+// Measurement: nrep slab products (exchange + kernels, COLLECTIVE on a split sector: every rank calls it with the same nrep) timed with HIP
+// events on the handle's stream; *ms_step = mean time of a whole product on this rank, *ms_kernels = mean time of its product kernels alone
+// (the panel product and pass A in exchange mode 2) -- what bench.py's roofline leg quotes for N > 1.
+int hxv_time_apply_slab(hxv_handle* h, const void* d_v_local, void* d_hv_local, int32_t nrep, float* ms_step, float* ms_kernels) {
+  if (!h || !d_v_local || !d_hv_local || nrep < 1 || !ms_step || !ms_kernels) return fail(HXV_ERR_ARG, "hxv_time_apply_slab: bad argument");
+  if (h->host.panel_rows > 0) return fail(HXV_ERR_STATE, "hxv_time_apply_slab: not on a panel handle");
+  HIPCHK(hipSetDevice(h->device));
+  for (auto& e : h->kt_ev)
+    if (!e) HIPCHK(hipEventCreate(&e));
+  const bool two = h->host.exchange == 2 && h->host.nranks > 1;
+  double tot = 0.0, ker = 0.0;
+  int rc = HXV_OK;
+  h->kt_on = 1;
+  for (int i = 0; i < nrep && rc == HXV_OK; ++i) {
+    hipError_t e = hipEventRecord(h->ev0, h->stream);
+    rc = apply_slab(h, (const double2*)d_v_local, (double2*)d_hv_local, h->stream);
+    if (rc) break;
+    if (e == hipSuccess) e = hipEventRecord(h->ev1, h->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(h->ev1);
+    float a = 0, b = 0, c = 0;
+    if (e == hipSuccess) e = hipEventElapsedTime(&a, h->ev0, h->ev1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&b, h->kt_ev[0], h->kt_ev[1]);
+    if (e == hipSuccess && two) e = hipEventElapsedTime(&c, h->kt_ev[2], h->kt_ev[3]);
+    if (e != hipSuccess) rc = fail(HXV_ERR_HIP, std::string("hxv_time_apply_slab: ") + hipGetErrorString(e));
+    tot += a;
+    ker += b + c;
+  }
+  h->kt_on = 0;
+  if (rc) return rc;
+  *ms_step = (float)(tot / nrep);
+  *ms_kernels = (float)(ker / nrep);
+  return HXV_OK;
 }
 
 // Where the exchange wants this rank's slab: its slot of the gather buffer (all-gather) / the front of the halo layout.  A caller that

@@ -96,6 +96,8 @@ struct hxv_handle {
   int64_t n_apply = 0;
   int64_t device_bytes = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t kt_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // hxv_time_apply_slab: events around the kernels of a slab product (two regions in exchange mode 2)
+  int kt_on = 0;
 
   template <typename T>
   hipError_t alloc(T** p, size_t n) {

@@ -1,5 +1,11 @@
-"""DimDw-sharded HxV across the GPUs of one node: one process per GPU, torch.distributed
-(backend "nccl" = RCCL over xGMI) as the plumbing.
+"""torch.distributed TWIN of the engine's three slab exchanges -- REHEARSAL CODE, not the product's N>1 path.
+
+Since round 3 the exchanges live behind the C-ABI (csrc/hxv_comm.cpp: hxv_comm_init + hxv_apply_device_slab, RCCL or thread ranks), and
+since round 4 `bench.py --gpus N` uses nothing else on its default `--backend nccl` path.  This module stays for `bench.py --backend gloo`
+and tests/test_distributed_gloo.py: the partitioning, the equal-count all-gather layout, the halo plan and the two transposes exercised at
+world sizes 2-4 on the CPU, where no GPU (and no RCCL) is needed.  A change of the exchange logic is made in hxv_comm.cpp and mirrored here.
+
+DimDw-sharded HxV across the GPUs of one node: one process per GPU, torch.distributed as the plumbing.
 
 Partition = the reference's own (ED_HAMILTONIAN.f90:93-105): rank r owns mpiQdw consecutive dw
 columns.  The reference reassembles with two MPI_AllToAllV transposes per product

@@ -45,7 +45,7 @@ EXPORTS = [
     "hxv_nnz", "hxv_get_csr", "hxv_get_diag", "hxv_set_option", "hxv_get_option", "hxv_get_stats", "hxv_pool_trim", "hxv_pool_stats", "hxv_last_error",
     "hxv_version", "hxv_comm_unique_id", "hxv_comm_init", "hxv_comm_free", "hxv_apply_device_slab", "hxv_exchange_count",
     "hxv_set_exchange_default", "hxv_exchange_mode", "hxv_halo_counts", "hxv_halo_lists", "hxv_halo_plan_from_csr",
-    "hxv_comm_local_create", "hxv_comm_init_local", "hxv_comm_local_destroy", "hxv_comm_local_abort",
+    "hxv_comm_local_create", "hxv_comm_init_local", "hxv_comm_local_destroy", "hxv_comm_local_abort", "hxv_time_apply_slab",
 ]
 
 _lib = None
@@ -119,6 +119,7 @@ def load_library():
     L.hxv_comm_init.argtypes = [vp, vp]
     L.hxv_comm_free.argtypes = [vp]
     L.hxv_apply_device_slab.argtypes = [vp, vp, vp, vp]
+    L.hxv_time_apply_slab.argtypes = [vp, vp, vp, i32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.hxv_exchange_count.argtypes = [vp]
     L.hxv_exchange_count.restype = i64
     L.hxv_set_exchange_default.argtypes = [i32]
@@ -489,6 +490,15 @@ class HxvSector:
         st = torch.cuda.current_stream(v_local.device).cuda_stream if stream is None else stream
         _chk(load_library().hxv_apply_device_slab(self._h, v_local.data_ptr(), hv_local.data_ptr(), st), "hxv_apply_device_slab")
         return hv_local
+
+    def time_apply_slab(self, v_local, hv_local, nrep: int):
+        """-> (ms per slab product incl. the exchange, ms of its kernels alone), HIP events on the handle's stream; collective."""
+        import torch
+
+        torch.cuda.synchronize()
+        a, b = C.c_float(), C.c_float()
+        _chk(load_library().hxv_time_apply_slab(self._h, v_local.data_ptr(), hv_local.data_ptr(), nrep, C.byref(a), C.byref(b)), "hxv_time_apply_slab")
+        return a.value, b.value
 
     @property
     def exchange_count(self) -> int:

@@ -127,6 +127,10 @@ int hxv_comm_local_destroy(void *group);
 /* d_hv_local = (H v)|slab from this rank's slab d_v_local (hxv_localvec_elems() elements each, padded device layout):
  * exchange + product, asynchronous on `stream`.  nranks==1 without a communicator: the plain product.              */
 int hxv_apply_device_slab(hxv_handle *h, const void *d_v_local, void *d_hv_local, void *stream);
+/* Measurement: nrep such products on the handle's own stream, timed with HIP events (collective on a split sector: every rank calls
+ * it with the same nrep).  *ms_step = mean time of a whole product on this rank (exchange included), *ms_kernels = mean time of its
+ * product kernels alone (both kernel regions in exchange mode 2).                                                              */
+int hxv_time_apply_slab(hxv_handle *h, const void *d_v_local, void *d_hv_local, int32_t nrep, float *ms_step, float *ms_kernels);
 /* Where the exchange wants this rank's slab (its slot of the gather buffer): a caller that builds its vector there and hands
  * THAT pointer to hxv_apply_device_slab saves the slab copy of every product.  [qdw columns][pitch] complex elements; allocated on
  * first use; valid until hxv_comm_free / hxv_destroy; the device Lanczos drivers of a split sector keep their own vectors at the same

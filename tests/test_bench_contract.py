@@ -7,7 +7,7 @@ ROOT = Path(__file__).resolve().parent.parent
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    files = sorted((ROOT / "profiles").glob("r*_bench_n1_v*.json"), key=lambda p: int(re.search(r"_v(\d+)", p.name).group(1)))
+    files = sorted((ROOT / "profiles").glob("r*_bench_n1_v*.json"), key=lambda p: tuple(int(x) for x in re.search(r"r(\d+)_bench_n1_v(\d+)", p.name).groups()))
     line = json.loads(files[-1].read_text().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
               "config", "roofline", "cpu_baseline"):

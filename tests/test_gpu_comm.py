@@ -167,9 +167,11 @@ def test_halo_layout_rehearsal_one_gpu(built, world):
         hxv.set_exchange_default("allgather")
 
 
-def test_bench_rehearses_the_multi_gpu_calls_with_one_rank(built):
+@pytest.mark.parametrize("exchange", ["allgather", "halo", "alltoall"])
+def test_bench_rehearses_the_multi_gpu_calls_with_one_rank(built, exchange):
     """`bench.py --gpus N` (N > 1) cannot run on a one-GPU box; `--rehearse-capi` runs exactly its calls -- process group on RCCL,
-    hxv_comm_unique_id -> broadcast -> hxv_comm_init -> hxv_slab_home -> hxv_apply_device_slab, barrier, max over ranks -- with one rank."""
+    hxv_comm_unique_id -> broadcast -> hxv_comm_init -> hxv_slab_home -> hxv_apply_device_slab, the checked product before the warm-up,
+    barrier, max over ranks, the roofline leg through hxv_time_apply_slab -- with one rank, for every --exchange."""
     import json
     import os
     import subprocess
@@ -178,7 +180,9 @@ def test_bench_rehearses_the_multi_gpu_calls_with_one_rank(built):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--rehearse-capi", "--workload", "C2", "--steps", "3",
-                        "--warmup", "1"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+                        "--warmup", "1", "--exchange", exchange], capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["roofline"]["achieved"] > 0
+    assert line["checked"] is True and line["check_rel_err"] <= 1e-13 and "C-ABI" in line["config"]["transport"]
+    assert line["roofline"]["kernel_ms"] > 0 and line["roofline"]["slab_product_ms_on_stream"] >= line["roofline"]["kernel_ms"] * 0.99
