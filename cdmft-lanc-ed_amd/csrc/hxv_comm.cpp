@@ -27,6 +27,7 @@
 #include <mutex>
 
 #include "hxv_handle.hpp"
+#include "hxv_tile_dev.hpp"
 
 using namespace hxv;
 
@@ -410,7 +411,8 @@ struct A2A {
   std::vector<int> rn, ru0, cq, cc0;         // per rank: its rows (count, first) and columns (count, first)
   std::vector<int64_t> sp1, rp1, sp2, rp2;   // [P+1] element offsets of the per-peer blocks in the send / receive buffers, both transposes
   std::vector<int64_t> pan;                  // [P+1] element offsets of the ranks' column ranges in an UNPADDED panel (direct receive / send)
-  double2 *d_send = nullptr, *d_recv = nullptr, *d_x = nullptr, *d_y = nullptr, *d_w = nullptr;
+  double2 *d_send = nullptr, *d_recv = nullptr, *d_x = nullptr, *d_y = nullptr;
+  WtRange* d_wtr[2] = {nullptr, nullptr};    // [P] where pass A finds the dw part after the second transpose, per rank of origin (complex / real layout)
   int pp = 0;                                // panel pitch (complex layout)
   int mode = 0;                              // layout the panel / dw-part buffers were last used in (0 complex, 1 real): the pad rows differ
 };
@@ -418,8 +420,10 @@ struct A2A {
 static void a2a_release(hxv_handle* h) {
   A2A* a = static_cast<A2A*>(h->a2a);
   if (!a) return;
-  for (double2* p : {a->d_send, a->d_recv, a->d_x, a->d_y, a->d_w})
+  for (double2* p : {a->d_send, a->d_recv, a->d_x, a->d_y})
     if (p) pool_free(h->device, p);
+  for (WtRange* p : a->d_wtr)
+    if (p) (void)hipFree(p);
   if (a->panel) (void)hxv_destroy(a->panel);
   delete a;
   h->a2a = nullptr;
@@ -477,8 +481,8 @@ static int ensure_a2a(hxv_handle* h, hipStream_t st) {
   a->panel = out;
   a->pp = out->host.pitch;
   const size_t nsend = (size_t)std::max<int64_t>(std::max(a->sp1[P], a->sp2[P]), 1), nrecv = (size_t)std::max<int64_t>(std::max(a->rp1[P], a->rp2[P]), 1);
-  const size_t npanel = (size_t)s.dimdw * a->pp, nslab = (size_t)std::max(s.qdw, 1) * s.pitch;
-  struct { double2** p; size_t n; } bufs[5] = {{&a->d_send, nsend}, {&a->d_recv, nrecv}, {&a->d_x, npanel}, {&a->d_y, npanel}, {&a->d_w, nslab}};
+  const size_t npanel = (size_t)s.dimdw * a->pp;
+  struct { double2** p; size_t n; } bufs[4] = {{&a->d_send, nsend}, {&a->d_recv, nrecv}, {&a->d_x, npanel}, {&a->d_y, npanel}};
   for (auto& b : bufs) {
     hipError_t ea = pool_alloc(h->device, b.n * sizeof(double2), (void**)b.p);
     if (ea != hipSuccess) {
@@ -488,9 +492,34 @@ static int ensure_a2a(hxv_handle* h, hipStream_t st) {
     }
     h->device_bytes += (int64_t)(b.n * sizeof(double2));
   }
-  // pad rows of the panel and of the assembled dw part are never written by the unpack copies: zero them once
+  // pad rows of the panel are never written by the unpack copies: zero them once
   HIPCHK(hipMemsetAsync(a->d_x, 0, npanel * sizeof(double2), st));
-  HIPCHK(hipMemsetAsync(a->d_w, 0, nslab * sizeof(double2), st));
+  // Where the dw part of this rank's slab lies after the second transpose, per rank of origin: the blocks the peers sent stay in the
+  // receive buffer ([q columns][rn[p] rows] each), the block this rank kept stays in its panel output (column range cc0[me].., pitch =
+  // panel pitch).  Pass A reads them there (WtRange): no unpack copies, no assembled copy of the dw part.
+  for (int real = 0; real < 2; ++real) {
+    const size_t esz = real ? sizeof(double) : sizeof(double2);
+    const int64_t ppr = real ? (int64_t)pitch_real_of(out) : (int64_t)a->pp;
+    std::vector<WtRange> tab(P);
+    for (int p = 0; p < P; ++p) {
+      tab[p].row0 = a->ru0[p];
+      tab[p].row1 = a->ru0[p] + a->rn[p];
+      if (p == s.rank) {
+        tab[p].stride = ppr;
+        tab[p].base = reinterpret_cast<const char*>(a->d_y) + (size_t)a->cc0[p] * ppr * esz;
+      } else {
+        tab[p].stride = a->rn[p];
+        tab[p].base = reinterpret_cast<const char*>(a->d_recv) + (size_t)a->rp2[p] * esz;
+      }
+    }
+    hipError_t ea = hipMalloc((void**)&a->d_wtr[real], P * sizeof(WtRange));
+    if (ea == hipSuccess) ea = hipMemcpy(a->d_wtr[real], tab.data(), P * sizeof(WtRange), hipMemcpyHostToDevice);
+    if (ea != hipSuccess) {
+      h->a2a = a.release();
+      a2a_release(h);
+      return fail(HXV_ERR_HIP, std::string("all-to-all exchange tables: ") + hipGetErrorString(ea));
+    }
+  }
   h->a2a = a.release();
   return HXV_OK;
 }
@@ -516,12 +545,11 @@ static int apply_slab_a2a(hxv_handle* h, const void* v_, void* hv_, bool real, h
   if (a.mode != (real ? 1 : 0)) {
     // the pad rows of the two layouts sit at different places and the unpack copies never write pads
     HIPCHK(hipMemsetAsync(a.d_x, 0, (size_t)s.dimdw * a.pp * sizeof(double2), st));
-    HIPCHK(hipMemsetAsync(a.d_w, 0, (size_t)std::max(s.qdw, 1) * s.pitch * sizeof(double2), st));
     a.mode = real ? 1 : 0;
   }
   const char* v = static_cast<const char*>(v_);
   char *send = reinterpret_cast<char*>(a.d_send), *recv = reinterpret_cast<char*>(a.d_recv), *x = reinterpret_cast<char*>(a.d_x),
-       *y = reinterpret_cast<char*>(a.d_y), *w = reinterpret_cast<char*>(a.d_w);
+       *y = reinterpret_cast<char*>(a.d_y);
   // 1. my slab cut by the receivers' row ranges; my own block goes straight into the panel
   for (int p = 0; p < P; ++p) {
     if (p == me)
@@ -548,17 +576,13 @@ static int apply_slab_a2a(hxv_handle* h, const void* v_, void* hv_, bool real, h
     if (rc) return rc;
   }
   kt_mark(h, 1, st);
-  // 3. back to the column owners
-  for (int p = 0; p < P; ++p) {
-    if (p == me)
-      HIPCHK(copy_block(w + (size_t)a.ru0[me] * esz, pit, y + (size_t)a.cc0[me] * pp * esz, pp, nme, q, esz, st));
-    else if (!direct)
-      HIPCHK(copy_block(send + (size_t)a.sp2[p] * esz, nme, y + (size_t)a.cc0[p] * pp * esz, pp, nme, a.cq[p], esz, st));
-  }
+  // 3. back to the column owners: peers' blocks go out of the panel output (direct) or through the send buffer; what arrives STAYS in the
+  //    receive buffer and the block this rank keeps stays in the panel output -- pass A reads the pieces where they are (a.d_wtr)
+  if (!direct)
+    for (int p = 0; p < P; ++p)
+      if (p != me) HIPCHK(copy_block(send + (size_t)a.sp2[p] * esz, nme, y + (size_t)a.cc0[p] * pp * esz, pp, nme, a.cq[p], esz, st));
   rc = direct ? comm_sendrecv_cols(h, y, a.pan.data(), recv, a.rp2.data(), esz, st) : comm_sendrecv_cols(h, send, a.sp2.data(), recv, a.rp2.data(), esz, st);
   if (rc) return rc;
-  for (int p = 0; p < P; ++p)
-    if (p != me) HIPCHK(copy_block(w + (size_t)a.ru0[p] * esz, pit, recv + (size_t)a.rp2[p] * esz, a.rn[p], a.rn[p], q, esz, st));
   // 4. diagonal + up hops + the assembled dw part on the slab (pass A alone, with the Lanczos epilogue when asked for)
   if (!h->plan.usable) return fail(HXV_ERR_UNSUPPORTED, "all-to-all exchange: tiled kernels unavailable (too many distinct amplitudes)");
   hipError_t e;
@@ -567,10 +591,10 @@ static int apply_slab_a2a(hxv_handle* h, const void* v_, void* hv_, bool real, h
     DevSector d = h->dev;
     d.pitch = (int)pit;
     const double* vbase = reinterpret_cast<const double*>(v) - (int64_t)d.slab0 * d.pitch;  // (pass A addresses its slab as column slots slab0..)
-    e = launch_hxv_tiled_real(d, h->plan, vbase, reinterpret_cast<double*>(w), static_cast<double*>(hv_), st, ep, 1, true);
+    e = launch_hxv_tiled_real(d, h->plan, vbase, reinterpret_cast<double*>(recv), static_cast<double*>(hv_), st, ep, 1, true, a.d_wtr[1], P);
   } else {
     const double2* vbase = reinterpret_cast<const double2*>(v) - (int64_t)h->dev.slab0 * h->dev.pitch;
-    e = launch_hxv_tiled(h->dev, h->plan, vbase, a.d_w, static_cast<double2*>(hv_), st, ep, 1, true);
+    e = launch_hxv_tiled(h->dev, h->plan, vbase, a.d_recv, static_cast<double2*>(hv_), st, ep, 1, true, a.d_wtr[0], P);
   }
   if (e != hipSuccess) return fail(HXV_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
   kt_mark(h, 3, st);

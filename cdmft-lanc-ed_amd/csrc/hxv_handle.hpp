@@ -41,6 +41,8 @@ int finish_create(hxv_handle* h, int device, hxv_handle** out);  // uploads h->h
 bool lanczos_local_step_available(const hxv_handle* h);
 int lanczos_local_step(hxv_handle* h, bool real, const double2* q, double sq, const double2* qm, double sqm, double beta, double2* w,
                        bool sub_alpha, double* alpha, double* nrm_w);
+// exchange mode 2 on a split sector: pass A reads the dw part in pieces (one block per rank of origin) and runs on the tile kernel
+inline bool dw_part_in_pieces(const hxv_handle* h);
 }  // namespace hxv
 
 #define HIPCHK(expr)                                                                                   \
@@ -117,3 +119,5 @@ struct hxv_handle {
     return e;
   }
 };
+
+inline bool hxv::dw_part_in_pieces(const hxv_handle* h) { return h->host.exchange == 2 && h->host.nranks > 1; }

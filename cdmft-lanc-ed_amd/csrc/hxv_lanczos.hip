@@ -410,7 +410,7 @@ struct LzRunner {
       rc = reduce_scalar(h, h->d_partials + RED_BLOCKS, g, 1, 1);
       if (rc) return rc;
     } else {
-      const int64_t nwg = std::max<int64_t>(1, tiled_pass_up_workgroups(h->dev, h->plan, real));
+      const int64_t nwg = std::max<int64_t>(1, tiled_pass_up_workgroups(h->dev, h->plan, real, dw_part_in_pieces(h)));
       if (nwg > h->lz_partial_n) {
         if (h->d_lz_partial) (void)hipFree(h->d_lz_partial);
         h->d_lz_partial = nullptr;
@@ -450,7 +450,7 @@ struct LzRunner {
   // previous lz_next), alpha/beta go to device arrays.  q, qm, w are explicit so that a rotation cycle can be captured.
   int enqueue_device_iteration(double2* q, double2* qm, double2* w, double* d_alpha, double* d_beta, int nmax) {
     const int g = grid_for(n2);
-    const int64_t nwg = tiled_pass_up_workgroups(h->dev, h->plan, real);
+    const int64_t nwg = tiled_pass_up_workgroups(h->dev, h->plan, real, dw_part_in_pieces(h));
     LzEpilogue ep;
     ep.xm = qm;
     ep.scal = h->d_scalars;
@@ -640,7 +640,7 @@ int lanczos_local_step(hxv_handle* h, bool real, const double2* q, double sq, co
                        bool sub_alpha, double* alpha, double* nrm_w) {
   const int64_t n2 = real ? (int64_t)pitch_real_of(h) * h->host.qdw / 2 : (int64_t)h->host.pitch * h->host.qdw;
   const int g = grid_for(n2);
-  const int64_t nwg = std::max<int64_t>(1, tiled_pass_up_workgroups(h->dev, h->plan, real));
+  const int64_t nwg = std::max<int64_t>(1, tiled_pass_up_workgroups(h->dev, h->plan, real, dw_part_in_pieces(h)));
   if (nwg > h->lz_partial_n) {
     if (h->d_lz_partial) (void)hipFree(h->d_lz_partial);
     h->d_lz_partial = nullptr;
@@ -930,7 +930,7 @@ int hxv_lanczos_tridiag_pair(hxv_handle* h, const void* d_vin_a, const void* d_v
   const bool dist = comm_ready(h);
   const int64_t n = (int64_t)h->host.pitch * h->host.qdw;
   const int g = grid_for(n);
-  const int64_t nwg = std::max<int64_t>(1, tiled_pass_up_workgroups(h->dev, h->plan, false, true));
+  const int64_t nwg = std::max<int64_t>(1, tiled_pass_up_workgroups(h->dev, h->plan, false, dw_part_in_pieces(h)));
   // scalars: [0] alpha_a [1] beta_a [2] s_a [3] c_a [4] alpha_a*s_a ; [8..12] the same for b ; block partials behind them
   double* d_sc = nullptr;
   // every rank-local preparation that can fail comes BEFORE the agreement: a rank that cannot go on makes all ranks return

@@ -5,6 +5,15 @@
 
 namespace hxv {
 
+// Pass A's dw part in PIECES (exchange mode 2): after the second transpose the assembled dw part of a slab lies in one block per rank of
+// origin -- rows [row0,row1) of all local columns, column stride `stride` elements -- in the receive buffer (the block this rank kept: in
+// its panel output).  Pass A reads its accumulator init straight from there: element (row, local column c) = base[c*stride + row - row0].
+struct WtRange {
+  int32_t row0, row1;
+  int64_t stride;
+  const void* base;
+};
+
 struct DevTiles {
   const uint32_t* start;   // [nblocks+1]
   const uint32_t* tstart;  // [nblocks] start of the block whose in-block tables (perm, ell_in; gstart is aliased likewise) this block shares
@@ -28,6 +37,8 @@ struct DevTiles {
   int p16_bits;           // ell16 words: (coefficient index << p16_bits) | offset, two per 32-bit word
   const uint32_t* rs16;     // half-size row-slot tables: slots sl, sl+1 of a block in one word (same split), or null
   const uint32_t* rs16_off; // [nslots] offset of the packed table of the pair that STARTS at this slot
+  const WtRange* wtr;       // pass A, natural-layout dw part (wc == 0) given in row ranges instead of one array, or null
+  int nwtr;
 };
 
 constexpr int HOP_CHUNK = 8;

@@ -99,10 +99,21 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
   auto row_inputs = [&]() {
     if (p < n) {
       if (wt && wc == 0) {
-        // natural layout [local column][pitch] (all-to-all exchange: the dw part arrives assembled like hv)
-        const VT* __restrict__ wcol = wt + (int64_t)c0 * s.pitch + r0 + p;
+        // natural layout [local column][pitch] (the dw part assembled like hv) -- or, with t.wtr, the same in PIECES (all-to-all
+        // exchange): one block per rank of origin, read where the second transpose left it (WtRange)
+        const VT* wb = wt;
+        int64_t wstr = s.pitch;
+        int wrow = r0 + p;
+        if (t.wtr) {
+          int k = 0;
+          while (k + 1 < t.nwtr && wrow >= t.wtr[k].row1) ++k;
+          wb = reinterpret_cast<const VT*>(t.wtr[k].base);
+          wstr = t.wtr[k].stride;
+          wrow -= t.wtr[k].row0;
+        }
+        const VT* __restrict__ wcol = wb + (int64_t)c0 * wstr + wrow;
 #pragma unroll
-        for (int cc = 0; cc < C; ++cc) acc[cc] = wcol[(int64_t)min(cc, nc - 1) * s.pitch];
+        for (int cc = 0; cc < C; ++cc) acc[cc] = wcol[(int64_t)min(cc, nc - 1) * wstr];
       } else if (wt) {
         const VT* __restrict__ wrow = wt + ((int64_t)(c0 / wc) * s.dimup + r0 + p) * wc + (c0 % wc);
 #pragma unroll
@@ -1197,9 +1208,10 @@ static bool use_job_up(const DevSector& s, const TilePlan& plan, bool real_vec, 
   return true;
 }
 
-int64_t tiled_pass_up_workgroups(const DevSector& s, const TilePlan& plan, bool real_vec, bool pair) {
-  (void)pair;  // (both epilogues run on the same kernel: jobs where they apply, else one tile per workgroup)
-  if (use_job_up(s, plan, real_vec, true, false)) return job_up_workgroups(s, plan);
+int64_t tiled_pass_up_workgroups(const DevSector& s, const TilePlan& plan, bool real_vec, bool pieces) {
+  // (both epilogues run on the same kernel: jobs where they apply, else one tile per workgroup; a dw part handed over in pieces --
+  //  exchange mode 2 -- always goes through the tile kernel)
+  if (!pieces && use_job_up(s, plan, real_vec, true, false)) return job_up_workgroups(s, plan);
   const int C = real_vec ? real_cols(plan) : cplx_cols(plan);
   const int ngroups = (s.qdw + C - 1) / C;
   return (int64_t)((ngroups + 7) / 8) * 8 * plan.up.nblocks;
@@ -1207,7 +1219,7 @@ int64_t tiled_pass_up_workgroups(const DevSector& s, const TilePlan& plan, bool 
 
 template <typename VT>
 static hipError_t launch_tiled_vt(const DevSector& s, const TilePlan& plan, const VT* v, VT* wt, VT* hv, hipStream_t st, const LzEpilogue* lz,
-                                  int only_pass, bool wt_natural) {
+                                  int only_pass, bool wt_natural, const WtRange* wtr = nullptr, int nwtr = 0) {
   constexpr bool RV = std::is_same<VT, double>::value;
   // dispatch order of a group's blocks (TileOptions::block_order).  Automatic: by the particle number of the high orbitals where table
   // classes are few (it IS a class order there, and it keeps coupled blocks close: Ns=18 fabric traffic 330 -> 261 GB per product,
@@ -1220,10 +1232,10 @@ static hipError_t launch_tiled_vt(const DevSector& s, const TilePlan& plan, cons
   };
   DevTiles tu{plan.up.d_start, plan.up.d_tstart, plan.up.d_perm, plan.up.d_gstart, plan.up.d_gmax, plan.up.d_ell_in, plan.up.d_ell16,
               plan.d_scoef_up, plan.up.d_bh_ptr, plan.up.d_bh, plan.up.d_rs_ptr, plan.up.d_rs_off, plan.up.d_rs_tab, plan.up.d_rs_base, plan.up.d_rs_neg,
-              plan.up.nblocks, 2 * plan.ncoef_up + 1, plan.opt.debug, 0, pick_order(plan.up), plan.up.p16_bits, (plan.up.rs16_on && !(plan.opt.debug & 64)) ? plan.up.d_rs16 : nullptr, plan.up.d_rs16_off};
+              plan.up.nblocks, 2 * plan.ncoef_up + 1, plan.opt.debug, 0, pick_order(plan.up), plan.up.p16_bits, (plan.up.rs16_on && !(plan.opt.debug & 64)) ? plan.up.d_rs16 : nullptr, plan.up.d_rs16_off, wtr, nwtr};
   DevTiles td{plan.dw.d_start, plan.dw.d_tstart, plan.dw.d_perm, plan.dw.d_gstart, plan.dw.d_gmax, plan.dw.d_ell_in, plan.dw.d_ell16,
               plan.d_scoef_dw, plan.dw.d_bh_ptr, plan.dw.d_bh, plan.dw.d_rs_ptr, plan.dw.d_rs_off, plan.dw.d_rs_tab, plan.dw.d_rs_base, plan.dw.d_rs_neg,
-              plan.dw.nblocks, 2 * plan.ncoef_dw + 1, plan.opt.debug, 0, pick_order(plan.dw), plan.dw.p16_bits, (plan.dw.rs16_on && !(plan.opt.debug & 64)) ? plan.dw.d_rs16 : nullptr, plan.dw.d_rs16_off};
+              plan.dw.nblocks, 2 * plan.ncoef_dw + 1, plan.opt.debug, 0, pick_order(plan.dw), plan.dw.p16_bits, (plan.dw.rs16_on && !(plan.opt.debug & 64)) ? plan.dw.d_rs16 : nullptr, plan.dw.d_rs16_off, nullptr, 0};
   // (class order only where classes are few: with 11 table sets for 16 blocks (C4) the natural order measured 2.6 % faster)
   // (decided below, once the tile's row count R is known)
   const int C = RV ? real_cols(plan) : cplx_cols(plan), R = RV ? real_rows(plan) : plan.opt.rows_per_tile;
@@ -1237,7 +1249,7 @@ static hipError_t launch_tiled_vt(const DevSector& s, const TilePlan& plan, cons
   // (with the job kernels pass A's tile width no longer constrains the scratch layout)
   int wc = wt_natural ? 0 : (RV ? real_wc(plan) : std::max(C, plan.opt.wt_cols));
   bool job_a = false;
-  if constexpr (!RV) job_a = (passes & 1) && use_job_up(s, plan, false, lz != nullptr, wt_natural, &wc);
+  if constexpr (!RV) job_a = (passes & 1) && !wtr && use_job_up(s, plan, false, lz != nullptr, wt_natural, &wc);  // (a dw part in pieces: tile kernel)
   // (folded spH0nd block: one table row index and 2*C partner-column words per ordered orbital pair of a site, behind the coefficients)
   const int lds_nd = nd_folds(s) ? s.nd.nlat * s.nd.norb * (s.nd.norb - 1) * (2 * C + 1) * 4 : 0;
   const int lds_a = std::max(plan.up.max_block * C * (int)sizeof(VT) + tu.nscoef * 16 + lds_nd, plan.opt.lds_min_kb_up * 1024);
@@ -1269,18 +1281,18 @@ static hipError_t launch_tiled_vt(const DevSector& s, const TilePlan& plan, cons
 }
 
 hipError_t launch_hxv_tiled(const DevSector& s, const TilePlan& plan, const double2* v, double2* wt, double2* hv, hipStream_t st,
-                            const LzEpilogue* lz, int only_pass, bool wt_natural) {
+                            const LzEpilogue* lz, int only_pass, bool wt_natural, const WtRange* wtr, int nwtr) {
   // wt: scratch of tiled_wt_elems() elements (dw-hop part, column-group-blocked), owned by the handle
   if (s.qdw == 0) return hipSuccess;
-  return launch_tiled_vt<double2>(s, plan, v, wt, hv, st, lz, only_pass, wt_natural);
+  return launch_tiled_vt<double2>(s, plan, v, wt, hv, st, lz, only_pass, wt_natural, wtr, nwtr);
 }
 
 hipError_t launch_hxv_tiled_real(const DevSector& s, const TilePlan& plan, const double* v, double* wt, double* hv, hipStream_t st,
-                                 const LzEpilogue* lz, int only_pass, bool wt_natural) {
+                                 const LzEpilogue* lz, int only_pass, bool wt_natural, const WtRange* wtr, int nwtr) {
   // REAL vectors (H real; s.pitch must be the real pitch, a multiple of 16): wt needs no more bytes than in complex mode
   if (s.qdw == 0) return hipSuccess;
   if (!s.real_h) return hipErrorInvalidValue;
-  return launch_tiled_vt<double>(s, plan, v, wt, hv, st, lz, only_pass, wt_natural);
+  return launch_tiled_vt<double>(s, plan, v, wt, hv, st, lz, only_pass, wt_natural, wtr, nwtr);
 }
 
 }  // namespace hxv

@@ -111,7 +111,8 @@ struct LzEpilogue {
   double* partial2 = nullptr;
 };
 // workgroups of pass A (= partial sums of the Lanczos epilogue) for the product launch_hxv_tiled would run with an epilogue
-int64_t tiled_pass_up_workgroups(const DevSector& s, const TilePlan& plan, bool real_vec = false, bool pair = false);
+// pieces: the dw part arrives in row ranges (exchange mode 2: always the tile kernel)
+int64_t tiled_pass_up_workgroups(const DevSector& s, const TilePlan& plan, bool real_vec = false, bool pieces = false);
 int64_t tiled_wt_elems(const DevSector& s, const TilePlan& plan);
 
 struct PlanUploader {
@@ -121,15 +122,20 @@ struct PlanUploader {
 std::string make_tile_plan(const SectorHost& s, TilePlan& plan, const PlanUploader& up);
 // job kernels (hxv_jobs.hip)
 struct DevTiles;
+struct WtRange;
 bool job_up_usable(const DevSector& s, const TilePlan& plan);
 int64_t job_up_workgroups(const DevSector& s, const TilePlan& plan);
 bool job_up_fits(const DevSector& s, const TilePlan& plan, bool lz, int wc);
 hipError_t launch_up_job(const DevSector& s, const TilePlan& plan, const DevTiles& tu, int wc, const double2* v, const double2* wt, double2* hv,
                          const LzEpilogue* lz, hipStream_t st);
+// wtr / nwtr (with only_pass = 1, wt_natural): the dw part handed over in row ranges (WtRange, hxv_tile_dev.hpp) instead of one array;
+// wt_scratch must still be non-null (it marks "there is a dw part")
 hipError_t launch_hxv_tiled(const DevSector& s, const TilePlan& plan, const double2* v_full, double2* wt_scratch, double2* hv_local,
-                            hipStream_t st, const LzEpilogue* lz = nullptr, int only_pass = 0, bool wt_natural = false);
+                            hipStream_t st, const LzEpilogue* lz = nullptr, int only_pass = 0, bool wt_natural = false,
+                            const WtRange* wtr = nullptr, int nwtr = 0);
 // Same product on REAL vectors (double elements; H must be real, nranks == 1): s.pitch = real pitch (multiple of 16).
 hipError_t launch_hxv_tiled_real(const DevSector& s, const TilePlan& plan, const double* v, double* wt_scratch, double* hv, hipStream_t st,
-                                 const LzEpilogue* lz = nullptr, int only_pass = 0, bool wt_natural = false);
+                                 const LzEpilogue* lz = nullptr, int only_pass = 0, bool wt_natural = false, const WtRange* wtr = nullptr,
+                                 int nwtr = 0);
 
 }  // namespace hxv
