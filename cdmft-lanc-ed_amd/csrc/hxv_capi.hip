@@ -383,6 +383,8 @@ int hxv_apply_host(hxv_handle* h, int64_t nloc, const void* v, void* hv) {
   if (rc) return rc;
   if (h->host.qdw > 0) HIPCHK(hipMemcpy2DAsync(hv, col, h->d_stage_hv, pit, col, (size_t)h->host.qdw, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  h->h2d_bytes += (int64_t)(col * h->host.qdw);
+  h->d2h_bytes += (int64_t)(col * h->host.qdw);
   return HXV_OK;
 }
 
@@ -399,6 +401,48 @@ int hxv_time_apply(hxv_handle* h, const void* d_v_full, void* d_hv_local, int32_
   float ms = 0;
   HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
   *ms_per_apply = ms / (float)nrep;
+  return HXV_OK;
+}
+
+// ---- device vectors owned by the library: what a host program without a HIP binding of its own (the Fortran glue) keeps between calls ----
+int hxv_vector_alloc(hxv_handle* h, void** d_vec) {
+  if (!h || !d_vec) return fail(HXV_ERR_ARG, "hxv_vector_alloc: NULL argument");
+  HIPCHK(hipSetDevice(h->device));
+  const size_t bytes = (size_t)h->host.pitch * std::max(h->host.qdw, 1) * sizeof(double2);
+  void* p = nullptr;
+  HIPCHK(pool_alloc(h->device, bytes, &p));
+  HIPCHK(hipMemsetAsync(p, 0, bytes, h->stream));   // (pad rows must be zero; on the handle's stream, like every other fill)
+  HIPCHK(hipStreamSynchronize(h->stream));
+  *d_vec = p;
+  return HXV_OK;
+}
+
+int hxv_vector_free(hxv_handle* h, void* d_vec) {
+  if (!h) return fail(HXV_ERR_ARG, "hxv_vector_free: NULL handle");
+  if (!d_vec) return HXV_OK;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  pool_free(h->device, d_vec);
+  return HXV_OK;
+}
+
+int hxv_vector_from_host(hxv_handle* h, const void* v_host, void* d_vec) {
+  if (!h || !v_host || !d_vec) return fail(HXV_ERR_ARG, "hxv_vector_from_host: NULL argument");
+  HIPCHK(hipSetDevice(h->device));
+  const size_t col = (size_t)h->host.dimup * sizeof(double2), pit = (size_t)h->host.pitch * sizeof(double2);
+  if (h->host.qdw > 0) HIPCHK(hipMemcpy2DAsync(d_vec, pit, v_host, col, col, (size_t)h->host.qdw, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->h2d_bytes += (int64_t)(col * h->host.qdw);
+  return HXV_OK;
+}
+
+int hxv_vector_to_host(hxv_handle* h, const void* d_vec, void* v_host) {
+  if (!h || !v_host || !d_vec) return fail(HXV_ERR_ARG, "hxv_vector_to_host: NULL argument");
+  HIPCHK(hipSetDevice(h->device));
+  const size_t col = (size_t)h->host.dimup * sizeof(double2), pit = (size_t)h->host.pitch * sizeof(double2);
+  if (h->host.qdw > 0) HIPCHK(hipMemcpy2DAsync(v_host, col, d_vec, pit, col, (size_t)h->host.qdw, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->d2h_bytes += (int64_t)(col * h->host.qdw);
   return HXV_OK;
 }
 
@@ -607,6 +651,8 @@ int hxv_get_stats(const hxv_handle* h, hxv_stats* out) {
   out->k_dw = h->host.dw.K;
   out->n_hops_up = (int)h->host.up.coef.size();
   out->n_hops_dw = (int)h->host.dw.coef.size();
+  out->h2d_bytes = h->h2d_bytes;
+  out->d2h_bytes = h->d2h_bytes;
   return HXV_OK;
 }
 

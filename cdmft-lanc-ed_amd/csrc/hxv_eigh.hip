@@ -807,6 +807,7 @@ int hxv_eigh_lowest_host(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t max
       HIPCHK(hipMemcpy2DAsync((char*)evecs_host + (size_t)i * vecdim * sizeof(double2), col, d + (int64_t)i * n, pit, col,
                               (size_t)h->host.qdw, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  h->d2h_bytes += (int64_t)neigen * (int64_t)(col * h->host.qdw);
   return HXV_OK;
 }
 

@@ -96,6 +96,7 @@ struct hxv_handle {
   int32_t* d_send_cols = nullptr;
   int64_t n_exchange = 0;
   int64_t n_apply = 0;
+  int64_t h2d_bytes = 0, d2h_bytes = 0;  // vector-sized PCIe traffic of the host-array entry points and hxv_vector_from/to_host (hxv_get_stats)
   int64_t device_bytes = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t kt_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // hxv_time_apply_slab: events around the kernels of a slab product (two regions in exchange mode 2)

@@ -1078,6 +1078,7 @@ int hxv_lanczos_tridiag_host(hxv_handle* h, const void* vin_host, int32_t nlanc,
   if (h->host.qdw > 0)
     HIPCHK(hipMemcpy2DAsync(h->d_stage_v, pit, vin_host, col, col, (size_t)h->host.qdw, hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  h->h2d_bytes += (int64_t)(col * h->host.qdw);
   return hxv_lanczos_tridiag(h, h->d_stage_v, nlanc, alanc, blanc, threshold, nsteps);
 }
 
@@ -1093,6 +1094,7 @@ int hxv_lanczos_tridiag_pair_host(hxv_handle* h, const void* vin_a_host, const v
     HIPCHK(hipMemcpy2DAsync(h->d_stage_hv, pit, vin_b_host, col, col, (size_t)h->host.qdw, hipMemcpyHostToDevice, h->stream));
   }
   HIPCHK(hipStreamSynchronize(h->stream));
+  h->h2d_bytes += 2 * (int64_t)(col * h->host.qdw);
   return hxv_lanczos_tridiag_pair(h, h->d_stage_v, h->d_stage_hv, nlanc, alanc_a, blanc_a, alanc_b, blanc_b, threshold, nsteps_a, nsteps_b);
 }
 
@@ -1108,6 +1110,7 @@ int hxv_lanczos_eigh_host(hxv_handle* h, int32_t nitermax, double threshold, dou
     if (h->host.qdw > 0)
       HIPCHK(hipMemcpy2DAsync(vect_host, col, h->d_stage_hv, pit, col, (size_t)h->host.qdw, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    h->d2h_bytes += (int64_t)(col * h->host.qdw);
   }
   return HXV_OK;
 }

@@ -24,6 +24,26 @@ module ED_HAMILTONIAN_GPU_HXV
   public :: gpu_sp_lanc_tridiag_pair
   public :: gpu_sp_lanc_eigh
   public :: gpu_sp_eigh
+  !device-resident Green's-function pipeline (nothing Dim-sized crosses PCIe): see the block comment above gpu_sp_lanc_eigh_dev
+  public :: gpu_vector
+  public :: gpu_sp_lanc_eigh_dev
+  public :: gpu_keep_sector
+  public :: gpu_apply_ladder
+  public :: gpu_sp_lanc_tridiag_dev
+  public :: gpu_vector_to_host
+  public :: gpu_vector_from_host
+  public :: gpu_free_vector
+  public :: gpu_pcie_bytes
+  !the reference's own stored matrices handed over (spH0ups(1), spH0dws(1), spH0d, spH0nd flattened to CSR)
+  public :: gpu_build_Hv_sector_from_csr
+  public :: gpu_set_nonlocal_csr
+
+  !> A vector that lives on the device, in the layout of the sector it was made for.  Opaque: pass it back to the gpu_* routines.
+  type :: gpu_vector
+     type(c_ptr) :: d      = c_null_ptr    !device buffer (include/hxv.h: hxv_vector_alloc)
+     type(c_ptr) :: sector = c_null_ptr    !the sector (engine handle) it belongs to
+     logical     :: owns_sector = .false.  !gpu_keep_sector: that sector stays open for this vector until gpu_free_vector
+  end type gpu_vector
 
   !> SciFortran's drivers are generic in exactly this way: the serial form takes the product first, the MPI form the
   !! communicator first (call sites ED_DIAG.f90:152-156,161-165,176-184; ED_GF_NORMAL.f90:215,217).  Both forms end in
@@ -38,6 +58,13 @@ module ED_HAMILTONIAN_GPU_HXV
   interface gpu_sp_lanc_tridiag
      module procedure gpu_sp_lanc_tridiag_serial, gpu_sp_lanc_tridiag_mpi
   end interface gpu_sp_lanc_tridiag
+
+  !> mirrors struct hxv_stats of include/hxv.h
+  type, bind(C) :: hxv_stats
+     integer(c_int64_t) :: n_apply, algorithmic_bytes, device_bytes
+     integer(c_int32_t) :: kernel, real_h, k_up, k_dw, n_hops_up, n_hops_dw
+     integer(c_int64_t) :: h2d_bytes, d2h_bytes
+  end type hxv_stats
 
   !> mirrors struct hxv_model of include/hxv.h
   type, bind(C) :: hxv_model
@@ -116,6 +143,70 @@ module ED_HAMILTONIAN_GPU_HXV
        type(c_ptr),value            :: h
        integer(c_int8_t),intent(in) :: id(128)
      end function hxv_comm_init
+     integer(c_int) function hxv_create_from_csr(dimup,dimdw,up_rowptr,up_cols,up_vals,dw_rowptr,dw_cols,dw_vals,diag,rank,nranks,device,out) &
+          bind(C,name="hxv_create_from_csr")
+       import :: c_int, c_int32_t, c_int64_t, c_ptr, c_double_complex
+       integer(c_int32_t),value             :: dimup,dimdw,rank,nranks,device
+       integer(c_int64_t),intent(in)        :: up_rowptr(*),dw_rowptr(*)
+       integer(c_int32_t),intent(in)        :: up_cols(*),dw_cols(*)
+       complex(c_double_complex),intent(in) :: up_vals(*),dw_vals(*),diag(*)
+       type(c_ptr),intent(out)              :: out
+     end function hxv_create_from_csr
+     integer(c_int) function hxv_set_nonlocal_csr(h,rowptr,cols,vals) bind(C,name="hxv_set_nonlocal_csr")
+       import :: c_int, c_int32_t, c_int64_t, c_ptr, c_double_complex
+       type(c_ptr),value                    :: h
+       integer(c_int64_t),intent(in)        :: rowptr(*)
+       integer(c_int32_t),intent(in)        :: cols(*)
+       complex(c_double_complex),intent(in) :: vals(*)
+     end function hxv_set_nonlocal_csr
+     integer(c_int) function hxv_vector_alloc(h,d_vec) bind(C,name="hxv_vector_alloc")
+       import :: c_int, c_ptr
+       type(c_ptr),value       :: h
+       type(c_ptr),intent(out) :: d_vec
+     end function hxv_vector_alloc
+     integer(c_int) function hxv_vector_free(h,d_vec) bind(C,name="hxv_vector_free")
+       import :: c_int, c_ptr
+       type(c_ptr),value :: h,d_vec
+     end function hxv_vector_free
+     integer(c_int) function hxv_vector_from_host(h,v_host,d_vec) bind(C,name="hxv_vector_from_host")
+       import :: c_int, c_ptr, c_double_complex
+       type(c_ptr),value                    :: h,d_vec
+       complex(c_double_complex),intent(in) :: v_host(*)
+     end function hxv_vector_from_host
+     integer(c_int) function hxv_vector_to_host(h,d_vec,v_host) bind(C,name="hxv_vector_to_host")
+       import :: c_int, c_ptr, c_double_complex
+       type(c_ptr),value         :: h,d_vec
+       complex(c_double_complex) :: v_host(*)
+     end function hxv_vector_to_host
+     integer(c_int) function hxv_lanczos_eigh(h,nitermax,threshold,egs,d_vect,niter) bind(C,name="hxv_lanczos_eigh")
+       import :: c_int, c_int32_t, c_ptr, c_double
+       type(c_ptr),value        :: h,d_vect
+       integer(c_int32_t),value :: nitermax
+       real(c_double),value     :: threshold
+       real(c_double)           :: egs
+       integer(c_int32_t)       :: niter
+     end function hxv_lanczos_eigh
+     integer(c_int) function hxv_lanczos_tridiag(h,d_vin,nlanc,alanc,blanc,threshold,nsteps) bind(C,name="hxv_lanczos_tridiag")
+       import :: c_int, c_int32_t, c_ptr, c_double
+       type(c_ptr),value        :: h,d_vin
+       integer(c_int32_t),value :: nlanc
+       real(c_double)           :: alanc(*),blanc(*)
+       real(c_double),value     :: threshold
+       integer(c_int32_t)       :: nsteps
+     end function hxv_lanczos_tridiag
+     integer(c_int) function hxv_apply_ladder_axpy(from,to,orbital,spin,create,coef_re,coef_im,accumulate,d_psi,d_out,norm2) &
+          bind(C,name="hxv_apply_ladder_axpy")
+       import :: c_int, c_int32_t, c_ptr, c_double
+       type(c_ptr),value        :: from,to,d_psi,d_out
+       integer(c_int32_t),value :: orbital,spin,create,accumulate
+       real(c_double),value     :: coef_re,coef_im
+       real(c_double)           :: norm2
+     end function hxv_apply_ladder_axpy
+     integer(c_int) function hxv_get_stats(h,st) bind(C,name="hxv_get_stats")
+       import :: c_int, c_ptr, hxv_stats
+       type(c_ptr),value :: h
+       type(hxv_stats)   :: st
+     end function hxv_get_stats
      type(c_ptr) function hxv_last_error() bind(C,name="hxv_last_error")
        import :: c_ptr
      end function hxv_last_error
@@ -361,6 +452,164 @@ contains
        if(iverbose)write(*,"(A,I4,A,I6,A,F20.12)")"gpu_sp_eigh: converged=",nconv," matvecs=",nmv," E0=",eval(1)
     endif
   end subroutine gpu_sp_eigh_serial
+
+  !> ---------------------------------------------------------------------------------------------------------------------------
+  !! DEVICE-RESIDENT Green's-function channel.  The reference builds every channel on the host (ED_GF_NORMAL.f90:174-217): the ground
+  !! state comes out of the eigensolver into a host array, c^dagger|gs> is formed by a serial loop on the master, scattered, and handed
+  !! to sp_lanc_tridiag -- with the drivers above that is three Dim-sized PCIe transfers per channel.  Here the ground state stays where
+  !! the eigensolver left it and the start vector is made next to it:
+  !!     call gpu_build_Hv_sector(...isector...)                        !sector of the ground state
+  !!     call gpu_sp_lanc_eigh_dev(egs,gs,Nitermax,threshold)           !gs: type(gpu_vector), stays on the device
+  !!     call gpu_keep_sector(gs)                                       !the sector stays open for gs; another one can be built
+  !!     call gpu_build_Hv_sector(...jsector...)                        !sector of c^dagger|gs>  (ED_GF_NORMAL.f90:176)
+  !!     call gpu_apply_ladder(gs,ipos,ispin,.true.,vv,norm2)           !vv = c^dagger_{ipos,ispin}|gs>, norm2 = <vv|vv>  (:180-199)
+  !!     call gpu_sp_lanc_tridiag_dev(vv,alfa_,beta_)                   !(:215) the engine normalises vv itself
+  !!     call gpu_free_vector(vv); call gpu_delete_Hv_sector()
+  !!     ... further channels from the same gs ...
+  !!     call gpu_free_vector(gs)                                       !closes the ground state's sector too
+  !! Mixed channels (:370-406, :746-780): a second gpu_apply_ladder into the same vv with accumulate=.true. and coef.
+  !! On a split sector (after gpu_comm_init) every rank holds and builds its own slab.
+  !! ---------------------------------------------------------------------------------------------------------------------------
+  subroutine gpu_sp_lanc_eigh_dev(egs,vect,Nitermax,iverbose,threshold)
+    real(8),intent(inout)          :: egs
+    type(gpu_vector),intent(inout) :: vect
+    integer,intent(in)             :: Nitermax
+    logical,intent(in),optional    :: iverbose
+    real(8),intent(in),optional    :: threshold
+    real(8)                        :: thr
+    integer(c_int32_t)             :: niter
+    if(.not.c_associated(handle))stop "gpu_sp_lanc_eigh_dev ERROR: Hsector NOT set"
+    if(c_associated(vect%d))stop "gpu_sp_lanc_eigh_dev ERROR: the vector is in use (gpu_free_vector it first)"
+    call check(hxv_vector_alloc(handle,vect%d),"gpu_sp_lanc_eigh_dev")
+    vect%sector=handle; vect%owns_sector=.false.
+    thr=1d-12; if(present(threshold))thr=max(threshold,1d-15)
+    call check(hxv_lanczos_eigh(handle,int(Nitermax,c_int32_t),thr,egs,vect%d,niter),"gpu_sp_lanc_eigh_dev")
+    if(present(iverbose))then
+       if(iverbose)write(*,"(A,I6,A,F20.12)")"gpu_sp_lanc_eigh_dev: iterations=",niter," E0=",egs
+    endif
+  end subroutine gpu_sp_lanc_eigh_dev
+
+  !> The open sector stays open FOR this vector (it is needed again when c / c^dagger act on it); the module's "one open sector" slot
+  !! becomes free, so build_Hv_sector of another sector may follow.  gpu_free_vector closes the kept sector.
+  subroutine gpu_keep_sector(vect)
+    type(gpu_vector),intent(inout) :: vect
+    if(.not.c_associated(handle))stop "gpu_keep_sector ERROR: Hsector NOT set"
+    if(.not.c_associated(vect%sector,handle))stop "gpu_keep_sector ERROR: the vector does not belong to the open sector"
+    vect%owns_sector=.true.
+    handle=c_null_ptr
+  end subroutine gpu_keep_sector
+
+  !> out = [out +] coef * c^(dagger)_{ipos,ispin} psi, from psi's sector into the OPEN sector; norm2 = <out|out> afterwards.
+  !! ipos = 1-based orbital position in the spin string (iorb+(ilat-1)*Norb, ED_GF_NORMAL.f90:176-199), ispin = 1 (up) | 2 (dw).
+  subroutine gpu_apply_ladder(psi,ipos,ispin,create,out,norm2,coef,accumulate)
+    type(gpu_vector),intent(in)    :: psi
+    integer,intent(in)             :: ipos,ispin
+    logical,intent(in)             :: create
+    type(gpu_vector),intent(inout) :: out
+    real(8),intent(out)            :: norm2
+    complex(8),intent(in),optional :: coef
+    logical,intent(in),optional    :: accumulate
+    complex(8)                     :: cf
+    integer(c_int32_t)             :: acc,cr
+    if(.not.c_associated(handle))stop "gpu_apply_ladder ERROR: Hsector NOT set (build the target sector first)"
+    if(.not.c_associated(psi%d))stop "gpu_apply_ladder ERROR: empty source vector"
+    cf=(1d0,0d0); if(present(coef))cf=coef
+    acc=0; if(present(accumulate))then; if(accumulate)acc=1; endif
+    if(.not.c_associated(out%d))then
+       if(acc==1)stop "gpu_apply_ladder ERROR: accumulate into an empty vector"
+       call check(hxv_vector_alloc(handle,out%d),"gpu_apply_ladder")
+       out%sector=handle; out%owns_sector=.false.
+    endif
+    if(.not.c_associated(out%sector,handle))stop "gpu_apply_ladder ERROR: the target vector does not belong to the open sector"
+    cr=0; if(create)cr=1
+    call check(hxv_apply_ladder_axpy(psi%sector,handle,int(ipos-1,c_int32_t),int(ispin-1,c_int32_t),cr,dble(cf),aimag(cf),acc,psi%d,out%d,norm2),&
+         "gpu_apply_ladder")
+  end subroutine gpu_apply_ladder
+
+  !> sp_lanc_tridiag (ED_GF_NORMAL.f90:215) from a start vector that is on the device already (normalised by the engine).
+  subroutine gpu_sp_lanc_tridiag_dev(vin,alanc,blanc,threshold)
+    type(gpu_vector),intent(in) :: vin
+    real(8),intent(inout)       :: alanc(:),blanc(:)
+    real(8),intent(in),optional :: threshold
+    real(8)                     :: thr
+    integer(c_int32_t)          :: nsteps
+    if(.not.c_associated(handle))stop "gpu_sp_lanc_tridiag_dev ERROR: Hsector NOT set"
+    if(.not.c_associated(vin%sector,handle))stop "gpu_sp_lanc_tridiag_dev ERROR: the start vector does not belong to the open sector"
+    thr=1d-12; if(present(threshold))thr=threshold
+    call check(hxv_lanczos_tridiag(handle,vin%d,int(size(alanc),c_int32_t),alanc,blanc,thr,nsteps),"gpu_sp_lanc_tridiag_dev")
+  end subroutine gpu_sp_lanc_tridiag_dev
+
+  !> the vector in the reference's host layout (this rank's slab), when it is wanted there after all (e.g. state_list of ED_DIAG)
+  subroutine gpu_vector_to_host(vect,v)
+    type(gpu_vector),intent(in) :: vect
+    complex(8),intent(inout)    :: v(:)
+    if(.not.c_associated(vect%d))stop "gpu_vector_to_host ERROR: empty vector"
+    if(int(size(v),c_int64_t)/=hxv_vecdim(vect%sector))stop "gpu_vector_to_host ERROR: size(v) /= vecDim of the vector's sector"
+    call check(hxv_vector_to_host(vect%sector,vect%d,v),"gpu_vector_to_host")
+  end subroutine gpu_vector_to_host
+
+  subroutine gpu_vector_from_host(v,vect)
+    complex(8),intent(in)          :: v(:)
+    type(gpu_vector),intent(inout) :: vect
+    if(.not.c_associated(vect%d))then
+       if(.not.c_associated(handle))stop "gpu_vector_from_host ERROR: Hsector NOT set"
+       call check(hxv_vector_alloc(handle,vect%d),"gpu_vector_from_host")
+       vect%sector=handle; vect%owns_sector=.false.
+    endif
+    if(int(size(v),c_int64_t)/=hxv_vecdim(vect%sector))stop "gpu_vector_from_host ERROR: size(v) /= vecDim of the vector's sector"
+    call check(hxv_vector_from_host(vect%sector,v,vect%d),"gpu_vector_from_host")
+  end subroutine gpu_vector_from_host
+
+  subroutine gpu_free_vector(vect)
+    type(gpu_vector),intent(inout) :: vect
+    if(c_associated(vect%d))call check(hxv_vector_free(vect%sector,vect%d),"gpu_free_vector")
+    if(vect%owns_sector.and.c_associated(vect%sector))call check(hxv_destroy(vect%sector),"gpu_free_vector")
+    vect%d=c_null_ptr; vect%sector=c_null_ptr; vect%owns_sector=.false.
+  end subroutine gpu_free_vector
+
+  !> Vector-sized bytes the engine has moved over PCIe for a sector since it was opened (include/hxv.h: hxv_stats): the open sector,
+  !! or the kept sector of `vect`.
+  subroutine gpu_pcie_bytes(h2d,d2h,vect)
+    integer(8),intent(out)               :: h2d,d2h
+    type(gpu_vector),intent(in),optional :: vect
+    type(hxv_stats)                      :: st
+    type(c_ptr)                          :: hh
+    hh=handle; if(present(vect))hh=vect%sector
+    if(.not.c_associated(hh))stop "gpu_pcie_bytes ERROR: no sector"
+    call check(hxv_get_stats(hh,st),"gpu_pcie_bytes")
+    h2d=st%h2d_bytes; d2h=st%d2h_bytes
+  end subroutine gpu_pcie_bytes
+
+  !> build_Hv_sector from the reference's OWN stored matrices (ED_HAMILTONIAN_SPARSE_HxV.f90:40-152 has built spH0ups(1), spH0dws(1),
+  !! spH0d): flatten each sparse_matrix_csr (ED_SPARSE_MATRIX.f90:13-30) row by row --
+  !!     rowptr(1)=0; do i=1,Nrow; rowptr(i+1)=rowptr(i)+sparse%row(i)%Size
+  !!                              cols(rowptr(i)+1:rowptr(i+1))=sparse%row(i)%cols; vals(...)=sparse%row(i)%vals; enddo
+  !! (columns stay 1-based, as sp_insert_element stores them) -- and the diagonal spH0d as its local rows, one value per row.
+  subroutine gpu_build_Hv_sector_from_csr(DimUp,DimDw,up_rowptr,up_cols,up_vals,dw_rowptr,dw_cols,dw_vals,diag,MpiRank,MpiSize,device)
+    integer,intent(in)          :: DimUp,DimDw
+    integer(8),intent(in)       :: up_rowptr(:),dw_rowptr(:)     ![DimUp+1], [DimDw+1], 0-based offsets
+    integer,intent(in)          :: up_cols(:),dw_cols(:)         !1-based columns
+    complex(8),intent(in)       :: up_vals(:),dw_vals(:),diag(:) !diag: mpiQdw*DimUp local rows
+    integer,intent(in)          :: MpiRank,MpiSize
+    integer,intent(in),optional :: device
+    integer                     :: dev
+    if(c_associated(handle))stop "gpu_build_Hv_sector_from_csr ERROR: a sector is already open"
+    if(size(up_rowptr)/=DimUp+1.or.size(dw_rowptr)/=DimDw+1)stop "gpu_build_Hv_sector_from_csr ERROR: rowptr sizes"
+    dev=0;if(present(device))dev=device
+    call check(hxv_create_from_csr(int(DimUp,c_int32_t),int(DimDw,c_int32_t),int(up_rowptr,c_int64_t),int(up_cols,c_int32_t),up_vals,&
+         int(dw_rowptr,c_int64_t),int(dw_cols,c_int32_t),dw_vals,diag,int(MpiRank,c_int32_t),int(MpiSize,c_int32_t),int(dev,c_int32_t),handle),&
+         "gpu_build_Hv_sector_from_csr")
+  end subroutine gpu_build_Hv_sector_from_csr
+
+  !> spH0nd (Jx, Jp; ED_VARS_GLOBAL.f90:145, sparse/H_non_local.f90:23-98) of a sector opened from stored matrices: the LOCAL rows with the
+  !! reference's GLOBAL 1-based columns, flattened like the others.
+  subroutine gpu_set_nonlocal_csr(rowptr,cols,vals)
+    integer(8),intent(in) :: rowptr(:)
+    integer,intent(in)    :: cols(:)
+    complex(8),intent(in) :: vals(:)
+    if(.not.c_associated(handle))stop "gpu_set_nonlocal_csr ERROR: Hsector NOT set"
+    call check(hxv_set_nonlocal_csr(handle,int(rowptr,c_int64_t),int(cols,c_int32_t),vals),"gpu_set_nonlocal_csr")
+  end subroutine gpu_set_nonlocal_csr
 
   !> MpiComm-first forms: the call text of the reference's MpiStatus=T branches compiles against these unchanged,
   !!   call sp_eigh(MpiComm,spHtimesV_p,eig_values,eig_basis,Nblock,Nitermax,tol=lanc_tolerance,iverbose=(ed_verbose>3))   ED_DIAG.f90:152-156

@@ -17,6 +17,7 @@ program hxv_fortran_demo
 
   call plaquette()
   call chain_ns12()
+  call gf_channel_on_device()
 
 contains
 
@@ -157,6 +158,86 @@ contains
     spHtimesV_p => null()
     call gpu_delete_Hv_sector()
   end subroutine mpi_branch
+
+  !> One Green's-function channel of lanc_build_gf_normal (ED_GF_NORMAL.f90:174-217), C2 model: ground state of sector (6,6),
+  !! c^dagger_{1,up}|gs> in sector (7,6), 100 Lanczos steps there -- first DEVICE-RESIDENT (gpu_sp_lanc_eigh_dev -> gpu_apply_ladder ->
+  !! gpu_sp_lanc_tridiag_dev: the engine's PCIe counters must stay at zero), then the way the reference does it (ground state in a host
+  !! array, the master's serial loop :180-199 restated below, sp_lanc_tridiag on the host array).  alanc / blanc must agree.
+  subroutine gf_channel_on_device()
+    integer,parameter :: Nlat=4,Norb=1,Nspin=1,Nbath=2,Ns=12,ipos=1,ispin=1,nl=100
+    complex(8) :: impHloc(Nlat,Nlat,Nspin,Nspin,Norb,Norb),Hbath(Nlat,Nlat,Nspin,Nspin,Norb,Norb,Nbath)
+    real(8)    :: Vbath(Nlat,Nspin,Norb,Nbath),Uloc(5),eps(Nbath)
+    type(gpu_vector) :: gs,vv
+    real(8)    :: egs,norm2,norm2h,a1(nl),b1(nl),a2(nl),b2(nl)
+    integer(8) :: h2d_a,d2h_a,h2d_b,d2h_b
+    complex(8),allocatable :: psi(:),vvinit(:)
+    integer,allocatable    :: map6(:),map7(:),pos7(:)
+    integer    :: i,ib,m,n6,n7,iup,idw,jup,dimA,dimB,sgn,k
+    impHloc=(0d0,0d0); Hbath=(0d0,0d0)
+    do i=1,Nlat
+       if(i>1)impHloc(i,i-1,1,1,1,1)=-0.25d0
+       if(i<Nlat)impHloc(i,i+1,1,1,1,1)=-0.25d0
+    enddo
+    eps=[0.3d0,0.6d0]
+    do ib=1,Nbath
+       Hbath(:,:,:,:,:,:,ib)=-abs(impHloc)
+       do i=1,Nlat
+          Hbath(i,i,1,1,1,1,ib)=eps(ib)
+       enddo
+    enddo
+    Vbath=1d0/sqrt(2d0)
+    Uloc=0d0; Uloc(1)=2d0
+    !--- device-resident channel
+    call gpu_build_Hv_sector(Nlat,Norb,Nspin,Nbath,6,6,impHloc,Hbath,Vbath,Uloc,0d0,0d0,0d0,0d0,0d0,.true.,0,1)
+    dimA=gpu_vecDim_Hv_sector()
+    call gpu_sp_lanc_eigh_dev(egs,gs,512,threshold=1d-14)
+    call gpu_keep_sector(gs)
+    call gpu_build_Hv_sector(Nlat,Norb,Nspin,Nbath,7,6,impHloc,Hbath,Vbath,Uloc,0d0,0d0,0d0,0d0,0d0,.true.,0,1)
+    dimB=gpu_vecDim_Hv_sector()
+    call gpu_apply_ladder(gs,ipos,ispin,.true.,vv,norm2)
+    a1=0d0; b1=0d0
+    call gpu_sp_lanc_tridiag_dev(vv,a1,b1)
+    call gpu_pcie_bytes(h2d_a,d2h_a,gs)
+    call gpu_pcie_bytes(h2d_b,d2h_b)
+    write(*,"(A,F16.10,A,ES24.16,A,4I12)")"GF device channel: E0=",egs," norm2=",norm2," PCIe bytes (h2d,d2h) gs-sector, channel-sector=",&
+         h2d_a,d2h_a,h2d_b,d2h_b
+    call gpu_free_vector(vv)
+    !--- the reference's way: ground state on the host, c^dagger by the master's loop, host start vector
+    allocate(psi(dimA),vvinit(dimB))
+    call gpu_vector_to_host(gs,psi)
+    allocate(map6(924),map7(792),pos7(0:2**Ns-1))
+    n6=0; n7=0; pos7=0
+    do m=0,2**Ns-1
+       if(popcnt(m)==6)then; n6=n6+1; map6(n6)=m; endif
+       if(popcnt(m)==7)then; n7=n7+1; map7(n7)=m; pos7(m)=n7; endif
+    enddo
+    vvinit=(0d0,0d0)
+    do idw=1,n6                       !sector (6,6) -> (7,6): DimDw = C(12,6) both, DimUp 924 -> 792
+       do iup=1,n6
+          m=map6(iup)
+          if(btest(m,ipos-1))cycle
+          sgn=1; if(mod(popcnt(iand(m,2**(ipos-1)-1)),2)==1)sgn=-1
+          jup=pos7(ibset(m,ipos-1))
+          vvinit(jup+(idw-1)*n7)=sgn*psi(iup+(idw-1)*n6)
+       enddo
+    enddo
+    norm2h=dble(dot_product(vvinit,vvinit))
+    vvinit=vvinit/sqrt(norm2h)
+    a2=0d0; b2=0d0
+    spHtimesV_p => gpuMatVec_main
+    call gpu_sp_lanc_tridiag(spHtimesV_p,vvinit,a2,b2)
+    !(entry by entry on the early steps only: once the extremal Ritz values converge the recurrence amplifies rounding differences,
+    ! and the quantity the consumer uses -- the spectrum of the tridiagonal matrix, ED_GF_NORMAL.f90:949-953 -- is compared instead)
+    k=8
+    write(*,"(A,ES12.4,A,ES12.4,A,ES12.4,A,2F16.10)")"GF host-array channel: |norm2 diff|=",abs(norm2h-norm2)," max|da|(8)=",maxval(abs(a1(1:k)-a2(1:k))),&
+         " max|db|(8)=",maxval(abs(b1(1:k)-b2(1:k)))," lowest Ritz values=",lowest_tridiag(a1,b1),lowest_tridiag(a2,b2)
+    call gpu_pcie_bytes(h2d_b,d2h_b)
+    write(*,"(A,2I12)")"GF host-array channel: PCIe bytes (h2d,d2h) channel-sector=",h2d_b,d2h_b
+    spHtimesV_p => null()
+    call gpu_delete_Hv_sector()
+    call gpu_free_vector(gs)
+    deallocate(psi,vvinit,map6,map7,pos7)
+  end subroutine gf_channel_on_device
 
   !> lowest eigenvalue of the Lanczos tridiagonal by bisection (Sturm count); blanc(1) unused
   function lowest_tridiag(a,b) result(e)

@@ -34,7 +34,7 @@ class _Stats(C.Structure):
     _fields_ = [
         ("n_apply", C.c_int64), ("algorithmic_bytes", C.c_int64), ("device_bytes", C.c_int64),
         ("kernel", C.c_int32), ("real_h", C.c_int32), ("k_up", C.c_int32), ("k_dw", C.c_int32),
-        ("n_hops_up", C.c_int32), ("n_hops_dw", C.c_int32),
+        ("n_hops_up", C.c_int32), ("n_hops_dw", C.c_int32), ("h2d_bytes", C.c_int64), ("d2h_bytes", C.c_int64),
     ]
 
 
@@ -46,6 +46,7 @@ EXPORTS = [
     "hxv_version", "hxv_comm_unique_id", "hxv_comm_init", "hxv_comm_free", "hxv_apply_device_slab", "hxv_exchange_count",
     "hxv_set_exchange_default", "hxv_exchange_mode", "hxv_halo_counts", "hxv_halo_lists", "hxv_halo_plan_from_csr",
     "hxv_comm_local_create", "hxv_comm_init_local", "hxv_comm_local_destroy", "hxv_comm_local_abort", "hxv_time_apply_slab",
+    "hxv_vector_alloc", "hxv_vector_free", "hxv_vector_from_host", "hxv_vector_to_host",
 ]
 
 _lib = None
@@ -119,6 +120,10 @@ def load_library():
     L.hxv_comm_init.argtypes = [vp, vp]
     L.hxv_comm_free.argtypes = [vp]
     L.hxv_apply_device_slab.argtypes = [vp, vp, vp, vp]
+    L.hxv_vector_alloc.argtypes = [vp, C.POINTER(vp)]
+    L.hxv_vector_free.argtypes = [vp, vp]
+    L.hxv_vector_from_host.argtypes = [vp, vp, vp]
+    L.hxv_vector_to_host.argtypes = [vp, vp, vp]
     L.hxv_time_apply_slab.argtypes = [vp, vp, vp, i32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.hxv_exchange_count.argtypes = [vp]
     L.hxv_exchange_count.restype = i64

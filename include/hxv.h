@@ -312,6 +312,17 @@ int hxv_apply_ladder(hxv_handle *from, hxv_handle *to, int32_t orbital, int32_t 
 int hxv_apply_ladder_axpy(hxv_handle *from, hxv_handle *to, int32_t orbital, int32_t spin, int32_t create, double coef_re,
                           double coef_im, int32_t accumulate, const void *d_psi, void *d_out, double *norm2);
 
+/* ---- device vectors owned by the library --------------------------------------------------------------------------------
+ * For host programs without a HIP binding of their own (the Fortran glue): a local vector of the handle's sector in the padded device
+ * layout (hxv_localvec_elems() complex elements, zeroed), from the engine's buffer cache.  Such a pointer is what the device drivers take
+ * and return (hxv_lanczos_eigh's d_vect, hxv_apply_ladder's d_psi / d_out, hxv_lanczos_tridiag's d_vin), so a Green's-function channel --
+ * ground state, c^dagger|gs>, tridiagonalisation (ED_GF_NORMAL.f90:174-217) -- runs without a Dim-sized PCIe transfer; the two copies
+ * convert to / from the reference's contiguous host layout when a vector is wanted on the host after all.  Free before hxv_destroy. */
+int hxv_vector_alloc(hxv_handle *h, void **d_vec);
+int hxv_vector_free(hxv_handle *h, void *d_vec);
+int hxv_vector_from_host(hxv_handle *h, const void *v_host, void *d_vec);
+int hxv_vector_to_host(hxv_handle *h, const void *d_vec, void *v_host);
+
 /* ---- device-buffer cache.  A fresh hipMalloc costs ~25 ms per GB on this platform (0.7 s for the 28 GB Krylov basis of
  * hxv_eigh_lowest at Ns=16), and an ED run opens sectors one after another, so the vector-sized buffers a handle frees
  * (dw-hop scratch, Lanczos vectors, staging, Krylov basis) are kept per device and reused by the next handle.
@@ -366,6 +377,9 @@ typedef struct {
   int32_t real_h;           /* 1 if all hopping amplitudes are real        */
   int32_t k_up, k_dw;       /* max stored entries per row of H_up / H_dw   */
   int32_t n_hops_up, n_hops_dw;
+  int64_t h2d_bytes;        /* vector-sized host -> device traffic of the host-array entry points (hxv_apply_host, *_host drivers,   */
+  int64_t d2h_bytes;        /* hxv_vector_from_host) and device -> host (results, hxv_vector_to_host) since creation: 0 + 0 for a    */
+                            /* Green's-function channel that runs device-resident                                                  */
 } hxv_stats;
 int hxv_get_stats(const hxv_handle *h, hxv_stats *out);
 

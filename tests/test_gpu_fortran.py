@@ -97,3 +97,29 @@ def test_fortran_paired_tridiagonalisation(built):
     assert mp and ms, txt
     assert abs(float(mp.group(1)) - float(ms.group(1))) < 1e-10
     assert abs(float(mp.group(1)) - e0) < 1e-8 and abs(float(mp.group(2)) - e0) < 1e-8
+
+
+def test_fortran_device_resident_green_function_channel(built):
+    """gpu_sp_lanc_eigh_dev -> gpu_keep_sector -> gpu_apply_ladder -> gpu_sp_lanc_tridiag_dev (the three-line change of
+    ED_GF_NORMAL.f90:174-217 in INTEGRATION.md): ground state, c^dagger|gs> and a 100-step tridiagonalisation with NO Dim-sized PCIe
+    transfer (the engine's own h2d / d2h byte counters, hxv_get_stats), alanc / blanc equal to the host-array path -- the reference's
+    serial c^dagger loop restated in the demo host + gpu_sp_lanc_tridiag on the host array, which does move vectors."""
+    exe = built.build_fortran()
+    if exe is None:
+        pytest.skip("flang not available")
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    txt = out.stdout
+    m = re.search(r"GF device channel: E0=\s*([-\d.Ee+]+)\s*norm2=\s*([-\d.Ee+]+).*channel-sector=\s*(\d+)\s+(\d+)\s+(\d+)\s+(\d+)", txt)
+    assert m, txt
+    e0, norm2 = float(m.group(1)), float(m.group(2))
+    assert [int(m.group(k)) for k in (3, 4, 5, 6)] == [0, 0, 0, 0]            # nothing vector-sized crossed PCIe
+    e0_ref = float(re.search(r"C2 device eigh E0=\s*([-\d.Ee+]+)", txt).group(1))
+    assert abs(e0 - e0_ref) < 1e-9 and 0.0 < norm2 < 1.0
+    h = re.search(r"GF host-array channel: \|norm2 diff\|=\s*([-\d.Ee+]+)\s*max\|da\|\(8\)=\s*([-\d.Ee+]+)\s*max\|db\|\(8\)=\s*([-\d.Ee+]+)\s*"
+                  r"lowest Ritz values=\s*([-\d.Ee+]+)\s+([-\d.Ee+]+)", txt)
+    assert h, txt
+    assert float(h.group(1)) < 1e-12 and float(h.group(2)) < 1e-10 and float(h.group(3)) < 1e-10
+    assert abs(float(h.group(4)) - float(h.group(5))) < 1e-9
+    hb = re.search(r"GF host-array channel: PCIe bytes \(h2d,d2h\) channel-sector=\s*(\d+)\s+(\d+)", txt)
+    assert int(hb.group(1)) == 792 * 924 * 16                                  # the host start vector of sector (7,6), once

@@ -767,3 +767,38 @@ def test_fused_epilogue_matches_plain_recurrence_for_every_kernel_family(built, 
                     tried += 1
     assert tried == 24
     sec.close()
+
+
+def test_library_owned_device_vectors_and_pcie_counters(built):
+    """hxv_vector_alloc / _from_host / _to_host / _free (what the Fortran glue keeps between calls) and the h2d / d2h byte counters of
+    hxv_get_stats: a round trip is exact, device-resident drivers leave the counters alone, host-array entry points count their slabs."""
+    import ctypes as C
+    import hxv
+    from hxv import models
+
+    m = models.hm_1dchain(Nlat=2, Nbath=2, eps_bath=[0.3, 0.6])
+    sec = hxv.HxvSector.from_model(m, 3, 3)
+    L = hxv.load_library()
+    v = models.deterministic_vector(sec.Dim)
+    v /= np.linalg.norm(v)
+    d = C.c_void_p()
+    assert L.hxv_vector_alloc(sec._h, C.byref(d)) == 0 and d.value
+    assert sec.stats()["h2d_bytes"] == 0 and sec.stats()["d2h_bytes"] == 0
+    assert L.hxv_vector_from_host(sec._h, v.ctypes.data, d) == 0
+    back = np.zeros_like(v)
+    assert L.hxv_vector_to_host(sec._h, d, back.ctypes.data) == 0
+    assert np.array_equal(back, v)
+    st = sec.stats()
+    assert st["h2d_bytes"] == 16 * sec.Dim and st["d2h_bytes"] == 16 * sec.Dim
+    a = np.zeros(10)
+    b = np.zeros(10)
+    n = C.c_int32()
+    assert L.hxv_lanczos_tridiag(sec._h, d, 10, a.ctypes.data_as(C.POINTER(C.c_double)), b.ctypes.data_as(C.POINTER(C.c_double)), 1e-12, C.byref(n)) == 0
+    assert sec.stats()["h2d_bytes"] == 16 * sec.Dim                          # device-resident: nothing moved
+    a2, b2, _ = sec.lanczos_tridiag_host(v, 10)
+    assert np.allclose(a, a2, rtol=0, atol=1e-13) and sec.stats()["h2d_bytes"] == 32 * sec.Dim
+    sec.apply_host(v)
+    st = sec.stats()
+    assert st["h2d_bytes"] == 48 * sec.Dim and st["d2h_bytes"] == 32 * sec.Dim
+    assert L.hxv_vector_free(sec._h, d) == 0
+    sec.close()
