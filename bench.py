@@ -30,7 +30,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT / "cdmft-lanc-ed_amd"))
 sys.path.insert(0, str(ROOT))
 
-KERNELS_STAMP = "r03-final"   # bumped whenever the product kernels change: profiles/traffic.json is quoted only for the same stamp
+KERNELS_STAMP = "r04-a"   # bumped whenever the product kernels change: profiles/traffic.json is quoted only for the same stamp
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 

@@ -42,8 +42,11 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
   // column group: all blocks of a group share blockIdx%8 (= one XCD), and each XCD owns a contiguous range of
   // groups because neighbouring groups share the cache lines of the transposed scratch wt
   const int gl = j / t.nblocks;
-  const int g = xcd * groups_per_xcd + gl;
   int kb = j - gl * t.nblocks;
+  // (Round 4 also ran the tiles of Kanamori sectors block-major inside chunks of 8 - 64 column groups, so that the partner columns of the
+  //  folded spH0nd block's dw moves were L2-resident: 7.37 - 8.14 ms against 7.12 at C4 with Jx / Jp -- the hopping part's out-of-block
+  //  gathers, then G tiles apart, lose more than the block gains; profiles/r04_ab_kanamori_chunks.log.)
+  const int g = xcd * groups_per_xcd + gl;
   if (gl >= groups_per_xcd || g >= ngroups) {
     if (LZ && threadIdx.x == 0) {
       lz.partial[blockIdx.x] = 0.0;
