@@ -252,6 +252,9 @@ int hxv_destroy(hxv_handle* h) {
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   for (auto e : h->kt_ev)
     if (e) (void)hipEventDestroy(e);
+  for (auto e : h->ov_ev)
+    if (e) (void)hipEventDestroy(e);
+  if (h->stream2) (void)hipStreamDestroy(h->stream2);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -549,6 +552,10 @@ int hxv_set_option(hxv_handle* h, const char* name, int64_t value) {
     h->lz_inplace = value ? 1 : 0;
     return HXV_OK;
   }
+  if (!strcmp(name, "exchange_overlap")) {  // exchange mode 2: diagonal + up hops on a second stream during the transposes (plain products)
+    h->a2a_overlap = value ? 1 : 0;
+    return HXV_OK;
+  }
   if (!strcmp(name, "fold_nd")) {  // spH0nd inside pass A (default) or as its own pass over hv
     h->dev.nd.fold = h->host.nd.fold = value ? 1 : 0;
     return HXV_OK;
@@ -597,6 +604,7 @@ int64_t hxv_get_option(const hxv_handle* h, const char* name) {
   if (!strcmp(name, "lanczos_real_last")) return h->last_real;
   if (!strcmp(name, "slab_copies")) return h->n_slab_copy;  // exchanges whose vector was not at home in a gather buffer
   if (!strcmp(name, "lanczos_inplace")) return h->lz_inplace;
+  if (!strcmp(name, "exchange_overlap")) return h->a2a_overlap;
   if (!strcmp(name, "kernel")) return h->kernel;
   if (!strcmp(name, "tile_bits_up")) return h->plan.up.lowbits;
   if (!strcmp(name, "tile_bits_dw")) return h->plan.dw.lowbits;

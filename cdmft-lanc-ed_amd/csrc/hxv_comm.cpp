@@ -550,6 +550,29 @@ static int apply_slab_a2a(hxv_handle* h, const void* v_, void* hv_, bool real, h
   const char* v = static_cast<const char*>(v_);
   char *send = reinterpret_cast<char*>(a.d_send), *recv = reinterpret_cast<char*>(a.d_recv), *x = reinterpret_cast<char*>(a.d_x),
        *y = reinterpret_cast<char*>(a.d_y);
+  // OVERLAPPED form (option "exchange_overlap", plain products): the reference computes the diagonal and the up hops before its first
+  // transpose (ED_HAMILTONIAN_SPARSE_HxV.f90:250-270, then :272-296); here they run on a second stream WHILE pack, transpose, panel
+  // product and transpose back are under way, and the dw part is added at the end (hv += pieces: 32 B per local state more than the
+  // fused form, which reads the pieces as pass A's accumulator init).  Pays where a transpose takes longer than pass A on the slab.
+  const bool overlap = h->a2a_overlap && !ep && h->plan.usable;
+  if (overlap) {
+    if (!h->stream2) HIPCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    for (auto& e : h->ov_ev)
+      if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(h->ov_ev[0], st));                 // v is ready (and the previous user of hv is done) on st
+    HIPCHK(hipStreamWaitEvent(h->stream2, h->ov_ev[0], 0));
+    hipError_t eo;
+    if (real) {
+      DevSector d = h->dev;
+      d.pitch = (int)pit;
+      eo = launch_hxv_tiled_real(d, h->plan, reinterpret_cast<const double*>(v) - (int64_t)d.slab0 * d.pitch, nullptr, static_cast<double*>(hv_), h->stream2, nullptr, 1, true);
+    } else {
+      eo = launch_hxv_tiled(h->dev, h->plan, reinterpret_cast<const double2*>(v) - (int64_t)h->dev.slab0 * h->dev.pitch, nullptr, static_cast<double2*>(hv_), h->stream2,
+                            nullptr, 1, true);
+    }
+    if (eo != hipSuccess) return fail(HXV_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(eo));
+    HIPCHK(hipEventRecord(h->ov_ev[1], h->stream2));
+  }
   // 1. my slab cut by the receivers' row ranges; my own block goes straight into the panel
   for (int p = 0; p < P; ++p) {
     if (p == me)
@@ -583,6 +606,17 @@ static int apply_slab_a2a(hxv_handle* h, const void* v_, void* hv_, bool real, h
       if (p != me) HIPCHK(copy_block(send + (size_t)a.sp2[p] * esz, nme, y + (size_t)a.cc0[p] * pp * esz, pp, nme, a.cq[p], esz, st));
   rc = direct ? comm_sendrecv_cols(h, y, a.pan.data(), recv, a.rp2.data(), esz, st) : comm_sendrecv_cols(h, send, a.sp2.data(), recv, a.rp2.data(), esz, st);
   if (rc) return rc;
+  if (overlap) {
+    // 4'. the dw part joins what the second stream has computed meanwhile
+    HIPCHK(hipStreamWaitEvent(st, h->ov_ev[1], 0));
+    kt_mark(h, 2, st);
+    hipError_t ea = launch_add_pieces(hv_, a.d_wtr[real ? 1 : 0], P, s.dimup, (int)pit, q, real, st);
+    if (ea != hipSuccess) return fail(HXV_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(ea));
+    kt_mark(h, 3, st);
+    h->n_apply++;
+    h->n_exchange += 2;
+    return HXV_OK;
+  }
   // 4. diagonal + up hops + the assembled dw part on the slab (pass A alone, with the Lanczos epilogue when asked for)
   if (!h->plan.usable) return fail(HXV_ERR_UNSUPPORTED, "all-to-all exchange: tiled kernels unavailable (too many distinct amplitudes)");
   hipError_t e;

@@ -90,6 +90,9 @@ struct hxv_handle {
   double2* d_gather = nullptr;   // nranks * cmax * pitch elements (all-gather layout) / (qdw + halo) * pitch (halo layout)
   double2* d_gather_x[2] = {nullptr, nullptr};  // two more of the same for the device Lanczos on a split sector (three vectors rotate)
   double2* gather_cur = nullptr; // the gather buffer the exchange under way / last done runs on (peers of a thread group read it)
+  int a2a_overlap = 0;           // option "exchange_overlap": exchange mode 2 runs diagonal + up hops on a second stream while the transposes are under way
+  hipStream_t stream2 = nullptr; // that second stream and its two events (created on first use)
+  hipEvent_t ov_ev[2] = {nullptr, nullptr};
   void* a2a = nullptr;           // exchange 2 (two all-to-all transposes): panel handle, staging buffers, per-peer offsets (hxv_comm.cpp)
   int64_t n_slab_copy = 0;       // slab copies into a gather buffer (exchange with a vector that is not at home)
   double2* d_send = nullptr;     // halo exchange: packed columns, grouped by destination rank

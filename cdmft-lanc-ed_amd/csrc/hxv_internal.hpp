@@ -147,6 +147,9 @@ hipError_t launch_ladder(const uint32_t* map_from, int dim_from, const uint32_t*
                          int pitch_to, int dimdw_to, int orbital, int spin, int create, const double2* psi, double2* out, hipStream_t st,
                          double2 coef = double2{1.0, 0.0}, int accumulate = 0);
 // d_out[k*pitch + i] = d_in[cols[k]*pitch + i]: the columns a peer needs, packed for the halo exchange
+struct WtRange;
+// hv(row, c) += the dw part handed over in row ranges (exchange mode 2, overlapped form); hv: [ncols][pitch] elements of double2 or double
+hipError_t launch_add_pieces(void* hv, const WtRange* wtr, int nwtr, int dimup, int pitch, int ncols, bool real, hipStream_t st);
 hipError_t launch_pack_columns(const double2* d_in, double2* d_out, const int32_t* d_cols, int ncols, int pitch, hipStream_t st);
 // true: the tiled product adds the spH0nd block itself (pass A, hxv_tiled.hip); false: launch_hxv_nonlocal after the product
 inline bool nd_folds(const DevSector& s) { return s.nd.active && s.nd_up && s.nd_dw && s.nd.fold; }

@@ -7,6 +7,7 @@
 #include <algorithm>
 
 #include "hxv_device.hpp"
+#include "hxv_tile_dev.hpp"
 
 namespace hxv {
 
@@ -180,6 +181,31 @@ __global__ void __launch_bounds__(256) pack_columns_kernel(const double2* __rest
 hipError_t launch_pack_columns(const double2* d_in, double2* d_out, const int32_t* d_cols, int ncols, int pitch, hipStream_t st) {
   if (ncols <= 0) return hipSuccess;
   hipLaunchKernelGGL(pack_columns_kernel, dim3((unsigned)ncols), dim3(256), 0, st, d_in, d_out, d_cols, pitch);
+  return hipGetLastError();
+}
+
+// hv += the dw part, read where the second transpose of exchange mode 2 left it (one block per rank of origin, WtRange): the last step of
+// the OVERLAPPED form of that exchange, where diagonal + up hops ran on a second stream while the transposes were under way.
+template <typename VT>
+__global__ void __launch_bounds__(256) add_pieces_kernel(VT* __restrict__ hv, const WtRange* __restrict__ wtr, int nwtr, int dimup, int pitch) {
+  const int c = blockIdx.y;
+  for (int row = blockIdx.x * 256 + threadIdx.x; row < dimup; row += gridDim.x * 256) {
+    int k = 0;
+    while (k + 1 < nwtr && row >= wtr[k].row1) ++k;
+    const VT* __restrict__ src = reinterpret_cast<const VT*>(wtr[k].base) + (int64_t)c * wtr[k].stride + (row - wtr[k].row0);
+    VT a = hv[(int64_t)c * pitch + row];
+    vadd(a, *src);
+    hv[(int64_t)c * pitch + row] = a;
+  }
+}
+
+hipError_t launch_add_pieces(void* hv, const WtRange* wtr, int nwtr, int dimup, int pitch, int ncols, bool real, hipStream_t st) {
+  if (ncols <= 0) return hipSuccess;
+  const dim3 grid((unsigned)std::min((dimup + 255) / 256, 64), (unsigned)ncols);
+  if (real)
+    hipLaunchKernelGGL(add_pieces_kernel<double>, grid, dim3(256), 0, st, (double*)hv, wtr, nwtr, dimup, pitch);
+  else
+    hipLaunchKernelGGL(add_pieces_kernel<double2>, grid, dim3(256), 0, st, (double2*)hv, wtr, nwtr, dimup, pitch);
   return hipGetLastError();
 }
 

@@ -360,6 +360,9 @@ int hxv_get_diag(const hxv_handle *h, double *diag);
  *   the exchanges that had to copy.
  * Scheduling knobs (results unchanged): "pair_rows" -1|0|1 [-1 = by sector size: pass B runs the two row groups of a 128-byte line
  *   back to back], "job_max_blocks" [32: pass A as jobs only up to this many blocks per spin], "fold_nd" 0|1 [1: spH0nd inside pass A],
+ *   "exchange_overlap" 0|1 [0: exchange mode 2 of a split sector runs diagonal + up hops on a second stream WHILE the two transposes and the
+ *   panel product are under way (the reference's order, ED_HAMILTONIAN_SPARSE_HxV.f90:250-296) and adds the dw part at the end; plain
+ *   products only; 32 B per local state more HBM traffic than the fused form, for hiding pass A behind the links],
  *   "block_order" -1|0|1|2 [-1: dispatch order of a group's blocks in the tile kernels -- 1 by the particle number of the high orbitals
  *   (coupled blocks close together; the automatic choice where table classes are few), 0 largest block first, 2 natural].
  * Timing experiments (results are wrong or partial when set; refused unless HXV_EXPERIMENTS=1 is in the environment):

@@ -80,6 +80,14 @@ def test_product_of_every_rank_through_the_exchange(built, transport, name, nran
         else:
             with pytest.raises(hxv.HxvError, match="no gathered vector"):
                 sec.slab_home()
+            # the OVERLAPPED form of the two-transposes exchange (diagonal + up hops on a second stream during the transposes, the dw
+            # part added at the end -- the reference's own order, ED_HAMILTONIAN_SPARSE_HxV.f90:250-296): the same product
+            sec.set_option("exchange_overlap", 1)
+            for _ in range(2):   # (twice: the second product's second stream must wait for the first one's readers)
+                got_ov = sec.unpad(sec.apply_device_slab(dv)).cpu().numpy()
+            assert np.abs(got_ov - got_dev).max() <= 1e-14 * max(np.abs(got_dev).max(), 1e-300)
+            sec.set_option("exchange_overlap", 0)
+            n_ex = sec.exchange_count - 4
         sec.close()
         return lo, hi, got_host, got_dev, n_ex
 
