@@ -79,7 +79,7 @@ def test_random_models_sectors_shards_and_tile_options(built, seed):
         opts = [{}, {"lds_budget_kb": int(rng.choice([8, 16, 32])), "cols_per_tile": int(rng.choice([2, 4, 8])), "rows_per_tile": int(rng.choice([2, 4, 8])),
                      "threads_up": int(rng.choice([256, 512, 1024])), "threads_dw": int(rng.choice([256, 512, 1024])), "sort_mode": int(rng.integers(3)),
                      "wt_cols": int(rng.choice([2, 4, 8, 16])), "job_cols": int(rng.choice([1, 2])), "pair_rows": int(rng.choice([0, 1])),
-                     "job_groups": int(rng.choice([1, 3, 100])), "job_max_blocks": int(rng.choice([0, 32]))},
+                     "job_groups": int(rng.choice([1, 3, 100])), "job_max_blocks": int(rng.choice([0, 32])), "block_order": int(rng.choice([-1, 0, 1, 2]))},
                 {"kernel": 0}]
         for o in opts:
             try:
@@ -161,7 +161,8 @@ def test_random_ns12_models_multi_block_plans(built, shape, sector, seed):
         sec = hxv.HxvSector.from_model(m, nup, ndw, rank=rank, nranks=size)
         dv = torch.from_numpy(sec.to_gather_layout(v, size)).cuda()
         want = ref[sec.mpiIshift: sec.mpiIshift + sec.vecDim]
-        for o in ({}, {"lds_budget_kb": 16}, {"lds_budget_kb": 8, "cols_per_tile": 2, "rows_per_tile": 8}, {"kernel": 0}):
+        for o in ({}, {"lds_budget_kb": 16, "block_order": 0}, {"lds_budget_kb": 8, "cols_per_tile": 2, "rows_per_tile": 8, "block_order": 1}, {"block_order": 2},
+                  {"kernel": 0}):
             for k, val in o.items():
                 sec.set_option(k, val)
             got = sec.unpad(sec.apply_device(dv)).cpu().numpy()
