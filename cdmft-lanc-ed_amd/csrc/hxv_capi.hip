@@ -249,6 +249,8 @@ int hxv_destroy(hxv_handle* h) {
   pool_free(h->device, h->d_wt);
   for (auto& p : h->d_lz) pool_free(h->device, p);
   if (h->d_lz_partial) (void)hipFree(h->d_lz_partial);
+  for (void* v : h->owned_vectors) pool_free(h->device, v);  // (vectors the caller never freed)
+  h->owned_vectors.clear();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   for (auto e : h->kt_ev)
     if (e) (void)hipEventDestroy(e);
@@ -416,6 +418,7 @@ int hxv_vector_alloc(hxv_handle* h, void** d_vec) {
   HIPCHK(pool_alloc(h->device, bytes, &p));
   HIPCHK(hipMemsetAsync(p, 0, bytes, h->stream));   // (pad rows must be zero; on the handle's stream, like every other fill)
   HIPCHK(hipStreamSynchronize(h->stream));
+  h->owned_vectors.push_back(p);
   *d_vec = p;
   return HXV_OK;
 }
@@ -423,6 +426,9 @@ int hxv_vector_alloc(hxv_handle* h, void** d_vec) {
 int hxv_vector_free(hxv_handle* h, void* d_vec) {
   if (!h) return fail(HXV_ERR_ARG, "hxv_vector_free: NULL handle");
   if (!d_vec) return HXV_OK;
+  auto it = std::find(h->owned_vectors.begin(), h->owned_vectors.end(), d_vec);
+  if (it == h->owned_vectors.end()) return fail(HXV_ERR_ARG, "hxv_vector_free: not a vector of this handle (or freed already)");
+  h->owned_vectors.erase(it);
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   pool_free(h->device, d_vec);

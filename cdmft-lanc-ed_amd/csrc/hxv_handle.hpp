@@ -99,6 +99,7 @@ struct hxv_handle {
   int32_t* d_send_cols = nullptr;
   int64_t n_exchange = 0;
   int64_t n_apply = 0;
+  std::vector<void*> owned_vectors;      // hxv_vector_alloc'ed and not yet freed (hxv_destroy returns what is left to the buffer cache)
   int64_t h2d_bytes = 0, d2h_bytes = 0;  // vector-sized PCIe traffic of the host-array entry points and hxv_vector_from/to_host (hxv_get_stats)
   int64_t device_bytes = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;

@@ -317,7 +317,8 @@ int hxv_apply_ladder_axpy(hxv_handle *from, hxv_handle *to, int32_t orbital, int
  * layout (hxv_localvec_elems() complex elements, zeroed), from the engine's buffer cache.  Such a pointer is what the device drivers take
  * and return (hxv_lanczos_eigh's d_vect, hxv_apply_ladder's d_psi / d_out, hxv_lanczos_tridiag's d_vin), so a Green's-function channel --
  * ground state, c^dagger|gs>, tridiagonalisation (ED_GF_NORMAL.f90:174-217) -- runs without a Dim-sized PCIe transfer; the two copies
- * convert to / from the reference's contiguous host layout when a vector is wanted on the host after all.  Free before hxv_destroy. */
+ * convert to / from the reference's contiguous host layout when a vector is wanted on the host after all.  hxv_vector_free takes the handle the
+ * vector was allocated on, BEFORE that handle is destroyed; hxv_destroy returns whatever was not freed.                              */
 int hxv_vector_alloc(hxv_handle *h, void **d_vec);
 int hxv_vector_free(hxv_handle *h, void *d_vec);
 int hxv_vector_from_host(hxv_handle *h, const void *v_host, void *d_vec);
