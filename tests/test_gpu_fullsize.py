@@ -8,6 +8,8 @@ from the deterministic start vector of SURVEY.md 8d, run until |dE| < 1e-12 and 
 drivers run the same sectors at full size (call shapes ED_DIAG.f90:152-184, ED_GF_NORMAL.f90:215):
   hxv_lanczos_tridiag   alanc / blanc of the first 20 steps from the same start vector        1e-10 (relative to max |alanc|)
                         lowest Ritz value of the fixture's full run length                    1e-10 absolute
+                        G(i w_n) = <v|(i w_n + E0 - H)^-1|v>, the continued fraction the consumer builds from alanc / blanc
+                        (ED_GF_NORMAL.f90:915-975), first 32 Matsubara frequencies at beta = 50     1e-9 absolute (the stated G tolerance)
   hxv_lanczos_eigh      E0 (its own hashed start vector)                                      1e-10 absolute
   hxv_eigh_lowest       E0 (thick-restart Lanczos, ncv = 20)                                  1e-10 absolute
 """
@@ -66,6 +68,16 @@ def test_tridiag_first_steps_and_ritz_value_at_headline_size(built, name):
     # what the consumer does with the coefficients (ED_GF_NORMAL.f90:949-953): the tridiagonal matrix's lowest eigenvalue
     e0 = eigh_tridiagonal(a, b[1:], select="i", select_range=(0, 0))[0][0]
     assert abs(e0 - g["E0"]) <= 1e-10, (e0, g["E0"])
+    # ... and the Green's function of the start vector from the two coefficient sets: poles E_j - E0 of the tridiagonal matrix with weights
+    # Z(1,j)^2 (add_to_lanczos_gf_normal, :953-964), on wm = pi/beta*(2n-1) (:966-973).  Later alanc / blanc differ by amplified rounding;
+    # G does not care.
+    wm = np.pi / 50.0 * (2 * np.arange(1, 33) - 1)
+
+    def gf(al, bl):
+        ev, z = eigh_tridiagonal(np.asarray(al), np.asarray(bl)[1:])
+        return ((z[0, :] ** 2)[None, :] / (1j * wm[:, None] - (ev - g["E0"])[None, :])).sum(axis=1)
+
+    assert np.abs(gf(a, b) - gf(a_ref[:n_ref], b_ref[:n_ref])).max() <= 1e-9
     del v
     sec.close()
     torch.cuda.empty_cache()
