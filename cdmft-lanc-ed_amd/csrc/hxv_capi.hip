@@ -519,6 +519,11 @@ int hxv_set_option(hxv_handle* h, const char* name, int64_t value) {
     h->lz_graph = value ? 1 : 0;
     return HXV_OK;
   }
+  if (!strcmp(name, "eigh_keep_pct")) {
+    if (value < 5 || value > 80) return fail(HXV_ERR_ARG, "eigh_keep_pct must be in [5,80]");
+    h->eigh_keep_pct = (int)value;
+    return HXV_OK;
+  }
   if (!strcmp(name, "eigh_degenerate")) {
     h->eigh_degenerate = value ? 1 : 0;
     return HXV_OK;
@@ -604,6 +609,7 @@ int64_t hxv_get_option(const hxv_handle* h, const char* name) {
   if (!strcmp(name, "real_vectors")) return h->real_vectors;
   if (!strcmp(name, "lanczos_graph")) return h->lz_graph;
   if (!strcmp(name, "eigh_degenerate")) return h->eigh_degenerate;
+  if (!strcmp(name, "eigh_keep_pct")) return h->eigh_keep_pct;
   if (!strcmp(name, "eigh_measure_all")) return h->eigh_measure_all;
   if (!strcmp(name, "eigh_last_full_passes")) return h->eigh_last_full;
   if (!strcmp(name, "eigh_last_local_passes")) return h->eigh_last_local;

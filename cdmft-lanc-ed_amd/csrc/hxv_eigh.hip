@@ -247,8 +247,10 @@ bool jacobi_eigh(int n, std::vector<double>& A, std::vector<double>& w, std::vec
   return done;
 }
 
-int keep_count(int m, int neigen, int nconv) {
-  int k = neigen + std::min(nconv, (m - neigen) / 2) + std::max(1, (m - neigen) / 4);
+// Ritz pairs kept at a restart: the wanted ones, those already converged, and a share of the rest of the basis (option "eigh_keep_pct",
+// per cent of m - neigen; the restart cycle then has m - k new products)
+int keep_count(int m, int neigen, int nconv, int pct) {
+  int k = neigen + std::min(nconv, (m - neigen) / 2) + std::max(1, (m - neigen) * pct / 100);
   return std::max(1, std::min(k, m - 1));
 }
 
@@ -390,6 +392,27 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
     HIPCHK(hipStreamSynchronize(st));
     return HXV_OK;
   };
+  // (HXV_EIGH_TRACE only) the true projections of w = V[jt+1] on V[0..jt-2], measured and NOT removed: max |<v_b, w>| and where -- printed next
+  // to the estimate of the omega recurrence at every local step (how round 4 found the single-pass flaw of the cleaning steps)
+  auto measure_only = [&](int jt, double* mx, int* where) -> int {
+    const int nj = jt - 1;
+    *mx = 0.0;
+    *where = -1;
+    if (nj <= 0) return HXV_OK;
+    std::vector<double> cc(2 * (MAXCV + 1));
+    for (int g0 = 0; g0 < nj; g0 += JB) {
+      const int nb = std::min(JB, nj - g0);
+      hipLaunchKernelGGL(tr_mdot, dim3(g), dim3(256), 0, st, n, vec(g0), n, nb, vec(jt + 1), d_part);
+      hipLaunchKernelGGL(tr_colsum, dim3(1), dim3(256), 0, st, d_part, g, 2 * JB, 2 * nb, d_coef + 2 * g0, real ? 1 : 0);
+    }
+    HIPCHK(hipMemcpyAsync(cc.data(), d_coef, (size_t)2 * nj * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int i = 0; i < nj; ++i) {
+      const double a = std::sqrt(cc[2 * i] * cc[2 * i] + cc[2 * i + 1] * cc[2 * i + 1]) / nv[i];
+      if (a > *mx) *mx = a, *where = i;
+    }
+    return HXV_OK;
+  };
   auto norm2_of = [&](double2* x, double* out) -> int {
     hipLaunchKernelGGL(tr_scale_nrm, dim3(g), dim3(256), 0, st, n, x, 1.0, d_npart);
     hipLaunchKernelGGL(tr_colsum, dim3(1), dim3(256), 0, st, d_npart, g, 1, 1, d_nrm, 0);
@@ -484,6 +507,7 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
   bool closed = false;  // the Krylov space closed (invariant subspace): every returned pair is exact
   bool above = false;   // a check round stopped early: the lowest Ritz value minus its residual bound is already above `stop_above`
   const bool local_fused = lanczos_local_step_available(h);
+  const bool trace = getenv("HXV_EIGH_TRACE") != nullptr;
   auto trl = [&](int nlock, int nwant, uint64_t seed, double stop_above) -> int {
     above = false;
     const int ma = m - nlock;  // active basis size
@@ -522,9 +546,14 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
         // a step that is known in advance to need only the two local projections runs through the fused product: pass A
         // subtracts beta_j q_{j-1} and reduces alpha_j in its epilogue, one more pass subtracts alpha_j q_j and measures |w|
         // (not in the locking rounds: there every step also removes the locked eigenvectors, see gs_local)
-        const bool fused_local = local_fused && !h->eigh_measure_all && j > k && !force_full;
+        // (a FORCED step -- the second vector in a row to be cleaned against the whole basis -- takes its local step first, like any other:
+        //  one classical Gram-Schmidt pass over "H q_j" would measure the projection on an old vector v_b BEFORE beta_j q_{j-1} is taken
+        //  out, and q_{j-1} carries the very overlap with v_b that the step is there to stop -- the new vector would inherit it, the
+        //  estimates would say "clean", and a basis of more than ~30 vectors would lose a converged Ritz vector within a few cycles)
+        const bool forced = force_full && j > k && !h->eigh_measure_all;
+        const bool fused_local = local_fused && !h->eigh_measure_all && j > k;
         int rc;
-        double w2 = 0.0;
+        double w2 = 0.0, arrow2 = 0.0;  // arrow2: squared length of what the first step of a cycle takes out with the known coefficients
         if (fused_local) {
           double al = 0.0, nw = 0.0;
           rc = lanczos_local_step(h, real, av(j), nv[jt], av(j - 1), nv[jt - 1], t_at(j, j - 1), av(j + 1), nlock == 0, &al, &nw);
@@ -541,6 +570,23 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
           normalise_slot(jt);
           rc = real ? apply_slab_real(h, (const double*)av(j), (double*)av(j + 1), st) : apply_slab(h, av(j), av(j + 1), st);
           if (rc) return rc;
+          if (j == k && k > 0 && !h->eigh_measure_all) {
+            // First step of a cycle: H q_k couples to every kept Ritz vector with the KNOWN coefficient s_l (the arrow of T).  They are
+            // taken out first, with those coefficients, and the measured pass below then only finds what is left (rounding-size
+            // projections).  One classical pass over "H q_k" would instead measure a projection BEFORE the others are subtracted, and the
+            // kept Ritz vectors are orthogonal to each other only as far as the old basis was: the new vector would inherit
+            // sum_l s_l <y_b, y_l> against each of them -- above the estimates' starting level after a long cycle.
+            for (int l = 0; l < k; ++l) {
+              isel[l] = nlock + l;
+              csel[2 * l] = s_keep[l] / (nv[nlock + l] * nv[nlock + l]);
+              csel[2 * l + 1] = 0.0;
+              arrow2 += s_keep[l] * s_keep[l];
+            }
+            HIPCHK(hipMemcpyAsync(d_csel, csel.data(), (size_t)2 * k * sizeof(double), hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(d_isel, isel.data(), (size_t)k * sizeof(int), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(tr_maxpy, dim3(g), dim3(256), 0, st, n, V, n, k, d_isel, d_csel, av(j + 1), d_npart);
+            HIPCHK(hipStreamSynchronize(st));  // (csel / isel are host buffers the pass below reuses)
+          }
         }
         ++nmv;
         // Partial re-orthogonalisation (Simon 1984) in its thick-restart form: the loss of orthogonality of the next
@@ -549,9 +595,9 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
         // consecutive vectors.  Otherwise a step costs the two local projections.  (Option "eigh_measure_all" = 1
         // restores the round-1 behaviour: every projection measured at every step.)
         const bool first_after_restart = j == k;
-        bool full = h->eigh_measure_all || first_after_restart || force_full;
+        bool full = h->eigh_measure_all || first_after_restart;
         if (full) {
-          rc = gs_pass(jt, nlock, first_after_restart || force_full, &w2);
+          rc = gs_pass(jt, nlock, first_after_restart, &w2);
           ++n_full;
         } else if (fused_local) {
           ++n_local;
@@ -562,9 +608,10 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
         if (rc) return rc;
         t_at(j, j) = c[2 * jt];
         double c2sum = 0.0;
-        if (full)
+        if (full) {
           for (int t = 0; t < 2 * (jt + 1); ++t) c2sum += c[t] * c[t];
-        else
+          c2sum += arrow2;
+        } else
           c2sum = c[2 * jt] * c[2 * jt] + c[2 * jt + 1] * c[2 * jt + 1] + (j > k ? c[2 * (jt - 1)] * c[2 * (jt - 1)] + c[2 * (jt - 1) + 1] * c[2 * (jt - 1) + 1] : 0.0);
         if (!full)
           for (int b = 0; b < nlock; ++b) c2sum += c[2 * b] * c[2 * b] + c[2 * b + 1] * c[2 * b + 1];
@@ -607,7 +654,18 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
             om_next[jt] = noise;
             // sqrt(eps) would keep the EIGENVALUES at rounding level (Simon); the eigenvectors are handed to the Green's-function
             // stage, so the basis is kept orthogonal to 1e-12 instead and the returned vectors are orthonormalised once more at the end
-            if (maxom > 1e-12) {  // about to be lost: remove everything now, and again at the next step
+            if (trace) {
+              double mx = 0.0;
+              int wh = -1;
+              (void)measure_only(jt, &mx, &wh);
+              int we = -1;
+              double me = 0.0;
+              for (int b = 0; b < jt - 1; ++b)
+                if (std::fabs(om_next[b]) > me) me = std::fabs(om_next[b]), we = b;
+              fprintf(stderr, "[eigh]   j %d estimate max %.3e at %d | measured max %.3e at %d (relative to |w| %.3e) est there %.3e\n", j, me, we, mx / std::max(nrm, 1e-300), wh, nrm,
+                      wh >= 0 ? std::fabs(om_next[wh]) : 0.0);
+            }
+            if (maxom > 1e-12 || forced) {  // about to be lost: remove everything now, and again at the next step
               double w3 = 0.0;
               rc = gs_pass(jt, nlock, true, &w3);
               ++n_full;
@@ -646,6 +704,7 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
           beta_last = 0.0;
           break;
         }
+        if (trace) fprintf(stderr, "[eigh] it %d j %d jt %d %s%s alpha % .6e beta %.6e c2sum %.3e\n", it, j, jt, fused_local ? "fused " : "plain ", full ? "FULL" : "local", t_at(j, j), nrm, c2sum);
         if (j + 1 < ma) t_at(j + 1, j) = t_at(j, j + 1) = nrm;
         beta_last = nrm;
         nv[jt + 1] = nrm;  // left unnormalised: the next product (or whoever needs a unit vector) divides
@@ -656,6 +715,7 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
       if (!jacobi_eigh(meff, A, theta, S)) return fail(HXV_ERR_STATE, "hxv_eigh_lowest: projected eigenproblem did not converge");
       ne = std::min(nwant, meff);
       nconv = 0;
+      if (trace) fprintf(stderr, "[eigh] it %d restart: theta0 % .10e theta1 % .10e beta_last %.3e\n", it, theta[0], meff > 1 ? theta[1] : 0.0, beta_last);
       for (int i = 0; i < ne; ++i) {
         const double res = std::fabs(beta_last * S[(meff - 1) + (size_t)i * meff]);
         if (res <= tol * std::max(eps23, std::fabs(theta[i]))) ++nconv;
@@ -674,7 +734,7 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
         break;
       }
       if (nconv == ne || closed || it >= maxrestart) break;
-      k = keep_count(ma, nwant, nconv);
+      k = keep_count(ma, nwant, nconv, h->eigh_keep_pct);
       // Ritz vectors = (stored vectors) * diag(1/nv) * S
       Ssc.assign(S.begin(), S.begin() + (size_t)ma * k);
       for (int i = 0; i < k; ++i)

@@ -361,6 +361,7 @@ int hxv_get_diag(const hxv_handle *h, double *diag);
  *   the exchanges that had to copy.
  * Scheduling knobs (results unchanged): "pair_rows" -1|0|1 [-1 = by sector size: pass B runs the two row groups of a 128-byte line
  *   back to back], "job_max_blocks" [32: pass A as jobs only up to this many blocks per spin], "fold_nd" 0|1 [1: spH0nd inside pass A],
+ *   "eigh_keep_pct" 5..80 [20: share of the Krylov basis beyond the wanted pairs that a thick restart of hxv_eigh_lowest keeps],
  *   "exchange_overlap" 0|1 [0: exchange mode 2 of a split sector runs diagonal + up hops on a second stream WHILE the two transposes and the
  *   panel product are under way (the reference's order, ED_HAMILTONIAN_SPARSE_HxV.f90:250-296) and adds the dw part at the end; plain
  *   products only; 32 B per local state more HBM traffic than the fused form, for hiding pass A behind the links],

@@ -12,6 +12,8 @@ sec = hxv.HxvSector.from_model(m, nup, ndw)
 sec.set_option("eigh_measure_all", int(os.environ.get("MEASURE_ALL", 0)))
 sec.set_option("lanczos_fused", int(os.environ.get("FUSED", 1)))
 sec.set_option("real_vectors", int(os.environ.get("REAL_VECTORS", 1)))
+if "KEEP" in os.environ:
+    sec.set_option("eigh_keep_pct", int(os.environ["KEEP"]))
 neigen, ncv = int(os.environ.get("NEIGEN", 2)), int(os.environ.get("NCV", 20))
 for rep in range(int(os.environ.get("REPS", 1))):  # (a second run finds the Krylov basis in the engine's buffer cache)
     t = time.time()

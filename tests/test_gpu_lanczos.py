@@ -802,3 +802,47 @@ def test_library_owned_device_vectors_and_pcie_counters(built):
     assert st["h2d_bytes"] == 48 * sec.Dim and st["d2h_bytes"] == 32 * sec.Dim
     assert L.hxv_vector_free(sec._h, d) == 0
     sec.close()
+
+
+_C2E = {}
+
+
+def _c2e_matrix():
+    """oracle matrix of C2 with bath levels (Dim = 853 776) and its 8 lowest eigenvalues from ARPACK, built once per session"""
+    if not _C2E:
+        import scipy.sparse.linalg as sla
+        from hxv import models
+        from oracle.oracle import OracleSector
+        from helpers_matrix import oracle_full_matrix
+
+        _C2E["model"] = models.hm_1dchain(eps_bath=[0.3, 0.6])
+        _C2E["H"] = oracle_full_matrix(OracleSector(_C2E["model"], 6, 6))
+        _C2E["ref"] = np.sort(sla.eigsh(_C2E["H"], k=8, which="SA", ncv=48, tol=1e-12)[0])
+    return _C2E["model"], _C2E["H"], _C2E["ref"]
+
+
+@pytest.mark.parametrize("neig,ncv,real_vectors,fused", [(4, 40, 1, 1), (4, 40, 0, 1), (4, 40, 1, 0), (2, 33, 1, 1), (6, 60, 1, 1), (8, 64, 0, 1)])
+def test_eigh_lowest_large_krylov_basis(built, neig, ncv, real_vectors, fused):
+    """Nblock = lanc_ncv_factor * max(Neigen, lanc_nstates_sector) (ED_DIAG.f90:96) passes 30 as soon as a run asks for more than two states
+    per sector (finite temperature).  Round 4 found that cycles of more than ~30 steps LOST the converged Ritz vectors (energies of 1e25
+    reported as converged): the forced second cleaning step and the first step of a cycle each made ONE classical Gram-Schmidt pass over
+    "H q", which measures a projection before the local / arrow terms are taken out -- the new vector inherited the overlap the step was
+    there to remove while the estimates said "clean".  Eigenvalues against ARPACK on the oracle's matrix (C2, Dim = 853 776), residuals,
+    orthonormality, and the same answer as the measure-everything mode."""
+    import hxv
+
+    m, H, ref = _c2e_matrix()
+    sec = hxv.HxvSector.from_model(m, 6, 6)
+    sec.set_option("real_vectors", real_vectors)
+    sec.set_option("lanczos_fused", fused)
+    ev, X, nconv, nmv = sec.eigh_lowest(neig, ncv, 512, 0.0)
+    Xh = X.cpu().numpy().T
+    assert nconv == neig
+    assert np.abs(ev - ref[:neig]).max() < 1e-9, (ev, ref)
+    assert np.linalg.norm(H @ Xh - Xh * ev, axis=0).max() < 1e-8
+    assert np.abs(Xh.conj().T @ Xh - np.eye(neig)).max() < 1e-9
+    assert sec.get_option("eigh_last_local_passes") > 2 * sec.get_option("eigh_last_full_passes")   # still mostly local steps
+    sec.set_option("eigh_measure_all", 1)
+    ev_all, _, nconv_all, _ = sec.eigh_lowest(neig, ncv, 512, 0.0, want_vectors=False)
+    assert nconv_all == neig and np.abs(ev_all - ev).max() < 1e-10
+    sec.close()

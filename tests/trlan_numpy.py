@@ -26,8 +26,8 @@ def start_vector(dim: int, seed: int = 0x5EED5EED) -> np.ndarray:
 
 
 def keep_count(m: int, neigen: int, nconv: int) -> int:
-    """Ritz vectors kept at a restart (same rule as csrc/hxv_eigh.hip)."""
-    k = neigen + min(nconv, (m - neigen) // 2) + max(1, (m - neigen) // 4)
+    """Ritz vectors kept at a restart (the rule of csrc/hxv_eigh.hip at its default eigh_keep_pct = 20)."""
+    k = neigen + min(nconv, (m - neigen) // 2) + max(1, (m - neigen) * 20 // 100)
     return max(1, min(k, m - 1))
 
 
