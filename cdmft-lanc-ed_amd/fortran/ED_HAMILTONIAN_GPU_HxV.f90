@@ -37,6 +37,10 @@ module ED_HAMILTONIAN_GPU_HXV
   !the reference's own stored matrices handed over (spH0ups(1), spH0dws(1), spH0d, spH0nd flattened to CSR)
   public :: gpu_build_Hv_sector_from_csr
   public :: gpu_set_nonlocal_csr
+  !what the engine built for the open sector, in the layout gpu_build_Hv_sector_from_csr takes (parity against spH0ups / spH0dws / spH0d)
+  public :: gpu_sector_nnz
+  public :: gpu_get_sector_csr
+  public :: gpu_get_sector_diag
 
   !> A vector that lives on the device, in the layout of the sector it was made for.  Opaque: pass it back to the gpu_* routines.
   type :: gpu_vector
@@ -159,6 +163,24 @@ module ED_HAMILTONIAN_GPU_HXV
        integer(c_int32_t),intent(in)        :: cols(*)
        complex(c_double_complex),intent(in) :: vals(*)
      end function hxv_set_nonlocal_csr
+     integer(c_int64_t) function hxv_nnz(h,which) bind(C,name="hxv_nnz")
+       import :: c_int64_t, c_int32_t, c_ptr
+       type(c_ptr),value        :: h
+       integer(c_int32_t),value :: which
+     end function hxv_nnz
+     integer(c_int) function hxv_get_csr(h,which,rowptr,cols,vals) bind(C,name="hxv_get_csr")
+       import :: c_int, c_int32_t, c_int64_t, c_ptr, c_double_complex
+       type(c_ptr),value         :: h
+       integer(c_int32_t),value  :: which
+       integer(c_int64_t)        :: rowptr(*)
+       integer(c_int32_t)        :: cols(*)
+       complex(c_double_complex) :: vals(*)
+     end function hxv_get_csr
+     integer(c_int) function hxv_get_diag(h,diag) bind(C,name="hxv_get_diag")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr),value :: h
+       real(c_double)    :: diag(*)
+     end function hxv_get_diag
      integer(c_int) function hxv_vector_alloc(h,d_vec) bind(C,name="hxv_vector_alloc")
        import :: c_int, c_ptr
        type(c_ptr),value       :: h
@@ -600,6 +622,39 @@ contains
          int(dw_rowptr,c_int64_t),int(dw_cols,c_int32_t),dw_vals,diag,int(MpiRank,c_int32_t),int(MpiSize,c_int32_t),int(dev,c_int32_t),handle),&
          "gpu_build_Hv_sector_from_csr")
   end subroutine gpu_build_Hv_sector_from_csr
+
+  !> stored elements of H_up (which=1) / H_dw (which=2) of the open sector
+  function gpu_sector_nnz(which) result(nnz)
+    integer,intent(in) :: which
+    integer(8)         :: nnz
+    if(.not.c_associated(handle))stop "gpu_sector_nnz ERROR: Hsector NOT set"
+    nnz=hxv_nnz(handle,int(which-1,c_int32_t))
+  end function gpu_sector_nnz
+
+  !> H_up (which=1) / H_dw (which=2) of the open sector as the engine built it, flattened like spH0ups(1) / spH0dws(1) would be for
+  !! gpu_build_Hv_sector_from_csr: rowptr(DimSigma+1) 0-based offsets, cols 1-based, vals complex
+  subroutine gpu_get_sector_csr(which,rowptr,cols,vals)
+    integer,intent(in)       :: which
+    integer(8),intent(out)   :: rowptr(:)
+    integer,intent(out)      :: cols(:)
+    complex(8),intent(out)   :: vals(:)
+    integer(c_int64_t),allocatable :: rp(:)
+    integer(c_int32_t),allocatable :: cl(:)
+    if(.not.c_associated(handle))stop "gpu_get_sector_csr ERROR: Hsector NOT set"
+    if(int(size(cols),8)<hxv_nnz(handle,int(which-1,c_int32_t)).or.size(vals)<size(cols))stop "gpu_get_sector_csr ERROR: cols / vals too short"
+    allocate(rp(size(rowptr)),cl(size(cols)))
+    call check(hxv_get_csr(handle,int(which-1,c_int32_t),rp,cl,vals),"gpu_get_sector_csr")
+    rowptr=rp; cols=cl
+    deallocate(rp,cl)
+  end subroutine gpu_get_sector_csr
+
+  !> the (real) diagonal of the open sector, local rows -- spH0d's values
+  subroutine gpu_get_sector_diag(diag)
+    real(8),intent(out) :: diag(:)
+    if(.not.c_associated(handle))stop "gpu_get_sector_diag ERROR: Hsector NOT set"
+    if(int(size(diag),c_int64_t)/=hxv_vecdim(handle))stop "gpu_get_sector_diag ERROR: size(diag) /= vecDim"
+    call check(hxv_get_diag(handle,diag),"gpu_get_sector_diag")
+  end subroutine gpu_get_sector_diag
 
   !> spH0nd (Jx, Jp; ED_VARS_GLOBAL.f90:145, sparse/H_non_local.f90:23-98) of a sector opened from stored matrices: the LOCAL rows with the
   !! reference's GLOBAL 1-based columns, flattened like the others.

@@ -18,6 +18,7 @@ program hxv_fortran_demo
   call plaquette()
   call chain_ns12()
   call gf_channel_on_device()
+  call stored_matrices()
 
 contains
 
@@ -238,6 +239,54 @@ contains
     call gpu_free_vector(gs)
     deallocate(psi,vvinit,map6,map7,pos7)
   end subroutine gf_channel_on_device
+
+  !> The engine fed with STORED matrices, as a maintainer would hand over spH0ups(1), spH0dws(1), spH0d (gpu_build_Hv_sector_from_csr): here the
+  !! matrices come from a sector the engine built from the model itself (gpu_get_sector_csr / _diag), the C2-like chain, sector (6,6); the
+  !! product through the stored matrices must equal the product of the model-built sector.
+  subroutine stored_matrices()
+    integer,parameter :: Nlat=4,Norb=1,Nspin=1,Nbath=2
+    complex(8) :: impHloc(Nlat,Nlat,Nspin,Nspin,Norb,Norb),Hbath(Nlat,Nlat,Nspin,Nspin,Norb,Norb,Nbath)
+    real(8)    :: Vbath(Nlat,Nspin,Norb,Nbath),Uloc(5),eps(Nbath)
+    complex(8),allocatable :: v(:),hv1(:),hv2(:),uv(:),dv(:),dg(:)
+    real(8),allocatable    :: diag(:)
+    integer(8),allocatable :: urp(:),drp(:)
+    integer,allocatable    :: ucl(:),dcl(:)
+    integer    :: dim,i,ib,DimUp,DimDw
+    integer(8) :: nu,nd
+    impHloc=(0d0,0d0); Hbath=(0d0,0d0)
+    do i=1,Nlat
+       if(i>1)impHloc(i,i-1,1,1,1,1)=-0.25d0
+       if(i<Nlat)impHloc(i,i+1,1,1,1,1)=-0.25d0
+    enddo
+    eps=[0.3d0,0.6d0]
+    do ib=1,Nbath
+       Hbath(:,:,:,:,:,:,ib)=-abs(impHloc)
+       do i=1,Nlat
+          Hbath(i,i,1,1,1,1,ib)=eps(ib)
+       enddo
+    enddo
+    Vbath=1d0/sqrt(2d0)
+    Uloc=0d0; Uloc(1)=2d0
+    DimUp=924; DimDw=924
+    call gpu_build_Hv_sector(Nlat,Norb,Nspin,Nbath,6,6,impHloc,Hbath,Vbath,Uloc,0d0,0d0,0d0,0d0,0d0,.true.,0,1)
+    dim=gpu_vecDim_Hv_sector()
+    nu=gpu_sector_nnz(1); nd=gpu_sector_nnz(2)
+    allocate(v(dim),hv1(dim),hv2(dim),diag(dim),dg(dim),urp(DimUp+1),drp(DimDw+1),ucl(nu),dcl(nd),uv(nu),dv(nd))
+    call gpu_get_sector_csr(1,urp,ucl,uv)
+    call gpu_get_sector_csr(2,drp,dcl,dv)
+    call gpu_get_sector_diag(diag)
+    do i=1,dim
+       v(i)=cmplx(sin(0.37d0*(i-1)+0.11d0),cos(0.23d0*(i-1)+0.05d0),8)
+    enddo
+    call gpuMatVec_main(dim,v,hv1)
+    call gpu_delete_Hv_sector()
+    dg=cmplx(diag,0d0,8)
+    call gpu_build_Hv_sector_from_csr(DimUp,DimDw,urp,ucl,uv,drp,dcl,dv,dg,0,1)
+    call gpuMatVec_main(dim,v,hv2)
+    call gpu_delete_Hv_sector()
+    write(*,"(A,2I10,A,ES12.4,A,ES12.4)")"stored matrices: nnz(H_up),nnz(H_dw)=",nu,nd," max|Hv(csr)-Hv(model)|=",maxval(abs(hv2-hv1))," max|Hv|=",maxval(abs(hv1))
+    deallocate(v,hv1,hv2,diag,dg,urp,drp,ucl,dcl,uv,dv)
+  end subroutine stored_matrices
 
   !> lowest eigenvalue of the Lanczos tridiagonal by bisection (Sturm count); blanc(1) unused
   function lowest_tridiag(a,b) result(e)

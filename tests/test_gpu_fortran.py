@@ -123,3 +123,18 @@ def test_fortran_device_resident_green_function_channel(built):
     assert abs(float(h.group(4)) - float(h.group(5))) < 1e-9
     hb = re.search(r"GF host-array channel: PCIe bytes \(h2d,d2h\) channel-sector=\s*(\d+)\s+(\d+)", txt)
     assert int(hb.group(1)) == 792 * 924 * 16                                  # the host start vector of sector (7,6), once
+
+
+def test_fortran_stored_matrices_binding(built):
+    """gpu_build_Hv_sector_from_csr (the reference's spH0ups(1) / spH0dws(1) / spH0d handed over flattened) from the Fortran host: the
+    matrices come out of a model-built sector through gpu_get_sector_csr / _diag, go back in through the binding, and the two products
+    agree; nnz(H_up) = 8 568 is the survey's count for this model."""
+    exe = built.build_fortran()
+    if exe is None:
+        pytest.skip("flang not available")
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    m = re.search(r"stored matrices: nnz\(H_up\),nnz\(H_dw\)=\s*(\d+)\s+(\d+)\s*max\|Hv\(csr\)-Hv\(model\)\|=\s*([-\d.Ee+]+)\s*max\|Hv\|=\s*([-\d.Ee+]+)", out.stdout)
+    assert m, out.stdout
+    assert int(m.group(1)) == 8568 and int(m.group(2)) == 8568
+    assert float(m.group(3)) <= 1e-13 * float(m.group(4))

@@ -105,3 +105,40 @@ def test_ground_state_energy_at_headline_size(built, name, driver):
     del vec, hv
     sec.close()
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("exchange,transport", [("allgather", "rccl"), ("alltoall", "local"), ("halo", "local")])
+def test_ground_state_energy_at_headline_size_on_four_ranks(built, monkeypatch, exchange, transport):
+    """The same C3 sector split along DimDw over FOUR ranks (thread ranks sharing the one GPU; once through the engine's RCCL branches
+    with the test double of tests/rccl_double): hxv_lanczos_eigh on slabs -- exchanges in place, all-reduced sums, real vectors -- returns
+    the fixture's E0 within 1e-10 on every rank, and the slabs of the eigenvector assemble to a unit vector."""
+    import hxv
+    from hxv import models
+
+    if transport == "rccl":
+        monkeypatch.setenv("HXV_RCCL_LIB", str(built.build_rccl_double()))
+    g = GOLD["C3"]
+    m = models.hm_2dsquare()
+    hxv.pool_trim()
+    hxv.set_exchange_default(exchange)
+
+    def rank(r, group):
+        sec = hxv.HxvSector.from_model(m, 8, 8, rank=r, nranks=4)
+        assert sec.exchange_mode == exchange
+        group.join(sec)
+        e0, vec, nit = sec.lanczos_eigh(nitermax=512, threshold=1e-13, native=True)
+        n2 = float(vec.abs().pow(2).sum().item())
+        real = sec.get_option("lanczos_real_last")
+        del vec
+        sec.close()
+        return e0, n2, nit, real
+
+    try:
+        res = hxv.run_ranks(4, rank, transport=transport)
+    finally:
+        hxv.set_exchange_default("allgather")
+        hxv.pool_trim()
+    for e0, _, nit, real in res:
+        assert abs(e0 - g["E0"]) <= 1e-10, (e0, g["E0"], nit)
+        assert real == 1                                       # (H is real: the slabs on the links are real)
+    assert abs(sum(n2 for _, n2, _, _ in res) - 1.0) < 1e-10
