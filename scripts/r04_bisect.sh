@@ -1,4 +1,6 @@
 #!/bin/bash
+# (the trees build_dbg/wt_<sha> are `git archive <sha> cdmft-lanc-ed_amd include __graft_entry__.py | tar -x` extractions, each built with its own
+#  __graft_entry__.build_engine(); build_dbg/ is scratch and git-ignored)
 # round 4, item 1a: which commit slowed the real-vector Lanczos iteration (3.70 -> 4.00 ms)?  One process per extracted tree.
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
