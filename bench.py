@@ -10,7 +10,8 @@ With N>1 ranks the sector is split along DimDw exactly like the reference (ED_HA
 each step exchanges the slabs over RCCL THROUGH THE C-ABI (hxv_comm_unique_id -> broadcast -> hxv_comm_init ->
 hxv_apply_device_slab: what a Fortran rank of the reference would run; --exchange allgather [default] | halo | alltoall = the
 reference's own two transposes) and every rank computes its slab (strong scaling: the sector is fixed).  --backend gloo goes
-through torch.distributed instead (hxv/distributed.py).  value = algorithmic GB/s of the whole job = 32 B x Dim / step time
+through torch.distributed instead (hxv/distributed.py: the rehearsal twin).  Before the warm-up ONE product of a split run is checked on every
+rank against the unsplit sector (1e-13; "checked" / "check_rel_err" in the line; the run aborts otherwise; --no-check skips).  value = algorithmic GB/s of the whole job = 32 B x Dim / step time
 (read v once + write Hv once per basis state).
 
 Rank 0 prints ONE JSON line.  It also carries
