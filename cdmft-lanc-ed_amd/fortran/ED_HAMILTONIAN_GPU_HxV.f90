@@ -30,6 +30,7 @@ module ED_HAMILTONIAN_GPU_HXV
   public :: gpu_keep_sector
   public :: gpu_apply_ladder
   public :: gpu_sp_lanc_tridiag_dev
+  public :: gpu_sp_lanc_tridiag_pair_dev
   public :: gpu_vector_to_host
   public :: gpu_vector_from_host
   public :: gpu_free_vector
@@ -216,6 +217,15 @@ module ED_HAMILTONIAN_GPU_HXV
        real(c_double),value     :: threshold
        integer(c_int32_t)       :: nsteps
      end function hxv_lanczos_tridiag
+     integer(c_int) function hxv_lanczos_tridiag_pair(h,d_vin_a,d_vin_b,nlanc,alanc_a,blanc_a,alanc_b,blanc_b,threshold,nsteps_a,nsteps_b) &
+          bind(C,name="hxv_lanczos_tridiag_pair")
+       import :: c_int, c_int32_t, c_ptr, c_double
+       type(c_ptr),value        :: h,d_vin_a,d_vin_b
+       integer(c_int32_t),value :: nlanc
+       real(c_double)           :: alanc_a(*),blanc_a(*),alanc_b(*),blanc_b(*)
+       real(c_double),value     :: threshold
+       integer(c_int32_t)       :: nsteps_a,nsteps_b
+     end function hxv_lanczos_tridiag_pair
      integer(c_int) function hxv_apply_ladder_axpy(from,to,orbital,spin,create,coef_re,coef_im,accumulate,d_psi,d_out,norm2) &
           bind(C,name="hxv_apply_ladder_axpy")
        import :: c_int, c_int32_t, c_ptr, c_double
@@ -560,6 +570,23 @@ contains
     thr=1d-12; if(present(threshold))thr=threshold
     call check(hxv_lanczos_tridiag(handle,vin%d,int(size(alanc),c_int32_t),alanc,blanc,thr,nsteps),"gpu_sp_lanc_tridiag_dev")
   end subroutine gpu_sp_lanc_tridiag_dev
+
+  !> TWO channels of the same sector on one product (real H; gpu_sp_lanc_tridiag_pair with start vectors that are on the device already):
+  !! e.g. c^dagger_{i,up}|gs> and c^dagger_{j,up}|gs> of one ground state -- both real, both in the open sector.
+  subroutine gpu_sp_lanc_tridiag_pair_dev(vin_a,vin_b,alanc_a,blanc_a,alanc_b,blanc_b,threshold)
+    type(gpu_vector),intent(in) :: vin_a,vin_b
+    real(8),intent(inout)       :: alanc_a(:),blanc_a(:),alanc_b(:),blanc_b(:)
+    real(8),intent(in),optional :: threshold
+    real(8)                     :: thr
+    integer(c_int32_t)          :: na,nb
+    if(.not.c_associated(handle))stop "gpu_sp_lanc_tridiag_pair_dev ERROR: Hsector NOT set"
+    if(.not.(c_associated(vin_a%sector,handle).and.c_associated(vin_b%sector,handle)))&
+         stop "gpu_sp_lanc_tridiag_pair_dev ERROR: the start vectors do not belong to the open sector"
+    if(size(alanc_a)/=size(alanc_b))stop "gpu_sp_lanc_tridiag_pair_dev ERROR: the two channels need equally long alanc/blanc"
+    thr=1d-12; if(present(threshold))thr=threshold
+    call check(hxv_lanczos_tridiag_pair(handle,vin_a%d,vin_b%d,int(size(alanc_a),c_int32_t),alanc_a,blanc_a,alanc_b,blanc_b,thr,na,nb),&
+         "gpu_sp_lanc_tridiag_pair_dev")
+  end subroutine gpu_sp_lanc_tridiag_pair_dev
 
   !> the vector in the reference's host layout (this rank's slab), when it is wanted there after all (e.g. state_list of ED_DIAG)
   subroutine gpu_vector_to_host(vect,v)

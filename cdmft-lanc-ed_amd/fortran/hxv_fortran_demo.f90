@@ -202,6 +202,18 @@ contains
     call gpu_pcie_bytes(h2d_b,d2h_b)
     write(*,"(A,F16.10,A,ES24.16,A,4I12)")"GF device channel: E0=",egs," norm2=",norm2," PCIe bytes (h2d,d2h) gs-sector, channel-sector=",&
          h2d_a,d2h_a,h2d_b,d2h_b
+    !two channels at once: c^dagger_{1,up}|gs> and c^dagger_{2,up}|gs> as Re / Im of one complex Lanczos vector; channel a must reproduce a1, b1
+    block
+      type(gpu_vector) :: v2
+      real(8) :: n2b,pa(nl),pb(nl),qa(nl),qb(nl)
+      call gpu_apply_ladder(gs,2,ispin,.true.,v2,n2b)
+      pa=0d0; pb=0d0; qa=0d0; qb=0d0
+      call gpu_sp_lanc_tridiag_pair_dev(vv,v2,pa,pb,qa,qb)
+      call gpu_pcie_bytes(h2d_b,d2h_b)
+      write(*,"(A,ES12.4,A,ES12.4,A,2F16.10,A,2I12)")"GF device pair: max|alanc_a-single|(8)=",maxval(abs(pa(1:8)-a1(1:8)))," max|blanc_a-single|(8)=",maxval(abs(pb(1:8)-b1(1:8))),&
+           " lowest Ritz values a,b=",lowest_tridiag(pa,pb),lowest_tridiag(qa,qb)," PCIe bytes=",h2d_b,d2h_b
+      call gpu_free_vector(v2)
+    end block
     call gpu_free_vector(vv)
     !--- the reference's way: ground state on the host, c^dagger by the master's loop, host start vector
     allocate(psi(dimA),vvinit(dimB))

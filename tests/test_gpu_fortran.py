@@ -121,6 +121,11 @@ def test_fortran_device_resident_green_function_channel(built):
     assert h, txt
     assert float(h.group(1)) < 1e-12 and float(h.group(2)) < 1e-10 and float(h.group(3)) < 1e-10
     assert abs(float(h.group(4)) - float(h.group(5))) < 1e-9
+    pr = re.search(r"GF device pair: max\|alanc_a-single\|\(8\)=\s*([-\d.Ee+]+)\s*max\|blanc_a-single\|\(8\)=\s*([-\d.Ee+]+)\s*lowest Ritz values a,b=\s*([-\d.Ee+]+)\s+([-\d.Ee+]+)"
+                   r"\s*PCIe bytes=\s*(\d+)\s+(\d+)", txt)
+    assert pr, txt                                                             # gpu_sp_lanc_tridiag_pair_dev: two device channels on one product
+    assert float(pr.group(1)) < 1e-10 and float(pr.group(2)) < 1e-10 and abs(float(pr.group(3)) - float(h.group(4))) < 1e-9
+    assert int(pr.group(5)) == 0 and int(pr.group(6)) == 0 and float(pr.group(4)) < -5.0
     hb = re.search(r"GF host-array channel: PCIe bytes \(h2d,d2h\) channel-sector=\s*(\d+)\s+(\d+)", txt)
     assert int(hb.group(1)) == 792 * 924 * 16                                  # the host start vector of sector (7,6), once
 
