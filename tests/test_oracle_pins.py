@@ -161,3 +161,34 @@ def test_lanczos_tridiag_reproduces_dense_ground_state():
     a, b = s.lanc_tridiag(v / np.linalg.norm(v), 120)
     T = np.diag(a) + np.diag(b[1:], 1) + np.diag(b[1:], -1)
     assert abs(np.linalg.eigvalsh(T)[0] - e0) < 1e-10
+
+
+@pytest.mark.slow
+def test_fullsize_fixture_first_step_against_the_oracle():
+    """tests/golden/fullsize_e0.json (scripts/make_golden_fullsize.py) is what the GPU suite pins the drivers to at the headline size.  Here, on
+    the CPU and in under a minute: its internal consistency (lowest eigenvalue of the tridiagonal = the recorded E0) and its FIRST Lanczos step
+    redone from scratch with ONE product of the oracle's spMatVec_mpi_main at C3 (Dim = 165 636 900): alanc(1) = <v|H|v>, blanc(2) = |Hv - alanc(1) v|."""
+    from scipy.linalg import eigh_tridiagonal
+
+    gold = json.loads((Path(__file__).parent / "golden" / "fullsize_e0.json").read_text())
+    for name in ("C3", "C4"):
+        g = gold[name]
+        a, b = np.array(g["alanc"]), np.array(g["blanc"])
+        assert len(a) == g["iterations"] and b[0] == 0.0 and (b[1:] > 0).all()
+        e0 = eigh_tridiagonal(a, b[1:], select="i", select_range=(0, 0))[0][0]
+        assert abs(e0 - g["E0"]) < 1e-12
+    g = gold["C3"]
+    m = models.hm_2dsquare()
+    assert m.name == g["model"]
+    P = 8
+    v = models.deterministic_vector(g["Dim"])
+    nrm = np.sqrt(np.vdot(v, v).real)
+    assert abs(nrm - g["start_norm"]) < 1e-9 * nrm
+    v /= nrm
+    hv, secs = spMatVec_mpi_main(m, 8, 8, P, v)
+    for s in secs:
+        s.close()
+    alpha = np.vdot(v, hv).real
+    hv -= alpha * v
+    beta = np.sqrt(np.vdot(hv, hv).real)
+    assert abs(alpha - g["alanc"][0]) < 1e-11 * abs(alpha) and abs(beta - g["blanc"][1]) < 1e-11 * beta
