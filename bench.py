@@ -131,6 +131,10 @@ def main():
                     help="one GPU, launched through torch.distributed.run with ONE rank: run exactly the calls of the N>1 path "
                          "(process group on RCCL, hxv_comm_unique_id -> broadcast -> hxv_comm_init -> hxv_slab_home -> hxv_apply_device_slab, "
                          "barrier, max over ranks) on a one-rank communicator")
+    ap.add_argument("--capi", action="store_true",
+                    help="N>1 with --backend gloo: keep the C-ABI exchange (hxv_comm_init + hxv_apply_device_slab) for the data path and use gloo "
+                         "for the control plane only -- with HXV_RCCL_LIB pointing at tests/rccl_double/_build/librccl_double_mp.so this is how N "
+                         "processes on ONE GPU rehearse the driver's launch line through the engine's RCCL branches")
     ap.add_argument("--no-check", action="store_true", help="N>1: skip the one checked product before the warm-up (split vs unsplit product on every rank)")
     ap.add_argument("--check", action="store_true", help="(kept for old command lines: the check is the default now)")
     args = ap.parse_args()
@@ -174,7 +178,7 @@ def main():
     # N>1 on RCCL (the default): the exchange runs behind the C-ABI, exactly what a Fortran rank of the reference would call
     # (hxv_comm_unique_id on rank 0 -> the host program's own broadcast -> hxv_comm_init -> hxv_apply_device_slab), for all three
     # exchanges.  --backend gloo (CPU rendezvous, rehearsals only) goes through the torch twin hxv/distributed.py instead.
-    capi_exchange = multi and not by_sector and args.backend == "nccl"
+    capi_exchange = multi and not by_sector and (args.backend == "nccl" or args.capi)
     twin = multi and not by_sector and not capi_exchange
     if multi and not by_sector and args.exchange != "allgather":
         hxv.set_exchange_default(args.exchange if capi_exchange or args.exchange == "halo" else "allgather")   # layout chosen when the sector is opened
@@ -279,7 +283,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if multi:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_step = dt / args.steps * 1e3

@@ -108,7 +108,7 @@ int hxv_comm_free(hxv_handle *h);
  * offsets, the drivers' all-reduces, the collective error agreement -- is executed with several ranks by the second
  * transport below, which shares that code; the RCCL call sites themselves (counts, offsets and pointers of the grouped
  * ncclSend / ncclRecv, the in-place ncclAllGather, the ncclMax agreement) run with 2-4 ranks against a TEST double of RCCL's ten entry
- * points (tests/rccl_double, thread ranks of one process): the environment variable HXV_RCCL_LIB, read by hxv_comm_unique_id /
+ * points (tests/rccl_double: one for thread ranks of one process, one for separate processes on one GPU): the environment variable HXV_RCCL_LIB, read by hxv_comm_unique_id /
  * hxv_comm_init, names the library to load instead of the system's librccl (a communicator keeps the library it was made with).
  * THREAD RANKS: the nranks handles of a sector live in ONE process, one host thread per rank (same GPU or different GPUs of
  * the node); slabs travel by device-to-device copies ordered with HIP events, scalars through host memory.  Create the group

@@ -186,3 +186,31 @@ def test_bench_rehearses_the_multi_gpu_calls_with_one_rank(built, exchange):
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["roofline"]["achieved"] > 0
     assert line["checked"] is True and line["check_rel_err"] <= 1e-13 and "C-ABI" in line["config"]["transport"]
     assert line["roofline"]["kernel_ms"] > 0 and line["roofline"]["slab_product_ms_on_stream"] >= line["roofline"]["kernel_ms"] * 0.99
+
+
+@pytest.mark.parametrize("exchange,nproc", [("allgather", 2), ("halo", 3), ("alltoall", 2)])
+def test_bench_n_processes_on_one_gpu_through_the_rccl_branches(built, exchange, nproc):
+    """The driver's launch line -- `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`, one PROCESS per rank -- on a one-GPU
+    box: librccl refuses several ranks on one device, so HXV_RCCL_LIB points the engine's RCCL entry points at the process double of
+    tests/rccl_double (shared-memory staging) and gloo carries the control plane (`--capi --backend gloo`).  Everything else is the N > 1
+    path of bench.py: id broadcast, hxv_comm_init per process, hxv_slab_home, the checked product against the unsplit sector on every
+    rank, warm-up, timed steps, max over ranks, the roofline leg through hxv_time_apply_slab."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HXV_RCCL_LIB=str(built.build_rccl_double_mp()))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    port = {"allgather": "29581", "halo": "29582", "alltoall": "29583"}[exchange]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1", "--master-port", port,
+                        os.path.join(root, "bench.py"), "--gpus", str(nproc), "--backend", "gloo", "--capi", "--workload", "C2", "--steps", "3", "--warmup", "1",
+                        "--exchange", exchange], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == nproc and line["value"] > 0 and line["scaling"] == "strong"
+    assert line["checked"] is True and line["check_rel_err"] <= 1e-13 and "C-ABI" in line["config"]["transport"]
+    assert line["config"]["exchange"] == exchange and line["config"]["exchange_ingest_bytes_per_gpu"] > 0
+    assert line["roofline"]["kernel_ms"] > 0
