@@ -410,10 +410,15 @@ int hxv_time_apply(hxv_handle* h, const void* d_v_full, void* d_hv_local, int32_
 }
 
 // ---- device vectors owned by the library: what a host program without a HIP binding of its own (the Fortran glue) keeps between calls ----
-int hxv_vector_alloc(hxv_handle* h, void** d_vec) {
-  if (!h || !d_vec) return fail(HXV_ERR_ARG, "hxv_vector_alloc: NULL argument");
+int hxv_vector_alloc_many(hxv_handle* h, int32_t count, void** d_vec);
+
+int hxv_vector_alloc(hxv_handle* h, void** d_vec) { return hxv_vector_alloc_many(h, 1, d_vec); }
+
+// `count` local vectors in ONE allocation, consecutive (hxv_localvec_elems() elements apart): what hxv_eigh_lowest writes its eigenvectors to
+int hxv_vector_alloc_many(hxv_handle* h, int32_t count, void** d_vec) {
+  if (!h || !d_vec || count < 1) return fail(HXV_ERR_ARG, "hxv_vector_alloc: bad argument");
   HIPCHK(hipSetDevice(h->device));
-  const size_t bytes = (size_t)h->host.pitch * std::max(h->host.qdw, 1) * sizeof(double2);
+  const size_t bytes = (size_t)count * (size_t)h->host.pitch * std::max(h->host.qdw, 1) * sizeof(double2);
   void* p = nullptr;
   HIPCHK(pool_alloc(h->device, bytes, &p));
   HIPCHK(hipMemsetAsync(p, 0, bytes, h->stream));   // (pad rows must be zero; on the handle's stream, like every other fill)

@@ -27,6 +27,7 @@ module ED_HAMILTONIAN_GPU_HXV
   !device-resident Green's-function pipeline (nothing Dim-sized crosses PCIe): see the block comment above gpu_sp_lanc_eigh_dev
   public :: gpu_vector
   public :: gpu_sp_lanc_eigh_dev
+  public :: gpu_sp_eigh_dev
   public :: gpu_keep_sector
   public :: gpu_apply_ladder
   public :: gpu_sp_lanc_tridiag_dev
@@ -48,6 +49,7 @@ module ED_HAMILTONIAN_GPU_HXV
      type(c_ptr) :: d      = c_null_ptr    !device buffer (include/hxv.h: hxv_vector_alloc)
      type(c_ptr) :: sector = c_null_ptr    !the sector (engine handle) it belongs to
      logical     :: owns_sector = .false.  !gpu_keep_sector: that sector stays open for this vector until gpu_free_vector
+     logical     :: view = .false.         !part of another vector's allocation (eigenvectors 2.. of gpu_sp_eigh_dev): freed with the first
   end type gpu_vector
 
   !> SciFortran's drivers are generic in exactly this way: the serial form takes the product first, the MPI form the
@@ -187,6 +189,24 @@ module ED_HAMILTONIAN_GPU_HXV
        type(c_ptr),value       :: h
        type(c_ptr),intent(out) :: d_vec
      end function hxv_vector_alloc
+     integer(c_int) function hxv_vector_alloc_many(h,count,d_vec) bind(C,name="hxv_vector_alloc_many")
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr),value        :: h
+       integer(c_int32_t),value :: count
+       type(c_ptr),intent(out)  :: d_vec
+     end function hxv_vector_alloc_many
+     integer(c_int64_t) function hxv_localvec_elems(h) bind(C,name="hxv_localvec_elems")
+       import :: c_int64_t, c_ptr
+       type(c_ptr),value :: h
+     end function hxv_localvec_elems
+     integer(c_int) function hxv_eigh_lowest(h,neigen,ncv,maxrestart,tol,evals,d_evecs,nconv,nmatvec) bind(C,name="hxv_eigh_lowest")
+       import :: c_int, c_int32_t, c_ptr, c_double
+       type(c_ptr),value        :: h,d_evecs
+       integer(c_int32_t),value :: neigen,ncv,maxrestart
+       real(c_double),value     :: tol
+       real(c_double)           :: evals(*)
+       integer(c_int32_t)       :: nconv,nmatvec
+     end function hxv_eigh_lowest
      integer(c_int) function hxv_vector_free(h,d_vec) bind(C,name="hxv_vector_free")
        import :: c_int, c_ptr
        type(c_ptr),value :: h,d_vec
@@ -521,6 +541,42 @@ contains
     endif
   end subroutine gpu_sp_lanc_eigh_dev
 
+  !> sp_eigh (the default lanc_method="arpack" call, ED_DIAG.f90:152-160) with the eigenvectors left on the device: vects(1:size(eval)), all in
+  !! one allocation that vects(1) owns (gpu_free_vector(vects(1)) releases them all; the others are views).  Any of them can be handed to
+  !! gpu_keep_sector / gpu_apply_ladder like the vector of gpu_sp_lanc_eigh_dev.
+  subroutine gpu_sp_eigh_dev(eval,vects,Nblock,Nitermax,tol,iverbose)
+    real(8),intent(inout)          :: eval(:)
+    type(gpu_vector),intent(inout) :: vects(:)
+    integer,intent(in),optional    :: Nblock,Nitermax
+    real(8),intent(in),optional    :: tol
+    logical,intent(in),optional    :: iverbose
+    integer(c_int32_t)             :: ncv,nit,nconv,nmv
+    real(8)                        :: tl
+    integer                        :: i
+    integer(c_int64_t)             :: stride
+    complex(c_double_complex),pointer :: base(:)
+    if(.not.c_associated(handle))stop "gpu_sp_eigh_dev ERROR: Hsector NOT set"
+    if(size(vects)<size(eval))stop "gpu_sp_eigh_dev ERROR: size(vects) < size(eval)"
+    if(size(eval)>=64)stop "gpu_sp_eigh_dev ERROR: more than 63 eigenpairs per sector exceed the engine's Krylov basis (64 vectors)"
+    do i=1,size(eval)
+       if(c_associated(vects(i)%d))stop "gpu_sp_eigh_dev ERROR: a vector is in use (gpu_free_vector it first)"
+    enddo
+    ncv=0;   if(present(Nblock))ncv=int(min(Nblock,64),c_int32_t)
+    nit=512; if(present(Nitermax))nit=int(Nitermax,c_int32_t)
+    tl=0d0;  if(present(tol))tl=tol
+    call check(hxv_vector_alloc_many(handle,int(size(eval),c_int32_t),vects(1)%d),"gpu_sp_eigh_dev")
+    stride=hxv_localvec_elems(handle)
+    call c_f_pointer(vects(1)%d,base,[stride*size(eval)])      !(address arithmetic only: the memory is on the device)
+    do i=1,size(eval)
+       vects(i)%sector=handle; vects(i)%owns_sector=.false.; vects(i)%view=(i>1)
+       if(i>1)vects(i)%d=c_loc(base(1+(i-1)*stride))
+    enddo
+    call check(hxv_eigh_lowest(handle,int(size(eval),c_int32_t),ncv,nit,tl,eval,vects(1)%d,nconv,nmv),"gpu_sp_eigh_dev")
+    if(present(iverbose))then
+       if(iverbose)write(*,"(A,I4,A,I6,A,F20.12)")"gpu_sp_eigh_dev: converged=",nconv," matvecs=",nmv," E0=",eval(1)
+    endif
+  end subroutine gpu_sp_eigh_dev
+
   !> The open sector stays open FOR this vector (it is needed again when c / c^dagger act on it); the module's "one open sector" slot
   !! becomes free, so build_Hv_sector of another sector may follow.  gpu_free_vector closes the kept sector.
   subroutine gpu_keep_sector(vect)
@@ -611,9 +667,9 @@ contains
 
   subroutine gpu_free_vector(vect)
     type(gpu_vector),intent(inout) :: vect
-    if(c_associated(vect%d))call check(hxv_vector_free(vect%sector,vect%d),"gpu_free_vector")
+    if(c_associated(vect%d).and..not.vect%view)call check(hxv_vector_free(vect%sector,vect%d),"gpu_free_vector")
     if(vect%owns_sector.and.c_associated(vect%sector))call check(hxv_destroy(vect%sector),"gpu_free_vector")
-    vect%d=c_null_ptr; vect%sector=c_null_ptr; vect%owns_sector=.false.
+    vect%d=c_null_ptr; vect%sector=c_null_ptr; vect%owns_sector=.false.; vect%view=.false.
   end subroutine gpu_free_vector
 
   !> Vector-sized bytes the engine has moved over PCIe for a sector since it was opened (include/hxv.h: hxv_stats): the open sector,

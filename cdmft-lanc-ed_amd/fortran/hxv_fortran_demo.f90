@@ -192,6 +192,14 @@ contains
     call gpu_build_Hv_sector(Nlat,Norb,Nspin,Nbath,6,6,impHloc,Hbath,Vbath,Uloc,0d0,0d0,0d0,0d0,0d0,.true.,0,1)
     dimA=gpu_vecDim_Hv_sector()
     call gpu_sp_lanc_eigh_dev(egs,gs,512,threshold=1d-14)
+    !the default spectrum call (sp_eigh, ED_DIAG.f90:152-160) with its eigenvectors left on the device as well: same ground state
+    block
+      type(gpu_vector) :: ev(2)
+      real(8) :: e2(2)
+      call gpu_sp_eigh_dev(e2,ev,20,512,tol=1d-18)
+      write(*,"(A,2F16.10,A,ES12.4)")"GF device sp_eigh: E=",e2," |E0 - lanc_eigh E0|=",abs(e2(1)-egs)
+      call gpu_free_vector(ev(2)); call gpu_free_vector(ev(1))
+    end block
     call gpu_keep_sector(gs)
     call gpu_build_Hv_sector(Nlat,Norb,Nspin,Nbath,7,6,impHloc,Hbath,Vbath,Uloc,0d0,0d0,0d0,0d0,0d0,.true.,0,1)
     dimB=gpu_vecDim_Hv_sector()

@@ -46,7 +46,7 @@ EXPORTS = [
     "hxv_version", "hxv_comm_unique_id", "hxv_comm_init", "hxv_comm_free", "hxv_apply_device_slab", "hxv_exchange_count",
     "hxv_set_exchange_default", "hxv_exchange_mode", "hxv_halo_counts", "hxv_halo_lists", "hxv_halo_plan_from_csr",
     "hxv_comm_local_create", "hxv_comm_init_local", "hxv_comm_local_destroy", "hxv_comm_local_abort", "hxv_time_apply_slab",
-    "hxv_vector_alloc", "hxv_vector_free", "hxv_vector_from_host", "hxv_vector_to_host",
+    "hxv_vector_alloc", "hxv_vector_alloc_many", "hxv_vector_free", "hxv_vector_from_host", "hxv_vector_to_host",
 ]
 
 _lib = None
@@ -121,6 +121,7 @@ def load_library():
     L.hxv_comm_free.argtypes = [vp]
     L.hxv_apply_device_slab.argtypes = [vp, vp, vp, vp]
     L.hxv_vector_alloc.argtypes = [vp, C.POINTER(vp)]
+    L.hxv_vector_alloc_many.argtypes = [vp, i32, C.POINTER(vp)]
     L.hxv_vector_free.argtypes = [vp, vp]
     L.hxv_vector_from_host.argtypes = [vp, vp, vp]
     L.hxv_vector_to_host.argtypes = [vp, vp, vp]

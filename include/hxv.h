@@ -320,6 +320,7 @@ int hxv_apply_ladder_axpy(hxv_handle *from, hxv_handle *to, int32_t orbital, int
  * convert to / from the reference's contiguous host layout when a vector is wanted on the host after all.  hxv_vector_free takes the handle the
  * vector was allocated on, BEFORE that handle is destroyed; hxv_destroy returns whatever was not freed.                              */
 int hxv_vector_alloc(hxv_handle *h, void **d_vec);
+int hxv_vector_alloc_many(hxv_handle *h, int32_t count, void **d_vec); /* `count` vectors in one allocation, hxv_localvec_elems() apart: the d_evecs of hxv_eigh_lowest; freed as one */
 int hxv_vector_free(hxv_handle *h, void *d_vec);
 int hxv_vector_from_host(hxv_handle *h, const void *v_host, void *d_vec);
 int hxv_vector_to_host(hxv_handle *h, const void *d_vec, void *v_host);

@@ -114,6 +114,8 @@ def test_fortran_device_resident_green_function_channel(built):
     assert m, txt
     e0, norm2 = float(m.group(1)), float(m.group(2))
     assert [int(m.group(k)) for k in (3, 4, 5, 6)] == [0, 0, 0, 0]            # nothing vector-sized crossed PCIe
+    se = re.search(r"GF device sp_eigh: E=\s*([-\d.Ee+]+)\s+([-\d.Ee+]+)\s*\|E0 - lanc_eigh E0\|=\s*([-\d.Ee+]+)", txt)
+    assert se and float(se.group(3)) < 1e-9 and float(se.group(2)) > float(se.group(1))      # gpu_sp_eigh_dev: eigenvectors stay on the device
     e0_ref = float(re.search(r"C2 device eigh E0=\s*([-\d.Ee+]+)", txt).group(1))
     assert abs(e0 - e0_ref) < 1e-9 and 0.0 < norm2 < 1.0
     h = re.search(r"GF host-array channel: \|norm2 diff\|=\s*([-\d.Ee+]+)\s*max\|da\|\(8\)=\s*([-\d.Ee+]+)\s*max\|db\|\(8\)=\s*([-\d.Ee+]+)\s*"
