@@ -32,16 +32,42 @@ sys.path.insert(0, str(ROOT / "cdmft-lanc-ed_amd"))
 sys.path.insert(0, str(ROOT))
 
 KERNELS_STAMP = "r04-a"   # bumped whenever the product kernels change: profiles/traffic.json is quoted only for the same stamp
+XGMI_LINK_GBS = 153.0  # one xGMI link, per direction (7 links per GPU: SURVEY.md 8e)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
+def host_cpu():
+    """(cpu model, logical CPUs of the host, CPUs this process may run on, PHYSICAL cores among them) from /proc/cpuinfo."""
+    model, phys = "unknown", {}
+    try:
+        cur = {}
+        for line in open("/proc/cpuinfo"):
+            if ":" not in line:
+                if "processor" in cur:
+                    phys[int(cur["processor"])] = (cur.get("physical id", "0"), cur.get("core id", cur["processor"]))
+                cur = {}
+                continue
+            k, v = (x.strip() for x in line.split(":", 1))
+            cur[k] = v
+            if k == "model name":
+                model = v
+        if "processor" in cur:
+            phys[int(cur["processor"])] = (cur.get("physical id", "0"), cur.get("core id", cur["processor"]))
+    except OSError:
+        pass
+    allowed = sorted(os.sched_getaffinity(0))
+    ncores = len({phys.get(c, ("0", str(c))) for c in allowed})
+    return model, os.cpu_count() or len(allowed), len(allowed), max(1, ncores)
+
+
 def cpu_baseline(model, nup, ndw, budget_s=25.0):
-    """Reference algorithm on the host: oracle spMatVec_mpi_main with one thread-rank per core."""
+    """Reference algorithm on the host: oracle spMatVec_mpi_main with one thread-rank per PHYSICAL core this process may
+    use -- no cap; the core count that ran, the CPU model and the host's totals are stated."""
     import numpy as np
     from oracle.oracle import OracleSector, spMatVec_mpi_main
 
-    cores = len(os.sched_getaffinity(0))
-    P = max(1, min(cores, 16))
+    cpu_model, host_cpus, allowed, phys_cores = host_cpu()
+    P = phys_cores
     t0 = time.time()
     secs = [OracleSector(model, nup, ndw, r, P) for r in range(P)]
     build_s = time.time() - t0
@@ -59,9 +85,10 @@ def cpu_baseline(model, nup, ndw, budget_s=25.0):
     dt = (time.time() - t0) / n
     for s in secs:
         s.close()
-    return {"value": 32.0 * dim / dt / 1e9, "unit": "GB/s", "cores": P, "kind": "port",
-            "sample": f"{n} full products of the same sector, {P} thread-ranks (reference spMatVec_mpi_main restated in oracle/hxv_oracle.c; "
-                      f"matrix build {build_s:.1f}s untimed)", "s_per_matvec": dt}
+    return {"value": 32.0 * dim / dt / 1e9, "unit": "GB/s", "cores": P, "kind": "port", "cpu_model": cpu_model, "host_cores": host_cpus,
+            "cpus_allowed": allowed,
+            "sample": f"{n} full products of the same sector, {P} thread-ranks = the physical cores among the {allowed} CPUs this process may use "
+                      f"(reference spMatVec_mpi_main restated in oracle/hxv_oracle.c; matrix build {build_s:.1f}s untimed)", "s_per_matvec": dt}
 
 
 def copy_rate_gbs(dev, nbytes=1 << 30, reps=5):
@@ -118,6 +145,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lanczos", action="store_true", help="skip the Lanczos-iteration timing (N=1; second half of BASELINE's metric)")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the C4 / C5 product timings reported in config.other_workloads (N=1)")
+    ap.add_argument("--no-gf-solve", action="store_true",
+                    help="skip the solve-shaped leg (N=1, C3): the 56 Green's-function channels of one default solve, the target sector opened and "
+                         "closed around every channel as ED_GF_NORMAL.f90:208-222 does (config.gf_solve; about a minute)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 path on one GPU)")
     ap.add_argument("--exchange", default="allgather", choices=["allgather", "alltoall", "halo"],
                     help="N>1: allgather = one RCCL all-gather per product (BASELINE's mandated exchange, default); "
@@ -321,6 +351,14 @@ def main():
                 "algorithmic_bytes": 32 * sec.vecDim}
     if step_ev_ms is not None:
         roofline["slab_product_ms_on_stream"] = round(step_ev_ms, 4)   # exchange + kernels of this rank, HIP events (hxv_time_apply_slab)
+        # what the exchange costs each rank: the slab product on the stream minus its kernels; min / max over the ranks
+        ex_ms = step_ev_ms - k_ms
+        if multi:
+            t2 = torch.tensor([ex_ms, -ex_ms], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+            roofline["exchange_ms"] = {"this_rank": round(ex_ms, 4), "max": round(float(t2[0].item()), 4), "min": round(-float(t2[1].item()), 4)}
+        else:
+            roofline["exchange_ms"] = {"this_rank": round(ex_ms, 4), "max": round(ex_ms, 4), "min": round(ex_ms, 4)}
 
     ns = {"C2": 12, "C3": 16, "C4": 16, "C5": 18}[args.workload]
     out = {"metric": f"sector-HxV achieved HBM GB/s (algorithmic 32 B x Dim per product), Ns={ns} half-filled sector", "value": round(value, 1),
@@ -335,6 +373,12 @@ def main():
         out["checked"] = checked
         out["check_rel_err"] = check_err
         out["config"]["transport"] = "C-ABI (hxv_comm_init + hxv_apply_device_slab over RCCL)" if capi_exchange else f"torch.distributed ({args.backend}) twin, rehearsal only"
+        # WHICH librccl ran: the one the engine dlopen()ed for its communicator, and the one(s) mapped into this process (torch's own)
+        out["config"]["rccl_lib"] = sec.comm_library if capi_exchange else None
+        try:
+            out["config"]["rccl_libs_mapped"] = sorted({ln.split()[-1] for ln in open("/proc/self/maps") if "rccl" in ln.lower() and "/" in ln})
+        except OSError:
+            out["config"]["rccl_libs_mapped"] = []
     if world > 1 and not by_sector:
         # what the exchange moves into every GPU per product: the xGMI links, not HBM, bound the N>1 product
         slab = 16 * (-(-sec.DimDw // world)) * sec.pitch
@@ -342,6 +386,18 @@ def main():
         halo_cols = int(sec.halo_lists(world)[0].sum()) if sec.exchange_mode == "halo" else 0   # (the engine's own receive lists)
         out["config"]["exchange_ingest_bytes_per_gpu"] = ((world - 1) * slab if args.exchange == "allgather" else
                                                           16 * sec.pitch * halo_cols if args.exchange == "halo" else 2 * (world - 1) * slab // world)
+        # First-contact fields ("the result JSON should carry the link-bound alongside the measurement").  xGMI is point to point:
+        # every peer's bytes arrive over that peer's own link (153 GB/s each way, 7 links per GPU), so the bound is the LARGEST per-peer ingest
+        # over one link's rate.  all-gather: one slab per peer; two transposes: 2 x slab/world per peer; halo: the busiest peer's columns.
+        if args.exchange == "halo" and sec.exchange_mode == "halo":
+            per_peer = 16 * sec.pitch * int(sec.halo_lists(world)[0].max())
+        elif args.exchange == "alltoall":
+            per_peer = 2 * slab // world
+        else:
+            per_peer = slab
+        out["config"]["link_GBs_assumed"] = XGMI_LINK_GBS
+        out["config"]["link_bound_ms"] = round(per_peer / (XGMI_LINK_GBS * 1e9) * 1e3, 4)
+        out["config"]["link_bound_note"] = "largest per-peer ingest of one product / one xGMI link (point to point, 7 links per GPU); compute overlaps none of it in the default exchanges"
     if world == 1 and not args.rehearse_capi:
         # what each of the three exchanges would move into one GPU per product at 8 ranks
         rp, cols, _ = sec.csr("dw")
@@ -354,11 +410,39 @@ def main():
         lz_ms = sec.time_lanczos(20)
         out["config"]["lanczos_ms_per_iter"] = round(lz_ms, 4)
         out["config"]["lanczos_matvecs_per_s"] = round(1e3 / lz_ms, 2)
+        # the Lanczos half of the metric against the roofline.  Bytes CHARGED per iteration and basis state, complex vectors: the product
+        # 32 + w -= beta x_prev 16 (read x_prev; fused into the product's write) + w -= alpha x, |w| 48 (read w, x, write w: a
+        # pass of its own, alpha is a global reduction of the product) = 96; the design moves 144 (its two-pass product moves 80).
+        lz_bytes = 96 * sec.vecDim
+        roofline["lanczos"] = {"bytes_per_state": 96, "bytes": lz_bytes, "ms_per_iter": round(lz_ms, 4), "achieved": round(lz_bytes / (lz_ms * 1e-3) / 1e9, 1),
+                               "unit": "GB/s", "frac": round(lz_bytes / (lz_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "design_bytes_per_state": 144,
+                               "frac_of_design_floor": round(144.0 * sec.vecDim / (copy_gbs * 1e9) * 1e3 / lz_ms, 4)}
         sec.set_option("real_vectors", 1)
         if sec.real_vectors_available:
             lzr_ms = sec.time_lanczos(20)
             out["config"]["lanczos_real_vectors_ms_per_iter"] = round(lzr_ms, 4)
             out["config"]["lanczos_real_vectors_matvecs_per_s"] = round(1e3 / lzr_ms, 2)
+            # REAL vectors (real H): half of every byte count above -- product 16, iteration 48 charged, 72 moved by the design
+            vr = torch.randn(sec.DimDw * sec.DimUp, dtype=torch.float64, device=dev, generator=g)
+            vr = sec.pad_real(vr)
+            hr = torch.empty_like(vr)
+            for _ in range(3):
+                sec.apply_device_real(vr, hr)
+            e0_, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0_.record()
+            for _ in range(20):
+                sec.apply_device_real(vr, hr)      # (launched on torch's current stream: the events see it)
+            e1_.record()
+            torch.cuda.synchronize()
+            pr_ms = e0_.elapsed_time(e1_) / 20
+            del vr, hr
+            rb, rlz = 16 * sec.vecDim, 48 * sec.vecDim
+            roofline["real_vectors"] = {"product_bytes_per_state": 16, "product_ms": round(pr_ms, 4), "product_achieved": round(rb / (pr_ms * 1e-3) / 1e9, 1),
+                                        "product_frac": round(rb / (pr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                        "product_frac_of_design_floor": round(40.0 * sec.vecDim / (copy_gbs * 1e9) * 1e3 / pr_ms, 4),
+                                        "lanczos_bytes_per_state": 48, "lanczos_ms_per_iter": round(lzr_ms, 4), "lanczos_achieved": round(rlz / (lzr_ms * 1e-3) / 1e9, 1),
+                                        "lanczos_frac": round(rlz / (lzr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "unit": "GB/s"}
         if sec.real_vectors_available:
             # two real tridiagonalisations per complex product (hxv_lanczos_tridiag_pair: two Green's-function channels at once)
             va = torch.zeros(sec.localElems, dtype=torch.complex128, device=dev)
@@ -379,6 +463,31 @@ def main():
             out["config"]["lanczos_paired_real_ms_per_iter_per_channel"] = round(pair_ms / 2, 4)
             out["config"]["lanczos_paired_real_matvecs_per_s"] = round(2e3 / pair_ms, 2)
             del va, vb
+    if world == 1 and args.workload == "C3" and not args.no_gf_solve and not args.no_lanczos and not args.rehearse_capi:
+        # the callers' usage pattern as a measured whole (hxv/harness.py): ground state of (8,8) by the default spectrum call, then the
+        # 56 tridiagonalisations of build_gf_normal (ED_GF_NORMAL.f90:36-110; 8 diagonal + 24 real mixed + 24 complex mixed: chan4, the
+        # default), each with its sector N+-1 opened and closed around it (:208-222), device-resident, two real channels per product
+        from hxv.harness import gf_solve
+
+        hxv.sector_cache_clear()
+        recs, gs_ = gf_solve(model, nup, ndw, nlanc=200, symmetric=False, device=local_rank)
+        real_part = [r for r in recs if r["kind"] != "mix_xi"]
+        chan2_s = (gs_["gs_open_ms"] + gs_["gs_ms"] + sum(r["open_ms"] / (2 if r["paired"] else 1) + r["start_ms"] / (2 if r["paired"] else 1) + r["tridiag_ms"]
+                                                           + r["close_ms"] / (2 if r["paired"] else 1) for r in real_part)) * 1e-3
+        out["config"]["gf_solve"] = {
+            "what": "ground state + the 56 channels of one default solve (ed_gf_symmetric=F: chan4), nlanc 200, sector opened/closed per channel",
+            "gf_solve_s": round(gs_["gf_solve_s"], 2), "ground_state_s": round(gs_["gs_ms"] * 1e-3, 3), "ground_state_products": gs_["gs_nmatvec"],
+            "channels": gs_["channels"], "channels_real": gs_["channels_real"], "channels_complex": gs_["channels_complex"], "channels_paired": gs_["channels_paired"],
+            "real_channels_s": round(gs_["real_channels_s"], 2), "complex_channels_s": round(gs_["complex_channels_s"], 2),
+            "ms_per_channel_step_real_paired": round(gs_["real_channels_s"] * 1e3 / max(1, gs_["channels_real"]) / 200, 3),
+            "ms_per_channel_step_complex": round(gs_["complex_channels_s"] * 1e3 / max(1, gs_["channels_complex"]) / 200, 3),
+            "sector_opens": gs_["sector_opens"], "sector_open_cache_hits": gs_["sector_open_cache_hits"],
+            "sector_open_ms": {"first": round(gs_["sector_open_ms_first"], 2), "mean": round(gs_["sector_open_ms_mean"], 3), "max": round(gs_["sector_open_ms_max"], 2)},
+            "gf_solve_symmetric_s": round(chan2_s, 2),
+            "gf_solve_symmetric_note": "ed_gf_symmetric=T (chan2: the 32 real channels only) = the real-channel part of the same run; for real symmetric "
+                                       "H the complex channels carry nothing the real ones do not (INTEGRATION.md section 4)"}
+        del recs
+        torch.cuda.empty_cache()
     if world == 1 and args.workload == "C3" and not args.no_other_workloads and not args.rehearse_capi:
         # the other full-size configs, driver-timed on the same GPU (parity-test sizes of BASELINE.json, not the headline)
         sec.close()

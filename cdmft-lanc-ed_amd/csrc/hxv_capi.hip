@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 
 #include "hxv_internal.hpp"
 #include "hxv_tiles.hpp"
@@ -44,8 +45,112 @@ int ensure_wt(hxv_handle* h) {
 }  // namespace hxv
 
 namespace hxv {
-int finish_create(hxv_handle* h, int device, hxv_handle** out);
+namespace {
+double us_since(const std::chrono::steady_clock::time_point& t0) {
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
 }
+int64_t host_bytes_of(const SectorHost& s) {
+  auto vb = [](const auto& v) { return (int64_t)(v.capacity() * sizeof(v[0])); };
+  auto sp = [&](const SpinOp& o) { return vb(o.rowptr) + vb(o.cols) + vb(o.vals) + vb(o.ell) + vb(o.coef); };
+  return sp(s.up) + sp(s.dw) + vb(s.vcol) + vb(s.map_up) + vb(s.map_dw) + vb(s.a_up) + vb(s.a_dw) + vb(s.diag_stored) + vb(s.nd_up) + vb(s.nd_dw) +
+         vb(s.halo_cols) + vb(s.send_cols);
+}
+}  // namespace
+// the staged tables of an image whose host half is done (SectorImage::pending)
+struct SectorImage::Pending {
+  TableArena ar;
+  uint32_t *ell_up = nullptr, *ell_dw = nullptr, *vcol = nullptr, *map_up = nullptr, *map_dw = nullptr, *ndu = nullptr, *ndd = nullptr;
+  double2 *coef_up = nullptr, *coef_dw = nullptr;
+  double *a_up = nullptr, *a_dw = nullptr, *stored = nullptr;
+};
+namespace {
+// Host half of an open: the tile plan, and every device table of the sector staged in one image (TableArena).  No HIP call.
+int prepare_image(SectorImage& im) {
+  const SectorHost& s = im.host;
+  const auto t0 = std::chrono::steady_clock::now();
+  auto pd = std::make_shared<SectorImage::Pending>();
+  TableArena& ar = pd->ar;
+  ar.add(s.up.ell, &pd->ell_up);
+  ar.add(translate_ell_src(s.dw.ell, s.vcol), &pd->ell_dw);
+  ar.add(s.vcol, &pd->vcol);
+  std::vector<double2> cu(s.up.coef.size()), cd(s.dw.coef.size());
+  for (size_t i = 0; i < cu.size(); ++i) cu[i] = make_double2(s.up.coef[i].real(), s.up.coef[i].imag());
+  for (size_t i = 0; i < cd.size(); ++i) cd[i] = make_double2(s.dw.coef[i].real(), s.dw.coef[i].imag());
+  ar.add(cu, &pd->coef_up);
+  ar.add(cd, &pd->coef_dw);
+  if (s.separable_diag) {
+    ar.add(s.map_up, &pd->map_up);
+    ar.add(s.map_dw, &pd->map_dw);
+    ar.add(s.a_up, &pd->a_up);
+    ar.add(s.a_dw, &pd->a_dw);
+  } else {
+    ar.add(s.diag_stored, &pd->stored);
+  }
+  if (!s.nd_up.empty()) {
+    ar.add(s.nd_up, &pd->ndu);
+    ar.add(s.nd_dw, &pd->ndd);
+  }
+  PlanUploader pu{[&ar](const std::vector<uint32_t>& v, uint32_t** p) { return ar.add(v, p); },
+                  [&ar](const std::vector<double2>& v, double2** p) { return ar.add(v, p); }};
+  std::string perr = make_tile_plan(s, im.plan, pu);
+  if (!perr.empty()) return fail(HXV_ERR_HIP, perr);
+  if (!im.plan.usable) im.kernel = 0;  // too many distinct amplitudes for the LDS coefficient table
+  im.host_bytes = host_bytes_of(s);
+  im.pending = pd;
+  im.us_plan = us_since(t0);
+  return HXV_OK;
+}
+// Device half: one allocation, one copy, pointers patched.
+int upload_image(SectorImage& im, int device) {
+  if (!im.pending) {
+    int rc = prepare_image(im);
+    if (rc) return rc;
+  }
+  const SectorHost& s = im.host;
+  const auto t0 = std::chrono::steady_clock::now();
+  SectorImage::Pending& pd = *im.pending;
+  void* base = nullptr;
+  int64_t bytes = 0;
+  hipError_t e = pd.ar.commit(&base, &bytes);
+  if (base) {
+    im.allocs.push_back(base);
+    im.device_bytes += bytes;
+  }
+  im.device = device;
+  if (e != hipSuccess) return fail(HXV_ERR_HIP, std::string("upload of the sector tables: ") + hipGetErrorString(e));
+  DevSector& d = im.dev;
+  d.up = DevSpin{pd.ell_up, pd.coef_up, s.up.K, s.up.dim};
+  d.dw = DevSpin{pd.ell_dw, pd.coef_dw, s.dw.K, s.dw.dim};
+  d.diag.mode = s.separable_diag ? 0 : 1;
+  d.diag.a_up = pd.a_up;
+  d.diag.a_dw = pd.a_dw;
+  d.diag.map_up = pd.map_up;
+  d.diag.map_dw = pd.map_dw;
+  d.diag.stored = pd.stored;
+  d.diag.cross = s.cross;
+  d.dimup = s.dimup;
+  d.dimdw = s.dimdw;
+  d.pitch = s.pitch;
+  d.qdw = s.qdw;
+  d.dw0 = s.dw0;
+  d.slab0 = s.exchange == 1 ? 0 : s.rank * s.cmax;
+  d.vcol = pd.vcol;
+  d.vcol_identity = (s.nranks == 1) ? 1 : 0;
+  d.nd = s.nd;
+  d.nd_up = pd.ndu;
+  d.nd_dw = pd.ndd;
+  d.ndcsr_rowptr = nullptr;
+  d.ndcsr_cols = nullptr;
+  d.ndcsr_vals = nullptr;
+  d.real_h = (s.up.real_vals && s.dw.real_vals) ? 1 : 0;
+  im.pending.reset();
+  im.us_upload = us_since(t0);
+  im.uploaded = true;
+  return HXV_OK;
+}
+}  // namespace
+int finish_create(hxv_handle* h, int device, hxv_handle** out);
+}  // namespace hxv
 int hxv::finish_create(hxv_handle* h, int device, hxv_handle** out) {
   int ndev = 0;
   hipError_t e0 = hipGetDeviceCount(&ndev);
@@ -70,67 +175,25 @@ int hxv::finish_create(hxv_handle* h, int device, hxv_handle** out) {
   } while (0)
   HC(hipSetDevice(device));
   HC(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  HC(hipEventCreate(&h->ev0));
-  HC(hipEventCreate(&h->ev1));
-  SectorHost& s = h->host;
-  uint32_t *ell_up, *ell_dw, *map_up = nullptr, *map_dw = nullptr;
-  double2 *coef_up, *coef_dw;
-  double *a_up = nullptr, *a_dw = nullptr, *stored = nullptr;
-  HC(h->upload(&ell_up, s.up.ell));
-  HC(h->upload(&ell_dw, translate_ell_src(s.dw.ell, s.vcol)));
-  uint32_t* vcol;
-  HC(h->upload(&vcol, s.vcol));
-  std::vector<double2> cu(s.up.coef.size()), cd(s.dw.coef.size());
-  for (size_t i = 0; i < cu.size(); ++i) cu[i] = make_double2(s.up.coef[i].real(), s.up.coef[i].imag());
-  for (size_t i = 0; i < cd.size(); ++i) cd[i] = make_double2(s.dw.coef[i].real(), s.dw.coef[i].imag());
-  HC(h->upload(&coef_up, cu));
-  HC(h->upload(&coef_dw, cd));
-  if (s.separable_diag) {
-    HC(h->upload(&map_up, s.map_up));
-    HC(h->upload(&map_dw, s.map_dw));
-    HC(h->upload(&a_up, s.a_up));
-    HC(h->upload(&a_dw, s.a_dw));
-  } else {
-    HC(h->upload(&stored, s.diag_stored));
+  HC(hipEventCreateWithFlags(&h->ev0, hipEventDefault));
+  HC(hipEventCreateWithFlags(&h->ev1, hipEventDefault));
+  SectorImage& im = *h->img;
+  if (!im.uploaded) {
+    int rc = upload_image(im, device);
+    if (rc) {
+      const std::string msg = hxv_last_error();
+      return cleanup(rc, msg);
+    }
+    h->open_us[1] = im.us_plan;
+    h->open_us[2] = im.us_upload;
+    sector_cache_insert(h->img);
   }
-  DevSector& d = h->dev;
-  d.up = DevSpin{ell_up, coef_up, s.up.K, s.up.dim};
-  d.dw = DevSpin{ell_dw, coef_dw, s.dw.K, s.dw.dim};
-  d.diag.mode = s.separable_diag ? 0 : 1;
-  d.diag.a_up = a_up;
-  d.diag.a_dw = a_dw;
-  d.diag.map_up = map_up;
-  d.diag.map_dw = map_dw;
-  d.diag.stored = stored;
-  d.diag.cross = s.cross;
-  d.dimup = s.dimup;
-  d.dimdw = s.dimdw;
-  d.pitch = s.pitch;
-  d.qdw = s.qdw;
-  d.dw0 = s.dw0;
-  d.slab0 = s.exchange == 1 ? 0 : s.rank * s.cmax;
-  d.vcol = vcol;
-  d.vcol_identity = (s.nranks == 1) ? 1 : 0;
-  d.nd = s.nd;
-  d.nd_up = d.nd_dw = nullptr;
-  d.ndcsr_rowptr = nullptr;
-  d.ndcsr_cols = nullptr;
-  d.ndcsr_vals = nullptr;
-  if (!s.nd_up.empty()) {
-    uint32_t *ndu = nullptr, *ndd = nullptr;
-    HC(h->upload(&ndu, s.nd_up));
-    HC(h->upload(&ndd, s.nd_dw));
-    d.nd_up = ndu;
-    d.nd_dw = ndd;
-  }
-  d.real_h = (s.up.real_vals && s.dw.real_vals) ? 1 : 0;
-  HC(h->alloc(&h->d_partials, 2 * RED_BLOCKS));
-  HC(h->alloc(&h->d_scalars, 8));
-  PlanUploader pu{[h](const std::vector<uint32_t>& v, uint32_t** p) { return h->upload(p, v); },
-                  [h](const std::vector<double2>& v, double2** p) { return h->upload(p, v); }};
-  std::string perr = make_tile_plan(s, h->plan, pu);
-  if (!perr.empty()) return cleanup(HXV_ERR_HIP, perr);
-  if (!h->plan.usable) h->kernel = 0;  // too many distinct amplitudes for the LDS coefficient table
+  h->dev = im.dev;
+  h->plan = im.plan;
+  h->kernel = im.kernel;
+  // the handle's own scratch: partial sums [2][RED_BLOCKS] and the scalars [8] of the Lanczos drivers, one allocation
+  HC(h->alloc(&h->d_partials, 2 * RED_BLOCKS + 8));
+  h->d_scalars = h->d_partials + 2 * RED_BLOCKS;
 #undef HC
   *out = h;
   return HXV_OK;
@@ -160,21 +223,44 @@ int hxv_create_from_model(const hxv_model* model, int32_t nup, int32_t ndw, int3
                           hxv_handle** out) {
   if (!model || !out) return fail(HXV_ERR_ARG, "NULL model/out");
   *out = nullptr;
-  hxv_handle* h = new hxv_handle();
-  std::string e = build_sector_from_model(*model, nup, ndw, rank, nranks, h->host);
-  if (!e.empty()) {
-    delete h;
-    bool unsup = e.find("not implemented") != std::string::npos;
-    return fail(unsup ? HXV_ERR_UNSUPPORTED : HXV_ERR_ARG, "hxv_create_from_model: " + e);
+  const auto t0 = std::chrono::steady_clock::now();
+  // a sector that was open before (same model bytes, sector, split, exchange, device) shares the image of that open (hxv_cache.cpp)
+  const std::string key = sector_cache_key(*model, nup, ndw, rank, nranks, device, nranks > 1 ? default_exchange() : 0);
+  std::shared_ptr<SectorImage> img = sector_cache_find(key);
+  const bool hit = img != nullptr;
+  if (!hit) {
+    img = std::make_shared<SectorImage>();
+    std::string e = build_sector_from_model(*model, nup, ndw, rank, nranks, img->host);
+    if (!e.empty()) {
+      bool unsup = e.find("not implemented") != std::string::npos;
+      return fail(unsup ? HXV_ERR_UNSUPPORTED : HXV_ERR_ARG, "hxv_create_from_model: " + e);
+    }
+    img->key = key;
+    img->us_host = us_since(t0);
+    int rcp = prepare_image(*img);  // (the host half of the open: the plan and the staged tables, before any device is touched)
+    if (rcp) return rcp;
   }
-  return finish_create(h, device, out);
+  hxv_handle* h = new hxv_handle(img);
+  h->open_cache_hit = hit ? 1 : 0;
+  if (!hit) h->open_us[0] = img->us_host;
+  int rc = finish_create(h, device, out);
+  if (rc == HXV_OK) {
+    h->open_us[3] = us_since(t0);
+    if (const char* tr = getenv("HXV_TRACE_OPEN"))
+      if (tr[0] == '1')
+        fprintf(stderr, "[hxv open] (%d,%d) rank %d/%d dim %lld: %s host %.0f us, plan %.0f us, upload %.0f us, total %.0f us\n", nup, ndw, rank, nranks,
+                (long long)h->host.dim, hit ? "CACHED" : "built", h->open_us[0], h->open_us[1], h->open_us[2], h->open_us[3]);
+  } else if (const char* tr = getenv("HXV_TRACE_OPEN")) {
+    if (tr[0] == '1' && !hit) fprintf(stderr, "[hxv open] (%d,%d) dim %lld: host %.0f us, plan %.0f us (create failed with status %d)\n", nup, ndw, (long long)img->host.dim, img->us_host, img->us_plan, rc);
+  }
+  return rc;
 }
 
 int hxv_create_dw_panel(const hxv_model* model, int32_t nup, int32_t ndw, int32_t nrows, int32_t device, hxv_handle** out) {
   if (!model || !out) return fail(HXV_ERR_ARG, "NULL model/out");
   *out = nullptr;
   if (nrows < 1) return fail(HXV_ERR_ARG, "hxv_create_dw_panel: nrows < 1");
-  hxv_handle* h = new hxv_handle();
+  hxv_handle* h = new hxv_handle();  // (a private image: panels are not cached)
   std::string e = build_sector_from_model(*model, nup, ndw, 0, 1, h->host, nrows);
   if (!e.empty()) {
     delete h;
@@ -230,7 +316,7 @@ int hxv_set_nonlocal_csr(hxv_handle* h, const int64_t* rowptr, const int32_t* co
   h->dev.ndcsr_vals = d_v;
   // from here on the handle behaves like one with Jx / Jp: the block is its own pass after the product (never folded, no REAL-vector
   // mode, plain Lanczos recurrence)
-  h->dev.nd.active = h->host.nd.active = 1;
+  h->dev.nd.active = h->host.nd.active = 1;  // (from_csr handles own their image: nothing shares this host description)
   h->dev.nd.fold = h->host.nd.fold = 0;
   (void)real;
   return HXV_OK;
@@ -573,7 +659,7 @@ int hxv_set_option(hxv_handle* h, const char* name, int64_t value) {
     return HXV_OK;
   }
   if (!strcmp(name, "fold_nd")) {  // spH0nd inside pass A (default) or as its own pass over hv
-    h->dev.nd.fold = h->host.nd.fold = value ? 1 : 0;
+    h->dev.nd.fold = value ? 1 : 0;  // (the handle's copy: the host description may be shared with other handles)
     return HXV_OK;
   }
   // tiling knobs: rebuild the plan (old tables stay allocated until hxv_destroy)
@@ -601,10 +687,21 @@ int hxv_set_option(hxv_handle* h, const char* name, int64_t value) {
   HIPCHK(hipStreamSynchronize(h->stream));
   TilePlan np;
   np.opt = o;
-  PlanUploader pu{[h](const std::vector<uint32_t>& v, uint32_t** p) { return h->upload(p, v); },
-                  [h](const std::vector<double2>& v, double2** p) { return h->upload(p, v); }};
+  TableArena ar;  // (the handle's own tables from here on: the shared image keeps the default plan)
+  PlanUploader pu{[&ar](const std::vector<uint32_t>& v, uint32_t** p) { return ar.add(v, p); },
+                  [&ar](const std::vector<double2>& v, double2** p) { return ar.add(v, p); }};
   std::string perr = make_tile_plan(h->host, np, pu);
   if (!perr.empty()) return fail(HXV_ERR_ARG, perr);
+  if (np.usable) {
+    void* base = nullptr;
+    int64_t bytes = 0;
+    hipError_t ea = ar.commit(&base, &bytes);
+    if (base) {
+      h->allocs.push_back(base);
+      h->device_bytes += bytes;
+    }
+    if (ea != hipSuccess) return fail(HXV_ERR_HIP, std::string("upload of the tile tables: ") + hipGetErrorString(ea));
+  }
   h->plan = np;
   return HXV_OK;
 }
@@ -612,6 +709,12 @@ int hxv_set_option(hxv_handle* h, const char* name, int64_t value) {
 int64_t hxv_get_option(const hxv_handle* h, const char* name) {
   if (!h || !name) return -1;
   if (!strcmp(name, "real_vectors")) return h->real_vectors;
+  // what THIS open cost, microseconds (0 for the parts a cached image saved): host description, tile plan, table upload, whole create call
+  if (!strcmp(name, "open_us_host")) return (int64_t)h->open_us[0];
+  if (!strcmp(name, "open_us_plan")) return (int64_t)h->open_us[1];
+  if (!strcmp(name, "open_us_upload")) return (int64_t)h->open_us[2];
+  if (!strcmp(name, "open_us_total")) return (int64_t)h->open_us[3];
+  if (!strcmp(name, "open_cache_hit")) return h->open_cache_hit;
   if (!strcmp(name, "lanczos_graph")) return h->lz_graph;
   if (!strcmp(name, "eigh_degenerate")) return h->eigh_degenerate;
   if (!strcmp(name, "eigh_keep_pct")) return h->eigh_keep_pct;
@@ -669,7 +772,7 @@ int hxv_get_stats(const hxv_handle* h, hxv_stats* out) {
   if (!h || !out) return fail(HXV_ERR_ARG, "hxv_get_stats: NULL");
   out->n_apply = h->n_apply;
   out->algorithmic_bytes = 32 * (int64_t)h->host.qdw * h->host.dimup;
-  out->device_bytes = h->device_bytes;
+  out->device_bytes = h->device_bytes + h->img->device_bytes;  // (the sector's tables may be shared with other handles of the same sector)
   out->kernel = h->kernel;
   out->real_h = h->dev.real_h;
   out->k_up = h->host.up.K;

@@ -44,6 +44,8 @@ struct Rccl {
   decltype(&ncclRecv) Recv = nullptr;
   decltype(&ncclGroupStart) GroupStart = nullptr;
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclCommAbort) CommAbort = nullptr;  // optional: hxv_comm_abort
+  std::string path;                              // file the symbols came from (dladdr)
   std::string err;
 };
 // One symbol table per library.  HXV_RCCL_LIB (read at every hxv_comm_unique_id / hxv_comm_init) names the library to use instead of the
@@ -86,6 +88,12 @@ Rccl* rccl() {
     SYM(GroupStart, ncclGroupStart)
     SYM(GroupEnd, ncclGroupEnd)
 #undef SYM
+    r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(r.lib, "ncclCommAbort"));  // (not required of a library)
+    {
+      // where the library was found: the first real N>1 run must be able to say WHICH librccl it ran (bench.py: config.rccl_lib)
+      Dl_info di;
+      if (r.GetUniqueId && dladdr(reinterpret_cast<void*>(r.GetUniqueId), &di) && di.dli_fname) r.path = di.dli_fname;
+    }
   }
   return tables.emplace(key, std::move(t)).first->second.get();
 }
@@ -276,7 +284,7 @@ int exchange(hxv_handle* h, const void* d_v_local, bool real, hipStream_t st) {
 
 namespace hxv {
 
-bool comm_ready(const hxv_handle* h) { return h->comm != nullptr || h->lgroup != nullptr; }
+bool comm_ready(const hxv_handle* h) { return (h->comm != nullptr && !h->comm_aborted) || h->lgroup != nullptr; }
 
 // Does p point into one of the handle's gather buffers (hxv_slab_home hands out a slot of the first)?  The device Lanczos drivers zero
 // the slab's place in all three before they read their start vector: a start vector that lives there is staged first.
@@ -555,12 +563,20 @@ static int apply_slab_a2a(hxv_handle* h, const void* v_, void* hv_, bool real, h
   // product and transpose back are under way, and the dw part is added at the end (hv += pieces: 32 B per local state more than the
   // fused form, which reads the pieces as pass A's accumulator init).  Pays where a transpose takes longer than pass A on the slab.
   const bool overlap = h->a2a_overlap && !ep && h->plan.usable;
+  //  every error return below the launch on the second stream waits for it first: the caller may free or reuse v / hv at once
+  struct JoinSecondStream {
+    hipStream_t s2 = nullptr;
+    ~JoinSecondStream() {
+      if (s2) (void)hipStreamSynchronize(s2);
+    }
+  } join2;
   if (overlap) {
     if (!h->stream2) HIPCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     for (auto& e : h->ov_ev)
       if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHK(hipEventRecord(h->ov_ev[0], st));                 // v is ready (and the previous user of hv is done) on st
     HIPCHK(hipStreamWaitEvent(h->stream2, h->ov_ev[0], 0));
+    kt_mark(h, 4, h->stream2);
     hipError_t eo;
     if (real) {
       DevSector d = h->dev;
@@ -571,6 +587,8 @@ static int apply_slab_a2a(hxv_handle* h, const void* v_, void* hv_, bool real, h
                             nullptr, 1, true);
     }
     if (eo != hipSuccess) return fail(HXV_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(eo));
+    kt_mark(h, 5, h->stream2);
+    join2.s2 = h->stream2;  // from here on pass A is writing hv on the second stream: no return may leave it unjoined
     HIPCHK(hipEventRecord(h->ov_ev[1], h->stream2));
   }
   // 1. my slab cut by the receivers' row ranges; my own block goes straight into the panel
@@ -609,6 +627,7 @@ static int apply_slab_a2a(hxv_handle* h, const void* v_, void* hv_, bool real, h
   if (overlap) {
     // 4'. the dw part joins what the second stream has computed meanwhile
     HIPCHK(hipStreamWaitEvent(st, h->ov_ev[1], 0));
+    join2.s2 = nullptr;  // joined in stream order: st now waits for pass A
     kt_mark(h, 2, st);
     hipError_t ea = launch_add_pieces(hv_, a.d_wtr[real ? 1 : 0], P, s.dimup, (int)pit, q, real, st);
     if (ea != hipSuccess) return fail(HXV_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(ea));
@@ -685,9 +704,10 @@ int apply_slab_real(hxv_handle* h, const double* d_v_local, double* d_hv_local, 
 
 void comm_release(hxv_handle* h) {
   if (h->comm) {
-    (void)api(h)->CommDestroy((ncclComm_t)h->comm);
+    if (!h->comm_aborted) (void)api(h)->CommDestroy((ncclComm_t)h->comm);  // (ncclCommAbort has freed an aborted communicator)
     h->comm = nullptr;
     h->comm_api = nullptr;
+    h->comm_aborted = 0;
   }
   if (LocalGroup* G = lg(h)) {
     // (the group object itself belongs to whoever created it: hxv_comm_local_destroy)
@@ -778,6 +798,33 @@ int hxv_comm_local_abort(void* group) {
   return HXV_OK;
 }
 
+// A rank of the communicator has failed OUTSIDE the library: wake this handle's collectives instead of leaving them waiting for it.
+// RCCL: ncclCommAbort (callable from another host thread while this rank's thread sits in a collective; the communicator is gone
+// afterwards -- later calls on the handle report a missing communicator, hxv_comm_free / hxv_destroy still clean up).  Thread ranks:
+// the whole group is marked broken, like hxv_comm_local_abort.
+int hxv_comm_abort(hxv_handle* h) {
+  if (!h) return HXV_OK;
+  if (LocalGroup* G = lg(h)) {
+    std::lock_guard<std::mutex> lk(G->mu);
+    G->broken = true;
+    G->cv.notify_all();
+    return HXV_OK;
+  }
+  if (!h->comm || h->comm_aborted) return HXV_OK;
+  Rccl* r = api(h);
+  if (!r || !r->CommAbort) return fail(HXV_ERR_UNSUPPORTED, "hxv_comm_abort: the RCCL library in use exports no ncclCommAbort");
+  h->comm_aborted = 1;
+  ncclResult_t e = r->CommAbort((ncclComm_t)h->comm);
+  if (e != ncclSuccess) return nccl_fail(r, "ncclCommAbort", e);
+  return HXV_OK;
+}
+
+// the file the RCCL entry points of this handle's communicator were resolved from ("" without one): what bench.py reports as config.rccl_lib
+const char* hxv_comm_library(const hxv_handle* h) {
+  if (!h || !h->comm_api) return "";
+  return static_cast<const Rccl*>(h->comm_api)->path.c_str();
+}
+
 int hxv_comm_local_destroy(void* group) {
   LocalGroup* G = reinterpret_cast<LocalGroup*>(group);
   if (!G) return HXV_OK;
@@ -835,6 +882,7 @@ int hxv_time_apply_slab(hxv_handle* h, const void* d_v_local, void* d_hv_local, 
   for (auto& e : h->kt_ev)
     if (!e) HIPCHK(hipEventCreate(&e));
   const bool two = h->host.exchange == 2 && h->host.nranks > 1;
+  const bool ov = two && h->a2a_overlap && h->plan.usable;  // overlapped mode 2: pass A runs on the second stream, between kt_ev[4] and [5]
   double tot = 0.0, ker = 0.0;
   int rc = HXV_OK;
   h->kt_on = 1;
@@ -848,9 +896,11 @@ int hxv_time_apply_slab(hxv_handle* h, const void* d_v_local, void* d_hv_local, 
     if (e == hipSuccess) e = hipEventElapsedTime(&a, h->ev0, h->ev1);
     if (e == hipSuccess) e = hipEventElapsedTime(&b, h->kt_ev[0], h->kt_ev[1]);
     if (e == hipSuccess && two) e = hipEventElapsedTime(&c, h->kt_ev[2], h->kt_ev[3]);
+    float d = 0;
+    if (e == hipSuccess && ov) e = hipEventElapsedTime(&d, h->kt_ev[4], h->kt_ev[5]);
     if (e != hipSuccess) rc = fail(HXV_ERR_HIP, std::string("hxv_time_apply_slab: ") + hipGetErrorString(e));
     tot += a;
-    ker += b + c;
+    ker += b + c + d;  // (the kernels' own time: with the overlap, more than their share of the step)
   }
   h->kt_on = 0;
   if (rc) return rc;

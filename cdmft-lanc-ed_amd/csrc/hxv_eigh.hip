@@ -274,6 +274,7 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
   if (!h || !evals || neigen < 1 || maxrestart < 0) return fail(HXV_ERR_ARG, "hxv_eigh_lowest: bad argument");
   if (h->host.nranks != 1 && !comm_ready(h))
     return fail(HXV_ERR_STATE, "hxv_eigh_lowest on a split sector needs the communicator: call hxv_comm_init after opening the sector");
+  HIPCHK(hipSetDevice(h->device));  // (before the first collective: thread ranks on several GPUs each have their own current device)
   const int64_t dim = h->host.dim;
   if (ncv <= 0) ncv = 10 * neigen;  // the reference's default: lanc_ncv_factor=10, lanc_ncv_add=0 (ED_INPUT_VARS.f90:174-175)
   const int m = (int)std::min<int64_t>(std::max(ncv, neigen + 1), dim);

@@ -3,6 +3,7 @@
 #pragma once
 #include <algorithm>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -37,7 +38,68 @@ void launch_to_complex(const hxv_handle* h, const double* src, double2* dst, hip
 void launch_init_real(const hxv_handle* h, double* q, uint64_t seed, hipStream_t st);
 // one Lanczos step on normalised vectors through the fused product (hxv_lanczos.hip): w = H q - beta*qm, alpha = <q,w>, w -= alpha*q, |w|
 int comm_lz_homes(hxv_handle* h, bool real, double2* out[3]);
-int finish_create(hxv_handle* h, int device, hxv_handle** out);  // uploads h->host, builds the tile plan (hxv_capi.hip); deletes h on failure
+int finish_create(hxv_handle* h, int device, hxv_handle** out);  // builds the tile plan, uploads the tables of h->img (hxv_capi.hip); deletes h on failure
+
+// Device tables of a sector travel in ONE allocation and ONE host-to-device copy: a sector has ~50 of them (maps, ELL tables, tile
+// tables of both spins) and a hipMalloc + synchronous hipMemcpy each cost more than building them.  add() copies the table into a
+// host staging image at once (the caller's vector may die) and remembers where the device pointer is to be stored; commit() allocates,
+// copies and patches the pointers, which must still be alive then.
+struct TableArena {
+  struct Item {
+    size_t off;
+    void** dst;
+  };
+  std::vector<char> stage;
+  std::vector<Item> items;
+  template <typename T>
+  hipError_t add(const std::vector<T>& v, T** p) {
+    const size_t off = (stage.size() + 255) & ~(size_t)255, bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+    stage.resize(off + bytes, 0);
+    if (!v.empty()) std::memcpy(stage.data() + off, v.data(), v.size() * sizeof(T));
+    items.push_back({off, (void**)p});
+    *p = nullptr;
+    return hipSuccess;
+  }
+  // -> the base of the allocation (the caller owns it: hipFree), its size in *bytes
+  hipError_t commit(void** base, int64_t* bytes) {
+    *base = nullptr;
+    *bytes = (int64_t)std::max<size_t>(stage.size(), 256);
+    hipError_t e = hipMalloc(base, (size_t)*bytes);
+    if (e != hipSuccess) return e;
+    if (!stage.empty()) e = hipMemcpy(*base, stage.data(), stage.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return e;
+    for (const Item& it : items) *it.dst = (char*)*base + it.off;
+    items.clear();
+    std::vector<char>().swap(stage);
+    return hipSuccess;
+  }
+};
+
+// What opening a sector builds and never changes afterwards: the host description (basis maps, one-spin matrices, diagonal tables),
+// the tile plan of the default options and every device table of both.  Handles SHARE it (shared_ptr): the reference re-opens the
+// same sector for every Green's-function channel (build_Hv_sector / delete_Hv_sector around each sp_lanc_tridiag, ED_GF_NORMAL.f90:208-222),
+// and the images of closed sectors stay in a per-process cache keyed by everything that determines them (hxv_capi.hip: sector_cache).
+struct SectorImage {
+  SectorHost host;
+  DevSector dev{};
+  TilePlan plan;
+  int kernel = 1;                 // 0: too many distinct amplitudes for the tile kernels
+  int device = -1;
+  std::vector<void*> allocs;      // device allocations (the table arena)
+  int64_t device_bytes = 0, host_bytes = 0;
+  std::string key;                // full cache key (compared byte for byte); empty: not cacheable (from_csr, panels)
+  double us_host = 0, us_plan = 0, us_upload = 0;  // what building it cost (microseconds)
+  bool uploaded = false;
+  // between the host half of an open (tile plan built, every table staged) and its device half (one allocation, one copy): the staged
+  // tables and the device pointers they will be patched into
+  struct Pending;
+  std::shared_ptr<Pending> pending;
+  ~SectorImage();
+};
+// the cache of closed sectors' images (hxv_cache.cpp); an empty key means "do not cache"
+std::string sector_cache_key(const hxv_model& m, int nup, int ndw, int rank, int nranks, int device, int exchange);
+std::shared_ptr<SectorImage> sector_cache_find(const std::string& key);
+void sector_cache_insert(const std::shared_ptr<SectorImage>& im);
 bool lanczos_local_step_available(const hxv_handle* h);
 int lanczos_local_step(hxv_handle* h, bool real, const double2* q, double sq, const double2* qm, double sqm, double beta, double2* w,
                        bool sub_alpha, double* alpha, double* nrm_w);
@@ -53,7 +115,11 @@ inline bool dw_part_in_pieces(const hxv_handle* h);
   } while (0)
 
 struct hxv_handle {
-  hxv::SectorHost host;
+  std::shared_ptr<hxv::SectorImage> img;  // shared, immutable (see SectorImage); `host` below is img->host
+  hxv::SectorHost& host;
+  explicit hxv_handle(std::shared_ptr<hxv::SectorImage> i = std::make_shared<hxv::SectorImage>()) : img(std::move(i)), host(img->host) {}
+  double open_us[4] = {0, 0, 0, 0};       // this open: host build, tile plan, upload, whole call (get_option "open_us_*"); 0 0 0 on a cache hit
+  int open_cache_hit = 0;
   int device = 0;
   hipStream_t stream = nullptr;
   std::vector<void*> allocs;
@@ -84,6 +150,7 @@ struct hxv_handle {
   int kernel = 1;
   // split sector: RCCL communicator over the nranks handles (hxv_comm_init) and the gathered vector
   void* comm = nullptr;          // ncclComm_t
+  int comm_aborted = 0;          // hxv_comm_abort has run on `comm` (freed by ncclCommAbort: never destroyed again, never used again)
   void* comm_api = nullptr;      // the RCCL entry points that communicator was created with (hxv_comm.cpp: the system's librccl, or HXV_RCCL_LIB)
   void* lgroup = nullptr;        // thread ranks of one process (hxv_comm_init_local): the group object, see hxv_comm.cpp
   const char* xfer_send = nullptr;         // thread ranks: what this rank offers in the column exchange under way (comm_sendrecv_cols)
@@ -104,7 +171,7 @@ struct hxv_handle {
   int64_t h2d_bytes = 0, d2h_bytes = 0;  // vector-sized PCIe traffic of the host-array entry points and hxv_vector_from/to_host (hxv_get_stats)
   int64_t device_bytes = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  hipEvent_t kt_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // hxv_time_apply_slab: events around the kernels of a slab product (two regions in exchange mode 2)
+  hipEvent_t kt_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // hxv_time_apply_slab: events around the kernels of a slab product (two regions in exchange mode 2; [4], [5]: pass A on the second stream of its overlapped form)
   int kt_on = 0;
 
   template <typename T>

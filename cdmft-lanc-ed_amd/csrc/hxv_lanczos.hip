@@ -686,14 +686,15 @@ extern "C" {
 int hxv_lanczos_tridiag(hxv_handle* h, const void* d_vin, int32_t nlanc, double* alanc, double* blanc, double threshold,
                         int32_t* nsteps) {
   if (!h) return fail(HXV_ERR_ARG, "hxv_lanczos_tridiag: NULL handle");
+  HIPCHK(hipSetDevice(h->device));  // (before the first collective: thread ranks on several GPUs each have their own current device)
   // (split sector: a rank whose arguments are bad tells its peers instead of leaving them in the first all-reduce)
   if (int rca = comm_agree(h, (!d_vin || nlanc < 1 || !alanc || !blanc) ? fail(HXV_ERR_ARG, "hxv_lanczos_tridiag: bad argument") : HXV_OK)) return rca;
-  HIPCHK(hipSetDevice(h->device));
   const int64_t n = (int64_t)h->host.pitch * h->host.qdw;  // this rank's slab
   StageFree staged{h, {nullptr, nullptr}};
   // REAL-vector mode: H real and the start vector purely real (c / c^dagger applied to a real ground state is) ->
   // the whole recurrence stays real; alanc/blanc are the same numbers at half the bytes per pass
   bool real = want_real(h);
+  int rc_pre = HXV_OK;
   if (h->host.nranks != 1 && !comm_ready(h))
     return fail(HXV_ERR_STATE, "device Lanczos on a split sector needs the communicator: call hxv_comm_init after opening the sector");
   if (real) {  // sum of Im(vin)^2 over ALL ranks (dst = null: reduction only): every rank must take the same path
@@ -701,14 +702,14 @@ int hxv_lanczos_tridiag(hxv_handle* h, const void* d_vin, int32_t nlanc, double*
     const int g = grid_for((int64_t)pr * h->host.qdw);
     hipLaunchKernelGGL(lz_to_real, dim3(g), dim3(256), 0, h->stream, h->host.dimup, h->host.qdw, h->host.pitch, pr,
                        (const double2*)d_vin, (double*)nullptr, h->d_partials);
-    int rci = reduce_scalar(h, h->d_partials, g, 5, 0);
-    if (rci) return rci;
+    // (a rank that fails here must still meet its peers in the agreement below, not leave them there: ADVICE r4)
+    rc_pre = reduce_scalar(h, h->d_partials, g, 5, 0);
     double im2 = 0.0;
-    HIPCHK(hipMemcpyAsync(&im2, h->d_scalars + 5, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    if (!rc_pre && hipMemcpyAsync(&im2, h->d_scalars + 5, sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc_pre = fail(HXV_ERR_HIP, "hxv_lanczos_tridiag: reading the real-vector check failed");
+    if (!rc_pre && hipStreamSynchronize(h->stream) != hipSuccess) rc_pre = fail(HXV_ERR_HIP, "hxv_lanczos_tridiag: the real-vector check failed");
     real = im2 == 0.0;
   }
-  int rc = stage_start_vector(h, d_vin, &staged.p[0]);  // (a start vector at hxv_slab_home: staged before its home is cleared)
+  int rc = rc_pre ? rc_pre : stage_start_vector(h, d_vin, &staged.p[0]);  // (a start vector at hxv_slab_home: staged before its home is cleared)
   rc = comm_agree(h, rc ? rc : ensure_lz(h, real));  // (a rank that could not allocate tells its peers before the first all-reduce)
   if (rc) return rc;
   LzRunner lz(h, h->lz_vec[0], h->lz_vec[1], h->lz_vec[2], real);
@@ -811,6 +812,7 @@ int hxv_lanczos_tridiag(hxv_handle* h, const void* d_vin, int32_t nlanc, double*
 
 int hxv_lanczos_eigh(hxv_handle* h, int32_t nitermax, double threshold, double* egs, void* d_vect, int32_t* niter) {
   if (!h || nitermax < 1 || !egs) return fail(HXV_ERR_ARG, "hxv_lanczos_eigh: bad argument");
+  HIPCHK(hipSetDevice(h->device));  // (before the first collective)
   const bool real = want_real(h);  // the start vector is ours: real when H is (REAL-vector mode)
   int rc = comm_agree(h, ensure_lz(h, real));
   if (rc) return rc;

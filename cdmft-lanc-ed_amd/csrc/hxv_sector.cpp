@@ -13,7 +13,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
-#include <map>
+#include <thread>
 
 #include "hxv_internal.hpp"
 
@@ -118,42 +118,60 @@ std::string one_body(const ModelView& mv, int spin, std::vector<Hop>& hops, std:
 inline int parity_below(uint32_t m, int pos) { return __builtin_popcount(m & ((1u << pos) - 1u)) & 1; }
 
 // H_sigma(i,j) for all basis states: rows collect (j, value) in ascending j, i.e. the
-// reference's row-list order (it loops over the source state j outermost).
-void apply_hops(const std::vector<uint32_t>& map, const std::vector<Hop>& hops, SpinOp& op) {
-  int dim = (int)map.size();
+// reference's row-list order (it loops over the source state j outermost).  Entries are generated source-major and brought to
+// rows by a stable counting sort; two hops that land on the same (row, column) -- only possible when the hop LIST holds the same
+// ordered orbital pair twice -- are summed in list order where the first of them stands (ED_SPARSE_MATRIX.f90:267-273).
+void apply_hops(const std::vector<uint32_t>& map, const std::vector<Hop>& hops_in, int ns, SpinOp& op) {
+  const int dim = (int)map.size();
   op.dim = dim;
-  std::vector<std::vector<std::pair<int32_t, cplx>>> rows(dim);
+  // same (a <- b) twice in the list: one hop with the summed amplitude at the first one's place (sign flips are exact, so
+  // +-t1 +-t2 summed per element is bit for bit +-(t1 + t2))
+  std::vector<Hop> hops;
+  hops.reserve(hops_in.size());
+  for (const Hop& h : hops_in) {
+    bool dup = false;
+    for (Hop& g : hops)
+      if (g.a == h.a && g.b == h.b) {
+        g.t += h.t;
+        dup = true;
+        break;
+      }
+    if (!dup) hops.push_back(h);
+  }
+  // index of a configuration: a table over all ns-bit integers where that is small, else binary search in the sorted map
+  std::vector<int32_t> index_of;
+  if (ns <= 20) {
+    index_of.assign((size_t)1 << ns, -1);
+    for (int j = 0; j < dim; ++j) index_of[map[j]] = j;
+  }
+  struct Trip {
+    int32_t i, j;
+    cplx v;
+  };
+  std::vector<Trip> trips;
+  trips.reserve((size_t)dim * 16);
+  std::vector<int64_t> count(dim + 1, 0);
   for (int j = 0; j < dim; ++j) {
-    uint32_t m = map[j];
+    const uint32_t m = map[j];
     for (const Hop& h : hops) {
       if (!((m >> h.b) & 1u) || ((m >> h.a) & 1u)) continue;
-      uint32_t m1 = m & ~(1u << h.b);
-      int sgn = parity_below(m, h.b) ^ parity_below(m1, h.a);
-      uint32_t m2 = m1 | (1u << h.a);
-      int i = (int)(std::lower_bound(map.begin(), map.end(), m2) - map.begin());
-      cplx val = sgn ? -h.t : h.t;
-      auto& r = rows[i];
-      bool dup = false;
-      for (auto& e : r)
-        if (e.first == j) {  // ED_SPARSE_MATRIX.f90:267-273: same (row,col) -> summed
-          e.second += val;
-          dup = true;
-          break;
-        }
-      if (!dup) r.emplace_back(j, val);
+      const uint32_t m1 = m & ~(1u << h.b);
+      const int sgn = parity_below(m, h.b) ^ parity_below(m1, h.a);
+      const uint32_t m2 = m1 | (1u << h.a);
+      const int i = index_of.empty() ? (int)(std::lower_bound(map.begin(), map.end(), m2) - map.begin()) : index_of[m2];
+      trips.push_back({i, j, sgn ? -h.t : h.t});
+      ++count[i + 1];
     }
   }
   op.rowptr.assign(dim + 1, 0);
-  for (int i = 0; i < dim; ++i) op.rowptr[i + 1] = op.rowptr[i] + (int64_t)rows[i].size();
-  op.cols.resize((size_t)op.rowptr[dim]);
-  op.vals.resize((size_t)op.rowptr[dim]);
-  for (int i = 0; i < dim; ++i) {
-    int64_t p = op.rowptr[i];
-    for (auto& e : rows[i]) {
-      op.cols[p] = e.first;
-      op.vals[p] = e.second;
-      ++p;
-    }
+  for (int i = 0; i < dim; ++i) op.rowptr[i + 1] = op.rowptr[i] + count[i + 1];
+  op.cols.resize(trips.size());
+  op.vals.resize(trips.size());
+  std::vector<int64_t> fill(op.rowptr.begin(), op.rowptr.end() - 1);
+  for (const Trip& t : trips) {
+    const int64_t p = fill[t.i]++;
+    op.cols[p] = t.j;
+    op.vals[p] = t.v;
   }
 }
 
@@ -280,13 +298,14 @@ std::vector<uint32_t> translate_ell_src(const std::vector<uint32_t>& ell, const 
 
 std::string build_ell(SpinOp& op) {
   if (op.dim > (1 << ELL_SRC_BITS)) return "spin-sector dimension exceeds 2^20 (ELL source index)";
-  std::map<std::pair<double, double>, int> ids;
   op.coef.clear();
   op.real_vals = true;
   int K = 0;
   for (int i = 0; i < op.dim; ++i) K = std::max<int>(K, (int)(op.rowptr[i + 1] - op.rowptr[i]));
   op.K = K;
   op.ell.assign((size_t)std::max(K, 1) * op.dim, ELL_EMPTY);
+  // distinct |amplitudes| in order of first appearance (a handful: the last one found is tried first)
+  int last = -1;
   for (int i = 0; i < op.dim; ++i) {
     int k = 0;
     for (int64_t p = op.rowptr[i]; p < op.rowptr[i + 1]; ++p, ++k) {
@@ -297,17 +316,21 @@ std::string build_ell(SpinOp& op) {
         sign = 1;
       }
       if (c.imag() != 0.0) op.real_vals = false;
-      auto key = std::make_pair(c.real(), c.imag());
-      auto it = ids.find(key);
-      int id;
-      if (it == ids.end()) {
+      int id = -1;
+      if (last >= 0 && op.coef[last] == c)
+        id = last;
+      else
+        for (int q = 0; q < (int)op.coef.size(); ++q)
+          if (op.coef[q] == c) {
+            id = q;
+            break;
+          }
+      if (id < 0) {
         id = (int)op.coef.size();
         if (id >= MAX_COEF) return "more than 1023 distinct hopping amplitudes";
-        ids.emplace(key, id);
         op.coef.push_back(c);
-      } else {
-        id = it->second;
       }
+      last = id;
       op.ell[(size_t)k * op.dim + i] = (uint32_t)op.cols[p] | ((uint32_t)id << ELL_SRC_BITS) | (sign << 31);
     }
   }
@@ -340,6 +363,7 @@ std::string build_sector_from_model(const hxv_model& m, int nup, int ndw, int ra
 
   std::vector<Hop> hops_up, hops_dw;
   std::vector<double> eps_up, eps_dw;
+  bool twin_spins = false;  // H_up and H_dw are the same matrix (Nspin = 1 or equal spin blocks, nup = ndw): built once
   std::string e = one_body(mv, 0, hops_up, eps_up);          // spin index 1       (H_up.f90:14)
   if (!e.empty()) return e;
   e = one_body(mv, m.nspin - 1, hops_dw, eps_dw);            // spin index Nspin   (H_dw.f90:14)
@@ -358,9 +382,22 @@ std::string build_sector_from_model(const hxv_model& m, int nup, int ndw, int ra
     s.up.dim = panel_rows;
     s.up.rowptr.assign(panel_rows + 1, 0);
   } else {
-    apply_hops(s.map_up, hops_up, s.up);
   }
-  apply_hops(s.map_dw, hops_dw, s.dw);
+  {
+    // the two one-spin matrices are independent: one host thread each (equal spins and fillings: one build, one copy)
+    auto same_hops = [&]() {
+      if (hops_up.size() != hops_dw.size()) return false;
+      for (size_t q = 0; q < hops_up.size(); ++q)
+        if (hops_up[q].a != hops_dw[q].a || hops_up[q].b != hops_dw[q].b || hops_up[q].t != hops_dw[q].t) return false;
+      return true;
+    };
+    const bool twin = panel_rows == 0 && nup == ndw && same_hops();
+    std::thread th;
+    if (panel_rows == 0 && !twin) th = std::thread([&] { apply_hops(s.map_up, hops_up, ns, s.up); });
+    apply_hops(s.map_dw, hops_dw, ns, s.dw);
+    if (th.joinable()) th.join();
+    twin_spins = twin;
+  }
   // (the spH0nd block reaches columns that H_dw does not: it keeps the all-gather layout)
   if (nranks > 1 && panel_rows == 0 && default_exchange() == 1) {
     if (m.norb > 1 && (m.jx != 0.0 || m.jp != 0.0)) {
@@ -388,10 +425,16 @@ std::string build_sector_from_model(const hxv_model& m, int nup, int ndw, int ra
   // (exchange 2 = the reference's two transposes: the all-gather layout stays, only the product's exchange differs)
   // (its row panels need a row for every rank: tiny sectors keep the all-gather)
   if (nranks > 1 && nranks <= s.dimup && panel_rows == 0 && default_exchange() == 2 && !(m.norb > 1 && (m.jx != 0.0 || m.jp != 0.0))) s.exchange = 2;
-  e = build_ell(s.up);
-  if (!e.empty()) return e;
-  e = build_ell(s.dw);
-  if (!e.empty()) return e;
+  {
+    std::string e_up;
+    std::thread th;
+    if (!twin_spins) th = std::thread([&] { e_up = build_ell(s.up); });
+    e = build_ell(s.dw);
+    if (th.joinable()) th.join();
+    if (!e_up.empty()) return e_up;
+    if (!e.empty()) return e;
+    if (twin_spins) s.up = s.dw;
+  }
 
   // ---- diagonal: D(iup,idw) = a_up[iup] + a_dw[idw] + cross(mup,mdw)   (H_local.f90:21-93)
   const int L = m.nlat, O = m.norb, nimp = L * O;

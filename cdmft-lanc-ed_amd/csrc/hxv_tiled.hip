@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <numeric>
 #include <type_traits>
 
@@ -1142,9 +1143,10 @@ std::string make_tile_plan(const SectorHost& s, TilePlan& plan, const PlanUpload
   plan.ncoef_dw = (int)s.dw.coef.size();
   plan.usable = plan.ncoef_up <= TILE_MAX_COEF && plan.ncoef_dw <= TILE_MAX_COEF;
   if (!plan.usable) return "";
-  HostTiles h;
-  auto one = [&](const SpinOp& op, const std::vector<uint32_t>& map, int npart, int width, int force, int budget_kb, int max_block,
-                 const std::vector<uint32_t>* vcol, bool sorted_out, int sort_mode, SpinTiles& t) -> std::string {
+  // the two spins' tables are independent: built on one host thread each, handed to the uploader afterwards (it is not re-entrant)
+  HostTiles hu, hd;
+  auto build = [&](const SpinOp& op, const std::vector<uint32_t>& map, int npart, int width, int force, int budget_kb, int max_block,
+                   const std::vector<uint32_t>* vcol, bool sorted_out, int sort_mode, SpinTiles& t, HostTiles& h) -> std::string {
     const int tile_rows = sorted_out ? 0 : width;
     const int budget = budget_kb * 1024 - 16 * (2 * (int)op.coef.size() + 1);
     int L = 32, chunk = std::max(1, std::min(budget / (16 * width), max_block));
@@ -1152,6 +1154,9 @@ std::string make_tile_plan(const SectorHost& s, TilePlan& plan, const PlanUpload
     build_spin_tiles(op, map, L, chunk, vcol, sort_mode, sorted_out, tile_rows, o.spread_banks != 0, t, h);
     if ((int64_t)t.max_block * width * 16 + 16 * (2 * (int64_t)op.coef.size() + 1) > 160 * 1024) return "tile does not fit the 160 KB LDS";
     if (t.max_block > max_block) return "block larger than the workgroup (one thread per block row/column)";
+    return "";
+  };
+  auto send = [&](HostTiles& h, SpinTiles& t) -> std::string {
     if (up.u32(h.start, &t.d_start) != hipSuccess || up.u32(h.perm, &t.d_perm) != hipSuccess ||
         up.u32(h.gstart, &t.d_gstart) != hipSuccess || up.u32(h.gmax, &t.d_gmax) != hipSuccess ||
         up.u32(h.ell_in, &t.d_ell_in) != hipSuccess || up.u32(h.tstart, &t.d_tstart) != hipSuccess ||
@@ -1165,12 +1170,20 @@ std::string make_tile_plan(const SectorHost& s, TilePlan& plan, const PlanUpload
     return "";
   };
   static const std::vector<uint32_t> no_map;  // panel handles have no up basis: plain index chunks (pass A never runs)
-  std::string e = one(s.up, s.panel_rows > 0 ? no_map : s.map_up, s.nup, o.cols_per_tile, o.force_bits_up, o.lds_budget_kb_up, o.threads_up, nullptr, true, 0,
-                      plan.up);
-  if (!e.empty()) return e;
+  std::string e_up, e;
+  std::thread th([&] {
+    e_up = build(s.up, s.panel_rows > 0 ? no_map : s.map_up, s.nup, o.cols_per_tile, o.force_bits_up, o.lds_budget_kb_up, o.threads_up, nullptr, true, 0,
+                 plan.up, hu);
+  });
   // pass B sorts by the inner count only: its outer table is read in natural column order
-  e = one(s.dw, s.map_dw, s.ndw, o.rows_per_tile, o.force_bits_dw, o.lds_budget_kb_dw, o.threads_dw, &s.vcol, false,
-          o.sort_mode_dw ? 1 : 0, plan.dw);
+  e = build(s.dw, s.map_dw, s.ndw, o.rows_per_tile, o.force_bits_dw, o.lds_budget_kb_dw, o.threads_dw, &s.vcol, false, o.sort_mode_dw ? 1 : 0, plan.dw,
+            hd);
+  th.join();
+  if (!e_up.empty()) return e_up;
+  if (!e.empty()) return e;
+  e = send(hu, plan.up);
+  if (!e.empty()) return e;
+  e = send(hd, plan.dw);
   if (!e.empty()) return e;
   if (up.d2(signed_coefs(s.up), &plan.d_scoef_up) != hipSuccess || up.d2(signed_coefs(s.dw), &plan.d_scoef_dw) != hipSuccess)
     return "upload of coefficient tables failed";

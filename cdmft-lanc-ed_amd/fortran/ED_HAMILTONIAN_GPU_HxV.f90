@@ -48,9 +48,23 @@ module ED_HAMILTONIAN_GPU_HXV
   type :: gpu_vector
      type(c_ptr) :: d      = c_null_ptr    !device buffer (include/hxv.h: hxv_vector_alloc)
      type(c_ptr) :: sector = c_null_ptr    !the sector (engine handle) it belongs to
-     logical     :: owns_sector = .false.  !gpu_keep_sector: that sector stays open for this vector until gpu_free_vector
-     logical     :: view = .false.         !part of another vector's allocation (eigenvectors 2.. of gpu_sp_eigh_dev): freed with the first
+     logical     :: owns_sector = .false.  !gpu_keep_sector was called with this vector (informational: the sector's life is counted, below)
+     logical     :: view = .false.         !part of another vector's allocation (eigenvectors 2.. of gpu_sp_eigh_dev)
+     type(c_ptr) :: base   = c_null_ptr    !the allocation it lives in (= d unless a view)
   end type gpu_vector
+
+  !Lifetimes are COUNTED, so vectors may be freed in any order (ADVICE r4): an allocation goes back to the engine when the last
+  !gpu_vector in it is freed (the eigenvectors of gpu_sp_eigh_dev share one), and a kept sector (gpu_keep_sector) is closed when the last
+  !vector made on it is freed -- whichever vector that is.  A sector closed by gpu_delete_Hv_sector while vectors of it are still alive
+  !takes their memory with it (hxv_destroy returns it): those vectors become empty shells and freeing them later is a no-op.
+  type :: ref_entry
+     type(c_ptr) :: key  = c_null_ptr
+     integer     :: n    = 0
+     logical     :: kept = .false.         !sectors: stays open until its last vector is freed
+     logical     :: dead = .false.         !sectors: destroyed while vectors were alive
+  end type ref_entry
+  integer,parameter    :: MAXREF=512
+  type(ref_entry),save :: sector_refs(MAXREF), alloc_refs(MAXREF)
 
   !> SciFortran's drivers are generic in exactly this way: the serial form takes the product first, the MPI form the
   !! communicator first (call sites ED_DIAG.f90:152-156,161-165,176-184; ED_GF_NORMAL.f90:215,217).  Both forms end in
@@ -316,9 +330,47 @@ contains
          int(MpiSize,c_int32_t),int(dev,c_int32_t),handle),"gpu_build_Hv_sector")
   end subroutine gpu_build_Hv_sector
 
+  !---- reference tables of the device vectors (see type ref_entry) ----
+  integer function ref_find(tab,key) result(i)
+    type(ref_entry),intent(in) :: tab(:)
+    type(c_ptr),intent(in)     :: key
+    do i=1,size(tab)
+       if(tab(i)%n>0.and.c_associated(tab(i)%key,key))return
+    enddo
+    i=0
+  end function ref_find
+  subroutine ref_add(tab,key)
+    type(ref_entry),intent(inout) :: tab(:)
+    type(c_ptr),intent(in)        :: key
+    integer                       :: i
+    i=ref_find(tab,key)
+    if(i==0)then
+       do i=1,size(tab)
+          if(tab(i)%n==0)exit
+       enddo
+       if(i>size(tab))stop "ED_HAMILTONIAN_GPU_HxV ERROR: more than 512 live device vectors / sectors"
+       tab(i)%key=key; tab(i)%kept=.false.; tab(i)%dead=.false.
+    endif
+    tab(i)%n=tab(i)%n+1
+  end subroutine ref_add
+  !a new gpu_vector in allocation `base` of sector `sector`
+  subroutine vec_born(vect,sector,base,view)
+    type(gpu_vector),intent(inout) :: vect
+    type(c_ptr),intent(in)         :: sector,base
+    logical,intent(in)             :: view
+    vect%sector=sector; vect%base=base; vect%view=view; vect%owns_sector=.false.
+    call ref_add(alloc_refs,base)
+    call ref_add(sector_refs,sector)
+  end subroutine vec_born
+
   !> delete_Hv_sector hook (ED_HAMILTONIAN.f90:149-190)
   subroutine gpu_delete_Hv_sector()
-    if(c_associated(handle))call check(hxv_destroy(handle),"gpu_delete_Hv_sector")
+    integer :: i
+    if(c_associated(handle))then
+       i=ref_find(sector_refs,handle)
+       if(i>0)sector_refs(i)%dead=.true.   !vectors of this sector are still alive: hxv_destroy takes their memory back, their shells stay
+       call check(hxv_destroy(handle),"gpu_delete_Hv_sector")
+    endif
     handle=c_null_ptr
   end subroutine gpu_delete_Hv_sector
 
@@ -533,7 +585,7 @@ contains
     if(.not.c_associated(handle))stop "gpu_sp_lanc_eigh_dev ERROR: Hsector NOT set"
     if(c_associated(vect%d))stop "gpu_sp_lanc_eigh_dev ERROR: the vector is in use (gpu_free_vector it first)"
     call check(hxv_vector_alloc(handle,vect%d),"gpu_sp_lanc_eigh_dev")
-    vect%sector=handle; vect%owns_sector=.false.
+    call vec_born(vect,handle,vect%d,.false.)
     thr=1d-12; if(present(threshold))thr=max(threshold,1d-15)
     call check(hxv_lanczos_eigh(handle,int(Nitermax,c_int32_t),thr,egs,vect%d,niter),"gpu_sp_lanc_eigh_dev")
     if(present(iverbose))then
@@ -542,7 +594,7 @@ contains
   end subroutine gpu_sp_lanc_eigh_dev
 
   !> sp_eigh (the default lanc_method="arpack" call, ED_DIAG.f90:152-160) with the eigenvectors left on the device: vects(1:size(eval)), all in
-  !! one allocation that vects(1) owns (gpu_free_vector(vects(1)) releases them all; the others are views).  Any of them can be handed to
+  !! one allocation that is returned to the engine when the LAST of them is freed (any order).  Any of them can be handed to
   !! gpu_keep_sector / gpu_apply_ladder like the vector of gpu_sp_lanc_eigh_dev.
   subroutine gpu_sp_eigh_dev(eval,vects,Nblock,Nitermax,tol,iverbose)
     real(8),intent(inout)          :: eval(:)
@@ -568,8 +620,8 @@ contains
     stride=hxv_localvec_elems(handle)
     call c_f_pointer(vects(1)%d,base,[stride*size(eval)])      !(address arithmetic only: the memory is on the device)
     do i=1,size(eval)
-       vects(i)%sector=handle; vects(i)%owns_sector=.false.; vects(i)%view=(i>1)
        if(i>1)vects(i)%d=c_loc(base(1+(i-1)*stride))
+       call vec_born(vects(i),handle,vects(1)%d,i>1)
     enddo
     call check(hxv_eigh_lowest(handle,int(size(eval),c_int32_t),ncv,nit,tl,eval,vects(1)%d,nconv,nmv),"gpu_sp_eigh_dev")
     if(present(iverbose))then
@@ -577,12 +629,17 @@ contains
     endif
   end subroutine gpu_sp_eigh_dev
 
-  !> The open sector stays open FOR this vector (it is needed again when c / c^dagger act on it); the module's "one open sector" slot
-  !! becomes free, so build_Hv_sector of another sector may follow.  gpu_free_vector closes the kept sector.
+  !> The open sector stays open for the vectors made on it (it is needed again when c / c^dagger act on them); the module's "one open
+  !! sector" slot becomes free, so build_Hv_sector of another sector may follow.  The kept sector is closed when the LAST vector made on
+  !! it is freed (gpu_free_vector), in whatever order -- eigenvectors 2.. of gpu_sp_eigh_dev included.
   subroutine gpu_keep_sector(vect)
     type(gpu_vector),intent(inout) :: vect
+    integer                        :: i
     if(.not.c_associated(handle))stop "gpu_keep_sector ERROR: Hsector NOT set"
     if(.not.c_associated(vect%sector,handle))stop "gpu_keep_sector ERROR: the vector does not belong to the open sector"
+    i=ref_find(sector_refs,handle)
+    if(i==0)stop "gpu_keep_sector ERROR: no live vector of the open sector"
+    sector_refs(i)%kept=.true.
     vect%owns_sector=.true.
     handle=c_null_ptr
   end subroutine gpu_keep_sector
@@ -606,7 +663,7 @@ contains
     if(.not.c_associated(out%d))then
        if(acc==1)stop "gpu_apply_ladder ERROR: accumulate into an empty vector"
        call check(hxv_vector_alloc(handle,out%d),"gpu_apply_ladder")
-       out%sector=handle; out%owns_sector=.false.
+       call vec_born(out,handle,out%d,.false.)
     endif
     if(.not.c_associated(out%sector,handle))stop "gpu_apply_ladder ERROR: the target vector does not belong to the open sector"
     cr=0; if(create)cr=1
@@ -659,17 +716,35 @@ contains
     if(.not.c_associated(vect%d))then
        if(.not.c_associated(handle))stop "gpu_vector_from_host ERROR: Hsector NOT set"
        call check(hxv_vector_alloc(handle,vect%d),"gpu_vector_from_host")
-       vect%sector=handle; vect%owns_sector=.false.
+       call vec_born(vect,handle,vect%d,.false.)
     endif
     if(int(size(v),c_int64_t)/=hxv_vecdim(vect%sector))stop "gpu_vector_from_host ERROR: size(v) /= vecDim of the vector's sector"
     call check(hxv_vector_from_host(vect%sector,v,vect%d),"gpu_vector_from_host")
   end subroutine gpu_vector_from_host
 
+  !> Any order: the allocation goes back when its last vector is freed, a kept sector is closed when its last vector is freed.
   subroutine gpu_free_vector(vect)
     type(gpu_vector),intent(inout) :: vect
-    if(c_associated(vect%d).and..not.vect%view)call check(hxv_vector_free(vect%sector,vect%d),"gpu_free_vector")
-    if(vect%owns_sector.and.c_associated(vect%sector))call check(hxv_destroy(vect%sector),"gpu_free_vector")
-    vect%d=c_null_ptr; vect%sector=c_null_ptr; vect%owns_sector=.false.; vect%view=.false.
+    integer                        :: ia,is
+    if(c_associated(vect%d))then
+       is=ref_find(sector_refs,vect%sector)
+       ia=ref_find(alloc_refs,vect%base)
+       if(is==0.or.ia==0)stop "gpu_free_vector ERROR: not a live device vector (a copy of one that was freed already?)"
+       alloc_refs(ia)%n=alloc_refs(ia)%n-1
+       if(alloc_refs(ia)%n==0)then
+          if(.not.sector_refs(is)%dead)call check(hxv_vector_free(vect%sector,vect%base),"gpu_free_vector")
+          alloc_refs(ia)%key=c_null_ptr
+       endif
+       sector_refs(is)%n=sector_refs(is)%n-1
+       if(sector_refs(is)%n==0)then
+          if(sector_refs(is)%kept.and..not.sector_refs(is)%dead)then
+             if(c_associated(vect%sector,handle))handle=c_null_ptr   !(kept sectors are never the open one; belt and braces)
+             call check(hxv_destroy(vect%sector),"gpu_free_vector")
+          endif
+          sector_refs(is)%key=c_null_ptr; sector_refs(is)%kept=.false.; sector_refs(is)%dead=.false.
+       endif
+    endif
+    vect%d=c_null_ptr; vect%sector=c_null_ptr; vect%base=c_null_ptr; vect%owns_sector=.false.; vect%view=.false.
   end subroutine gpu_free_vector
 
   !> Vector-sized bytes the engine has moved over PCIe for a sector since it was opened (include/hxv.h: hxv_stats): the open sector,

@@ -257,6 +257,30 @@ contains
     spHtimesV_p => null()
     call gpu_delete_Hv_sector()
     call gpu_free_vector(gs)
+    !--- lifetimes in the awkward order (ADVICE r4): the sector is kept through a VIEW (eigenvector 2 of gpu_sp_eigh_dev), the first
+    !    eigenvector -- whose pointer is the allocation -- is freed first, and a further vector made on the kept sector outlives the keeper
+    block
+      type(gpu_vector) :: ev(2),extra,w1,w2
+      real(8) :: e2(2),n2c,n2d
+      complex(8),allocatable :: back(:)
+      call gpu_build_Hv_sector(Nlat,Norb,Nspin,Nbath,6,6,impHloc,Hbath,Vbath,Uloc,0d0,0d0,0d0,0d0,0d0,.true.,0,1)
+      call gpu_sp_eigh_dev(e2,ev,20,512,tol=1d-18)
+      call gpu_vector_from_host(psi,extra)                 !a third vector on the same sector
+      call gpu_keep_sector(ev(2))                          !kept through the view
+      call gpu_build_Hv_sector(Nlat,Norb,Nspin,Nbath,7,6,impHloc,Hbath,Vbath,Uloc,0d0,0d0,0d0,0d0,0d0,.true.,0,1)
+      call gpu_apply_ladder(ev(1),ipos,ispin,.true.,w1,n2c)
+      call gpu_free_vector(ev(1))                          !the allocation must survive: ev(2) lives in it
+      call gpu_apply_ladder(ev(2),ipos,ispin,.true.,w2,n2d)
+      call gpu_free_vector(w1); call gpu_free_vector(w2)
+      call gpu_free_vector(ev(2))                          !the keeper goes; `extra` still needs the sector
+      allocate(back(dimA))
+      call gpu_vector_to_host(extra,back)
+      call gpu_free_vector(extra)                          !last vector of the kept sector: closes it
+      call gpu_delete_Hv_sector()
+      write(*,"(A,ES12.4,A,ES12.4,A,ES12.4)")"GF lifetimes any order: |norm2(ev1) - norm2(gs)|=",abs(n2c-norm2)," norm2(ev2)=",n2d,&
+           " max|roundtrip - psi|=",maxval(abs(back-psi))
+      deallocate(back)
+    end block
     deallocate(psi,vvinit,map6,map7,pos7)
   end subroutine gf_channel_on_device
 

@@ -47,6 +47,7 @@ EXPORTS = [
     "hxv_set_exchange_default", "hxv_exchange_mode", "hxv_halo_counts", "hxv_halo_lists", "hxv_halo_plan_from_csr",
     "hxv_comm_local_create", "hxv_comm_init_local", "hxv_comm_local_destroy", "hxv_comm_local_abort", "hxv_time_apply_slab",
     "hxv_vector_alloc", "hxv_vector_alloc_many", "hxv_vector_free", "hxv_vector_from_host", "hxv_vector_to_host",
+    "hxv_sector_cache_clear", "hxv_sector_cache_stats", "hxv_comm_abort", "hxv_comm_library",
 ]
 
 _lib = None
@@ -138,6 +139,11 @@ def load_library():
     L.hxv_comm_init_local.argtypes = [vp, vp]
     L.hxv_comm_local_destroy.argtypes = [vp]
     L.hxv_comm_local_abort.argtypes = [vp]
+    L.hxv_comm_abort.argtypes = [vp]
+    L.hxv_comm_library.argtypes = [vp]
+    L.hxv_comm_library.restype = C.c_char_p
+    L.hxv_sector_cache_clear.argtypes = []
+    L.hxv_sector_cache_stats.argtypes = [pi64, pi64, pi64, pi64]
     _lib = L
     return L
 
@@ -158,6 +164,17 @@ def pool_stats(device: int = 0) -> dict:
     c, h, m = C.c_int64(), C.c_int64(), C.c_int64()
     load_library().hxv_pool_stats(device, C.byref(c), C.byref(h), C.byref(m))
     return {"cached_bytes": c.value, "hits": h.value, "misses": m.value}
+
+
+def sector_cache_clear():
+    """Drop the images of closed sectors (include/hxv.h, sector-image cache)."""
+    load_library().hxv_sector_cache_clear()
+
+
+def sector_cache_stats() -> dict:
+    e, b, h, m = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+    load_library().hxv_sector_cache_stats(C.byref(e), C.byref(b), C.byref(h), C.byref(m))
+    return {"entries": e.value, "bytes": b.value, "hits": h.value, "misses": m.value}
 
 
 def halo_plan_from_csr(dimdw: int, rowptr, cols, rank: int, nranks: int):
@@ -209,14 +226,26 @@ class RcclGroup:
     (tests/rccl_double) to run the engine's RCCL branches with several ranks on one GPU."""
 
     def __init__(self, nranks: int):
+        import threading
+
         self.nranks = nranks
         self.id = HxvSector.comm_unique_id()
+        self._joined = []
+        self._lock = threading.Lock()
 
     def join(self, sec: "HxvSector"):
         sec.comm_init(self.id)
+        with self._lock:
+            self._joined.append(sec)
 
     def abort(self):
-        pass  # (RCCL has no abort the engine uses; the double's waits time out)
+        """A rank's thread failed outside the library: ncclCommAbort on every communicator that has joined (hxv_comm_abort), so peers
+        blocked in a collective return an error.  (A rank lost BEFORE ncclCommInitRank completed cannot be helped: no communicator yet.)"""
+        with self._lock:
+            secs = list(self._joined)
+        for s in secs:
+            if getattr(s, "_h", None):
+                load_library().hxv_comm_abort(s._h)
 
     def close(self):
         pass
@@ -469,6 +498,14 @@ class HxvSector:
 
     def comm_free(self):
         _chk(load_library().hxv_comm_free(self._h), "hxv_comm_free")
+
+    def comm_abort(self):
+        _chk(load_library().hxv_comm_abort(self._h), "hxv_comm_abort")
+
+    @property
+    def comm_library(self) -> str:
+        """File the RCCL entry points of this handle's communicator came from (hxv_comm_library)."""
+        return load_library().hxv_comm_library(self._h).decode()
 
     def slab_home(self):
         """This rank's slot of the engine's gather buffer as a torch complex128 CUDA tensor of localElems elements: a vector built

@@ -103,6 +103,15 @@ int hxv_apply_host(hxv_handle *h, int64_t nloc, const void *v, void *hv);
 int hxv_comm_unique_id(void *id128);
 int hxv_comm_init(hxv_handle *h, const void *id128);
 int hxv_comm_free(hxv_handle *h);
+/* A rank has failed OUTSIDE the library (its host thread / process raised before its next collective): wake this handle's rank instead of
+ * leaving it inside a collective waiting for the lost peer.  RCCL communicators: ncclCommAbort -- callable from another host thread while
+ * the handle's own thread blocks in a collective; that collective returns an error, the communicator is gone (later calls report a missing
+ * communicator; hxv_comm_free / hxv_destroy still clean up).  Thread-rank groups: same as hxv_comm_local_abort.  HXV_ERR_UNSUPPORTED when
+ * the RCCL library in use exports no ncclCommAbort.                                                                                */
+int hxv_comm_abort(hxv_handle *h);
+/* The file the RCCL entry points of this handle's communicator were resolved from (dladdr; "" without a communicator): which librccl a
+ * multi-GPU run actually used, next to the one torch.distributed loaded.                                                          */
+const char *hxv_comm_library(const hxv_handle *h);
 /* STATUS of N>1 through RCCL: no round of this project has had more than one GPU, and RCCL refuses two ranks on one device, so
  * librccl itself has only ever run with ONE rank.  Everything around it -- slab copies, uneven splits, halo lists and
  * offsets, the drivers' all-reduces, the collective error agreement -- is executed with several ranks by the second
@@ -332,6 +341,17 @@ int hxv_vector_to_host(hxv_handle *h, const void *d_vec, void *v_host);
  * hxv_pool_trim returns everything cached on `device` (all devices if < 0) to the driver.                        */
 int hxv_pool_trim(int32_t device);
 int hxv_pool_stats(int32_t device, int64_t *cached_bytes, int64_t *hits, int64_t *misses);
+
+/* ---- sector-image cache.  The reference opens and closes a sector around EVERY Lanczos run: once per sector in ED_DIAG.f90:142-186 and
+ * once per Green's-function channel in ED_GF_NORMAL.f90:208-222 (+7 siblings; 56 channels of a 2x2 cluster re-open the same four sectors
+ * N+-1).  What hxv_create_from_model builds -- basis maps, one-spin matrices, tile plan, ~50 device tables -- depends only on the model
+ * bytes, (nup, ndw), (rank, nranks), the exchange and the device; the engine keeps the images of closed sectors and a re-open with the
+ * same inputs shares them (identical products bit for bit; a different bath is a different key).  Environment: HXV_SECTOR_CACHE=0 disables
+ * it, HXV_SECTOR_CACHE_MB caps host + device bytes (default 2048, least recently used out first).  hxv_get_option(h, "open_cache_hit" |
+ * "open_us_host" | "open_us_plan" | "open_us_upload" | "open_us_total") tells what THIS open cost.  Handles from hxv_create_from_csr and
+ * panel handles are not cached.                                                                                                */
+int hxv_sector_cache_clear(void);
+int hxv_sector_cache_stats(int64_t *entries, int64_t *bytes, int64_t *hits, int64_t *misses); /* any out may be NULL */
 
 /* ---- introspection (parity tests against spH0ups/spH0dws/spH0d) ------------------------ */
 int hxv_get_maps(const hxv_handle *h, int32_t *map_up, int32_t *map_dw); /* Hs(1)%map, Hs(2)%map */

@@ -1,4 +1,4 @@
-// TEST-ONLY double of the ten RCCL entry points the engine resolves (csrc/hxv_comm.cpp: rccl()), for ranks that are host THREADS of one
+// TEST-ONLY double of the RCCL entry points the engine resolves (ten, plus ncclCommAbort) (csrc/hxv_comm.cpp: rccl()), for ranks that are host THREADS of one
 // process sharing one GPU -- RCCL itself refuses two ranks on one device, and no round of this project has had a second GPU.  It exists
 // so that the RCCL branches of hxv_comm.cpp (the grouped ncclSend / ncclRecv of the column exchange and of both transposes, the in-place
 // ncclAllGather, the ncclSum / ncclMax all-reduces) EXECUTE with 2-4 ranks and are checked against the oracle: counts, offsets and
@@ -45,6 +45,7 @@ struct World {
   int joined = 0, alive = 0;
   int arrived = 0;
   uint64_t gen = 0;
+  bool broken = false;  // ncclCommAbort on any of its communicators: every wait gives up
   struct Post {
     const void* send = nullptr;
     void* recv = nullptr;
@@ -64,7 +65,7 @@ struct World {
       cv.notify_all();
       return true;
     }
-    return cv.wait_for(lk, std::chrono::duration<double>(TIMEOUT_S), [&] { return gen != g; });
+    return cv.wait_for(lk, std::chrono::duration<double>(TIMEOUT_S), [&] { return gen != g || broken; }) && !broken;
   }
 };
 
@@ -132,7 +133,7 @@ ncclResult_t run_group(std::vector<Op>& ops) {
     {
       std::unique_lock<std::mutex> lk(w.mu);
       auto& dq = w.q[(size_t)o.peer * w.n + o.c->rank];
-      if (!w.cv.wait_for(lk, std::chrono::duration<double>(TIMEOUT_S), [&] { return !dq.empty(); })) return ncclSystemError;
+      if (!w.cv.wait_for(lk, std::chrono::duration<double>(TIMEOUT_S), [&] { return !dq.empty() || w.broken; }) || w.broken) return ncclSystemError;
       m = dq.front();
       dq.pop_front();
     }
@@ -153,7 +154,7 @@ ncclResult_t run_group(std::vector<Op>& ops) {
     World& w = *ops[i].c->w;
     {
       std::unique_lock<std::mutex> lk(w.mu);
-      if (!w.cv.wait_for(lk, std::chrono::duration<double>(TIMEOUT_S), [&] { return mine[i]->taken; })) return ncclSystemError;
+      if (!w.cv.wait_for(lk, std::chrono::duration<double>(TIMEOUT_S), [&] { return mine[i]->taken || w.broken; }) || w.broken) return ncclSystemError;
     }
     HIPOK(hipStreamWaitEvent(ops[i].st, mine[i]->consumed, 0));
   }
@@ -236,6 +237,19 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm) {
     g_worlds.erase(w->key);
   }
   delete c;
+  return ncclSuccess;
+}
+
+// ncclCommAbort: any thread may call it while the communicator's own rank waits in a collective.  The double marks the WORLD broken (a
+// lost rank breaks every collective of the communicator anyway) and leaves the Comm object alone: its rank may be reading it right now.
+ncclResult_t ncclCommAbort(ncclComm_t comm) {
+  Comm* c = reinterpret_cast<Comm*>(comm);
+  if (!c) return ncclSuccess;
+  {
+    std::lock_guard<std::mutex> lk(c->w->mu);
+    c->w->broken = true;
+  }
+  c->w->cv.notify_all();
   return ncclSuccess;
 }
 

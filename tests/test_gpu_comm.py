@@ -207,10 +207,20 @@ def test_bench_n_processes_on_one_gpu_through_the_rccl_branches(built, exchange,
     port = {"allgather": "29581", "halo": "29582", "alltoall": "29583"}[exchange]
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1", "--master-port", port,
                         os.path.join(root, "bench.py"), "--gpus", str(nproc), "--backend", "gloo", "--capi", "--workload", "C2", "--steps", "3", "--warmup", "1",
-                        "--exchange", exchange], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+                        "--exchange", exchange], capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == nproc and line["value"] > 0 and line["scaling"] == "strong"
     assert line["checked"] is True and line["check_rel_err"] <= 1e-13 and "C-ABI" in line["config"]["transport"]
     assert line["config"]["exchange"] == exchange and line["config"]["exchange_ingest_bytes_per_gpu"] > 0
     assert line["roofline"]["kernel_ms"] > 0
+    # first-contact fields: the link bound next to the measurement, the RCCL library the engine resolved, the
+    # exchange's share of a slab product per rank
+    cfg, rl = line["config"], line["roofline"]
+    assert cfg["link_GBs_assumed"] == 153.0 and 0 < cfg["link_bound_ms"] < rl["slab_product_ms_on_stream"] * 1e3
+    per_peer = {"allgather": cfg["exchange_ingest_bytes_per_gpu"] / (nproc - 1), "alltoall": cfg["exchange_ingest_bytes_per_gpu"] / (nproc - 1)}.get(exchange)
+    if per_peer is not None:
+        assert abs(cfg["link_bound_ms"] - per_peer / 153e9 * 1e3) < 1e-3
+    assert cfg["rccl_lib"].endswith("librccl_double_mp.so") and isinstance(cfg["rccl_libs_mapped"], list)
+    ex = rl["exchange_ms"]
+    assert ex["min"] <= ex["this_rank"] <= ex["max"] and abs(ex["this_rank"] - (rl["slab_product_ms_on_stream"] - rl["kernel_ms"])) < 1e-3

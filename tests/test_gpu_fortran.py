@@ -130,6 +130,11 @@ def test_fortran_device_resident_green_function_channel(built):
     assert int(pr.group(5)) == 0 and int(pr.group(6)) == 0 and float(pr.group(4)) < -5.0
     hb = re.search(r"GF host-array channel: PCIe bytes \(h2d,d2h\) channel-sector=\s*(\d+)\s+(\d+)", txt)
     assert int(hb.group(1)) == 792 * 924 * 16                                  # the host start vector of sector (7,6), once
+    # vectors freed in the awkward order: the sector kept through a view, the allocation's first vector freed first, another
+    # vector of the kept sector outliving the keeper -- lifetimes are counted, nothing dangles
+    lt = re.search(r"GF lifetimes any order: \|norm2\(ev1\) - norm2\(gs\)\|=\s*([-\d.Ee+]+)\s*norm2\(ev2\)=\s*([-\d.Ee+]+)\s*max\|roundtrip - psi\|=\s*([-\d.Ee+]+)", txt)
+    assert lt, txt
+    assert float(lt.group(1)) < 1e-9 and 0.0 < float(lt.group(2)) < 1.0 and float(lt.group(3)) == 0.0
 
 
 def test_fortran_stored_matrices_binding(built):

@@ -376,6 +376,56 @@ def test_a_rank_thread_that_fails_outside_the_library_wakes_its_peers(built):
     assert len(seen) == 2 and all("dropped out" in s for s in seen), seen
 
 
+def test_a_rank_lost_after_joining_an_rccl_communicator_is_aborted(built):
+    """over RCCL a rank whose thread fails BETWEEN collectives used to leave its peers inside ncclAllReduce until the library's
+    own timeout (the double: 120 s; librccl: forever).  hxv.run_ranks now calls hxv_comm_abort (ncclCommAbort) on every joined handle:
+    the peer's collective returns an error at once, the original error is raised."""
+    import os
+    import threading
+    import time
+    import hxv
+
+    os.environ["HXV_RCCL_LIB"] = str(built.build_rccl_double())
+    try:
+        m, (nup, ndw) = _model("chain")
+        seen, took = [], []
+
+        def rank(r, group):
+            sec = hxv.HxvSector.from_model(m, nup, ndw, rank=r, nranks=2)
+            try:
+                group.join(sec)
+                assert sec.comm_library.endswith("librccl_double.so")
+                if r == 1:
+                    time.sleep(0.5)                                  # (rank 0 is inside its first all-reduce by now)
+                    raise RuntimeError("rank 1 failed after joining")
+                t0 = time.time()
+                try:
+                    sec.lanczos_eigh(64, 1e-10, want_vector=False)   # collective: waits for rank 1
+                except hxv.HxvError as e:
+                    seen.append(str(e))
+                    took.append(time.time() - t0)
+                    raise
+            finally:
+                sec.close()
+
+        out = []
+
+        def runner():
+            try:
+                hxv.run_ranks(2, rank, transport="rccl")
+            except BaseException as e:  # noqa: BLE001
+                out.append(e)
+
+        t = threading.Thread(target=runner)
+        t.start()
+        t.join(60)
+        assert not t.is_alive(), "the peer of the failed rank is still waiting"
+        assert len(out) == 1 and isinstance(out[0], RuntimeError) and "rank 1 failed" in str(out[0]), out
+        assert len(seen) == 1 and took[0] < 30.0, (seen, took)
+    finally:
+        os.environ.pop("HXV_RCCL_LIB", None)
+
+
 @pytest.mark.parametrize("exchange,real_vectors", [("allgather", 0), ("halo", 1)])
 def test_start_vector_built_at_the_slab_home(built, transport, exchange, real_vectors):
     """the drivers clear the slab's place in their three gather buffers before they read their input; a start vector that

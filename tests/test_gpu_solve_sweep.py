@@ -1,0 +1,202 @@
+"""The callers' usage pattern as a whole: every sector of a model opened, solved and closed the way ED_DIAG.f90:78-260
+does, every Green's-function channel of build_gf_normal (ED_GF_NORMAL.f90:36-110) with its sector opened and closed around it, and the
+sector-image cache that serves the re-opens.  The harness (hxv/harness.py) only drives the C-ABI; the numbers are compared with the CPU
+oracle's matrices (tests/golden/c2_sector_sweep.json, scripts/make_golden_c2_sweep.py) and with the oracle's own Lanczos."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).resolve().parent / "golden"
+
+
+def test_reopened_sector_shares_its_image_and_multiplies_bit_for_bit(built):
+    import torch
+    import hxv
+    from hxv import models
+
+    hxv.sector_cache_clear()
+    m = models.hm_1dchain()
+    st0 = hxv.sector_cache_stats()
+    a = hxv.HxvSector.from_model(m, 6, 6)
+    assert a.get_option("open_cache_hit") == 0 and a.get_option("open_us_plan") > 0
+    v = torch.randn(a.Dim, dtype=torch.complex128, device="cuda")
+    ha = a.apply_device(v).clone()
+    ea, _, _, _ = a.eigh_lowest(2, 20, want_vectors=False)
+    a.close()
+    b = hxv.HxvSector.from_model(m, 6, 6)                      # same model bytes, sector, split, device: the image of the first open
+    assert b.get_option("open_cache_hit") == 1 and b.get_option("open_us_host") == 0 and b.get_option("open_us_plan") == 0
+    c = hxv.HxvSector.from_model(m, 6, 6)                      # two OPEN handles share one image too
+    assert c.get_option("open_cache_hit") == 1
+    hb, hc = b.apply_device(v), c.apply_device(v)
+    torch.cuda.synchronize()
+    assert torch.equal(ha, hb) and torch.equal(ha, hc)
+    eb, _, _, _ = b.eigh_lowest(2, 20, want_vectors=False)
+    assert np.array_equal(ea, eb)
+    # a handle-private plan (a tiling option) leaves the shared image alone
+    b.set_option("cols_per_tile", 2)
+    hb2 = b.apply_device(v)
+    hc2 = c.apply_device(v)
+    torch.cuda.synchronize()
+    assert torch.equal(hc2, ha) and (hb2 - ha).abs().max().item() < 1e-12
+    b.close()
+    c.close()
+    # another bath is another key (the next DMFT iteration must never see a stale image)
+    m2 = models.hm_1dchain(eps_bath=[0.31, -0.2])
+    d = hxv.HxvSector.from_model(m2, 6, 6)
+    assert d.get_option("open_cache_hit") == 0
+    d.close()
+    # another sector, another split: misses; the same split again: a hit
+    e = hxv.HxvSector.from_model(m, 6, 6, rank=1, nranks=3)
+    assert e.get_option("open_cache_hit") == 0
+    e.close()
+    e = hxv.HxvSector.from_model(m, 6, 6, rank=1, nranks=3)
+    assert e.get_option("open_cache_hit") == 1
+    e.close()
+    st1 = hxv.sector_cache_stats()
+    assert st1["hits"] - st0["hits"] == 3 and st1["entries"] == 3
+    hxv.sector_cache_clear()
+    assert hxv.sector_cache_stats()["entries"] == 0
+    f = hxv.HxvSector.from_model(m, 6, 6)
+    assert f.get_option("open_cache_hit") == 0
+    hf = f.apply_device(v)
+    torch.cuda.synchronize()
+    assert torch.equal(hf, ha)
+    f.close()
+
+
+def test_reopening_the_headline_sector_costs_milliseconds(built):
+    """re-open of a cached Ns=16 sector <= 15 ms (~165 ms before), identical products."""
+    import time
+    import torch
+    import hxv
+    from hxv import models
+
+    hxv.sector_cache_clear()
+    m = models.hm_2dsquare(Nbath=3)
+    t0 = time.perf_counter()
+    a = hxv.HxvSector.from_model(m, 9, 8)
+    cold_ms = (time.perf_counter() - t0) * 1e3
+    v = torch.randn(a.fullElems, dtype=torch.complex128, device="cuda")
+    torch.view_as_real(v).view(-1, a.pitch, 2)[:, a.DimUp:, :] = 0.0
+    ha = a.apply_device(v).clone()
+    a.close()
+    times = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        b = hxv.HxvSector.from_model(m, 9, 8)
+        times.append((time.perf_counter() - t0) * 1e3)
+        assert b.get_option("open_cache_hit") == 1
+        hb = b.apply_device(v)
+        torch.cuda.synchronize()
+        assert torch.equal(ha, hb)
+        b.close()
+    print(f"Ns=16 sector (9,8): cold open {cold_ms:.1f} ms, cached re-opens {['%.2f' % t for t in times]} ms")
+    assert max(times) <= 15.0, times
+    hxv.sector_cache_clear()
+
+
+def test_every_sector_of_c2_against_the_oracle(built):
+    """ED_DIAG's sweep at Ns=12: all 169 sectors opened, solved (sp_eigh call shape: Neigen=2, Nblock=20) and closed; E0 and E1 within
+    1e-10 of the oracle's matrices (LAPACK below Dim=3000, ARPACK above).  Edge sectors (nup or ndw in {0, Ns}: DimUp or DimDw = 1) and
+    the sectors the reference would hand to LAPACK (Dim <= 1024) included."""
+    import hxv
+    from hxv import models
+    from hxv.harness import diag_sweep
+
+    gold = json.loads((GOLD / "c2_sector_sweep.json").read_text())
+    ref = {(r["nup"], r["ndw"]): r for r in gold["sectors"]}
+    m = models.hm_1dchain()
+    assert m.name == gold["model"]
+    recs = diag_sweep(m)
+    assert len(recs) == 169 == len(ref)
+    worst = 0.0
+    for r in recs:
+        g = ref[(r["nup"], r["ndw"])]
+        assert r["dim"] == g["dim"]
+        ne = min(2, r["dim"])
+        assert r["nconv"] == ne, r
+        err = np.abs(np.array(r["evals"][:ne]) - np.array(g["lowest"][:ne])).max()
+        worst = max(worst, err)
+        assert err <= 1e-10, (r, g)
+    nl = [r for r in recs if r["lanczos"]]
+    assert len(nl) == sum(1 for g in ref.values() if g["dim"] > 1024)
+    print(f"C2 sweep: {len(recs)} sectors ({len(nl)} above the Lanczos threshold), worst |dE| {worst:.2e}, open {sum(r['open_ms'] for r in recs):.0f} ms, "
+          f"solve {sum(r['solve_ms'] for r in recs):.0f} ms, close {sum(r['close_ms'] for r in recs):.0f} ms")
+
+
+def _apply_op_host(psi, maps_from, maps_to, pos, spin, create):
+    """c / c^dagger on orbital `pos` (0-based) of one spin, numpy restatement of ED_GF_NORMAL.f90:180-199 (sign: occupied orbitals below
+    pos on the same spin only)."""
+    src = maps_from[spin]
+    dst = maps_to[spin]
+    du_f, dd_f, du_t, dd_t = len(maps_from[0]), len(maps_from[1]), len(maps_to[0]), len(maps_to[1])
+    P = psi.reshape((du_f, dd_f), order="F")
+    out = np.zeros((du_t, dd_t), dtype=complex)
+    pos_of = {int(s): k for k, s in enumerate(dst)}
+    bit = 1 << pos
+    for k, s in enumerate(src):
+        s = int(s)
+        if bool(s & bit) == create:
+            continue
+        sgn = -1.0 if bin(s & (bit - 1)).count("1") % 2 else 1.0
+        t = pos_of[(s | bit) if create else (s & ~bit)]
+        if spin == 0:
+            out[t, :] += sgn * P[k, :]
+        else:
+            out[:, t] += sgn * P[:, k]
+    return out.reshape(-1, order="F")
+
+
+@pytest.mark.parametrize("symmetric", [False, True])
+def test_green_function_channels_in_the_callers_order(built, symmetric):
+    """build_gf_normal's channel list for a 4-site cluster (56 tridiagonalisations, 32 with ed_gf_symmetric), each with its sector opened
+    and closed around it; alanc / blanc of one channel of every kind against the ORACLE's Lanczos on the same start vector, paired
+    against unpaired runs, and the re-opens served by the cache."""
+    import hxv
+    from hxv import models
+    from hxv.harness import gf_solve, gf_channels
+    from oracle.oracle import OracleSector
+
+    hxv.sector_cache_clear()
+    m = models.hm_1dchain(Nlat=4, Nbath=1)          # Ns = 8, sector (4,4): Dim 4900; targets (5,4), (3,4): 3920
+    chans = gf_channels(m, symmetric)
+    assert len(chans) == (32 if symmetric else 56)
+    assert sum(1 for c in chans if c["kind"] == "mix_xi") == (0 if symmetric else 24)
+    nl = 60
+    recs, summ = gf_solve(m, 4, 4, nlanc=nl, symmetric=symmetric, pair=True, keep_tridiag=True, keep_psi=True)
+    recs1, summ1 = gf_solve(m, 4, 4, nlanc=nl, symmetric=symmetric, pair=False, keep_tridiag=True)
+    assert summ["channels"] == len(chans) == summ1["channels"]
+    assert summ["channels_complex"] == (0 if symmetric else 24) and summ["channels_paired"] == 32 and summ1["channels_paired"] == 0
+    # every open after the first of each target sector is a cache hit: 2 cold opens in the first solve, none in the second
+    assert summ["sector_opens"] - summ["sector_open_cache_hits"] == 2 and summ1["sector_opens"] == summ1["sector_open_cache_hits"] == len(chans)
+    key = lambda r: (r["kind"], r["create"], tuple(r["terms"]))
+    by1 = {key(r): r for r in recs1}
+    for r in recs:
+        r1 = by1[key(r)]
+        assert r["nsteps"] == r1["nsteps"] == nl and abs(r["norm2"] - r1["norm2"]) < 1e-12
+        assert np.abs(r["alanc"][:30] - r1["alanc"][:30]).max() < 1e-9 and np.abs(r["blanc"][:30] - r1["blanc"][:30]).max() < 1e-9
+    # the oracle's Lanczos (SciFortran's recurrence restated, oracle/hxv_oracle.c) on the same start vectors
+    psi = summ["psi"]
+    gs_o = OracleSector(m, 4, 4)
+    maps0 = (gs_o.map_up(), gs_o.map_dw())
+    w0 = np.linalg.eigvalsh(gs_o.dense())[0]
+    assert abs(summ["e0"] - w0) < 1e-10
+    seen = set()
+    for r in recs:
+        kd = (r["kind"], r["create"])
+        if kd in seen:
+            continue
+        seen.add(kd)
+        tu, td = r["sector"]
+        orc = OracleSector(m, tu, td)
+        maps1 = (orc.map_up(), orc.map_dw())
+        vin = sum(complex(cf) * _apply_op_host(psi, maps0, maps1, orb, 0, r["create"]) for orb, cf in r["terms"])
+        n2 = np.vdot(vin, vin).real
+        assert abs(n2 - r["norm2"]) < 1e-10
+        a, b = orc.lanc_tridiag(vin / np.sqrt(n2), 25)
+        assert np.abs(a - r["alanc"][:25]).max() < 1e-9 and np.abs(b[1:] - r["blanc"][1:25]).max() < 1e-9, kd
+    assert len(seen) == (4 if symmetric else 6)
+    hxv.sector_cache_clear()
