@@ -721,6 +721,8 @@ int64_t hxv_get_option(const hxv_handle* h, const char* name) {
   if (!strcmp(name, "eigh_measure_all")) return h->eigh_measure_all;
   if (!strcmp(name, "eigh_last_full_passes")) return h->eigh_last_full;
   if (!strcmp(name, "eigh_last_local_passes")) return h->eigh_last_local;
+  if (!strcmp(name, "eigh_last_search_products")) return h->eigh_last_search;  // *nmatvec of the last hxv_eigh_lowest = search + check
+  if (!strcmp(name, "eigh_last_check_products")) return h->eigh_last_check;
   if (!strcmp(name, "lanczos_real_last")) return h->last_real;
   if (!strcmp(name, "slab_copies")) return h->n_slab_copy;  // exchanges whose vector was not at home in a gather buffer
   if (!strcmp(name, "lanczos_inplace")) return h->lz_inplace;

@@ -783,6 +783,7 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
 
   int rc0 = trl(0, neigen, (uint64_t)0x5EED5EEDull, 1e300);
   if (rc0) return rc0;
+  const int nmv_search = nmv;  // products of the search itself; what follows are the optional check rounds for hidden copies
   // values and (absolute) basis slots of the pairs found so far
   std::vector<double> fval(theta.begin(), theta.begin() + ne);
   lockval = fval;
@@ -832,6 +833,8 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
   if (nmatvec_out) *nmatvec_out = nmv;
   h->eigh_last_full = n_full;
   h->eigh_last_local = n_local;
+  h->eigh_last_search = nmv_search;
+  h->eigh_last_check = nmv - nmv_search;
   if (d_evecs) {
     for (int i = 0; i < ne; ++i) {
       if (real)

@@ -142,8 +142,10 @@ struct hxv_handle {
   int lz_graph = 1;                // option "lanczos_graph": fixed-length tridiagonalisations run device-only, three iterations per hipGraph
   int eigh_measure_all = 0;        // option "eigh_measure_all": hxv_eigh_lowest measures every projection at every step (round-1 behaviour)
   int64_t eigh_last_full = 0, eigh_last_local = 0;  // Gram-Schmidt passes of the last hxv_eigh_lowest: whole basis / local only
+  int64_t eigh_last_search = 0, eigh_last_check = 0;  // products of the last hxv_eigh_lowest: the search / the check rounds for hidden copies
   int eigh_keep_pct = 20;          // option "eigh_keep_pct": share of the basis beyond the wanted pairs that a thick restart keeps
-  int eigh_degenerate = 1;         // option "eigh_degenerate": hxv_eigh_lowest looks for further copies of degenerate levels (locking rounds)
+  int eigh_degenerate = 0;         // option "eigh_degenerate": 1 = hxv_eigh_lowest looks for further copies of degenerate levels (locking rounds; about
+                                   // as many products again); 0 [default] = one Krylov space, what ARPACK (the call this replaces) does
   int real_vectors = 1;            // option "real_vectors": device Lanczos drivers use real vectors when H and the start vector are real
   int lz_buf_mode = 0;             // layout the d_lz work vectors were last used in (0 complex, 1 real): the pad rows differ
   int last_real = 0;               // did the last device Lanczos run use real vectors (get_option "lanczos_real_last")

@@ -19,6 +19,10 @@ module ED_HAMILTONIAN_GPU_HXV
   public :: gpuMatVec_MPI_main
   public :: gpu_comm_unique_id
   public :: gpu_comm_init
+  !sp_eigh's replacement looks for hidden copies of degenerate levels only when asked (engine option "eigh_degenerate", include/hxv.h): set
+  !this BEFORE build_Hv_sector for clusters whose point group has degenerate levels inside a sector (2x2 plaquette: D4) when every state
+  !within gs_threshold (ED_DIAG.f90:234-244) is wanted; the default is what ARPACK does (one Krylov space, no extra products)
+  logical,public,save :: gpu_eigh_degenerate=.false.
   public :: gpu_lanc_tridiag_host
   public :: gpu_sp_lanc_tridiag
   public :: gpu_sp_lanc_tridiag_pair
@@ -103,6 +107,12 @@ module ED_HAMILTONIAN_GPU_HXV
        integer(c_int32_t),value      :: nup,ndw,rank,nranks,device
        type(c_ptr),intent(out)       :: out
      end function hxv_create_from_model
+     integer(c_int) function hxv_set_option(h,name,value) bind(C,name="hxv_set_option")
+       import :: c_ptr,c_int,c_char,c_int64_t
+       type(c_ptr),value             :: h
+       character(kind=c_char)        :: name(*)
+       integer(c_int64_t),value      :: value
+     end function hxv_set_option
      integer(c_int) function hxv_destroy(h) bind(C,name="hxv_destroy")
        import :: c_int, c_ptr
        type(c_ptr),value :: h
@@ -328,6 +338,7 @@ contains
     endif
     call check(hxv_create_from_model(m,int(nup,c_int32_t),int(ndw,c_int32_t),int(MpiRank,c_int32_t),&
          int(MpiSize,c_int32_t),int(dev,c_int32_t),handle),"gpu_build_Hv_sector")
+    if(gpu_eigh_degenerate)call check(hxv_set_option(handle,"eigh_degenerate"//c_null_char,1_c_int64_t),"gpu_build_Hv_sector")
   end subroutine gpu_build_Hv_sector
 
   !---- reference tables of the device vectors (see type ref_entry) ----

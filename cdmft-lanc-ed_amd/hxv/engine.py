@@ -259,12 +259,15 @@ def run_ranks(nranks: int, fn, transport: str = "local"):
 
     group = LocalGroup(nranks) if transport == "local" else RcclGroup(nranks)
     out, err = [None] * nranks, [None] * nranks
+    order, lock = [], threading.Lock()   # errors in the order they happened: the first one is the cause, the rest are its peers waking up
 
     def work(r):
         try:
             out[r] = fn(r, group)
         except BaseException as e:  # noqa: BLE001 (reported to the caller below)
             err[r] = e
+            with lock:
+                order.append(e)
             group.abort()
 
     ts = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
@@ -279,10 +282,8 @@ def run_ranks(nranks: int, fn, transport: str = "local"):
         except HxvError:
             if not any(err):
                 raise
-    # the rank whose own failure started it, not a peer's "group aborted"
-    first = [e for e in err if e is not None and "thread-rank group" not in str(e)] or [e for e in err if e is not None]
-    if first:
-        raise first[0]
+    if order:
+        raise order[0]
     return out
 
 

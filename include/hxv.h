@@ -277,7 +277,7 @@ int hxv_lanczos_tridiag_pair_host(hxv_handle *h, const void *vin_a_host, const v
  * as a thick-restart Lanczos (the explicit-restart form of ARPACK's implicitly restarted Lanczos for Hermitian
  * operators) with a Krylov basis of ncv (= Nblock) vectors resident in HBM, full re-orthogonalisation and ARPACK's
  * convergence test |beta*s_mi| <= tol*max(eps^(2/3),|theta_i|)  (tol below machine epsilon -- the reference's default
- * lanc_tolerance=1e-18 -- is raised to epsilon).  nranks==1.
+ * lanc_tolerance=1e-18 -- is raised to epsilon).  Serial and split sectors (below).
  *   neigen       : number of lowest eigenpairs wanted (Neigen)
  *   ncv          : basis size (Nblock = lanc_ncv_factor*Neigen+lanc_ncv_add, ED_DIAG.f90:96); <=0 -> 10*neigen; max 64
  *   maxrestart   : restart limit (Nitermax)
@@ -286,13 +286,16 @@ int hxv_lanczos_tridiag_pair_host(hxv_handle *h, const void *vin_a_host, const v
  *   evecs_host   : host, eig_basis(Dim,neigen) in the reference's contiguous layout, or NULL
  *   *nconv       : how many of the neigen pairs met the test; *nmatvec: H x V products spent.
  * Needs (ncv+1) vectors of HBM; fails with HXV_ERR_HIP and a message naming the shortfall otherwise.
- * A single Krylov space sees ONE vector of an exactly degenerate level (ARPACK included), while ED_DIAG.f90:234-244 keeps
- * every state within gs_threshold of the minimum: so, once the wanted pairs have converged, they are locked and the
- * same iteration in their orthogonal complement looks for a state below the current neigen-th lowest value (a hidden
- * copy), repeatedly (option "eigh_degenerate", default 1; costs about as many products again when there is nothing to find).
- * Every step of such a round removes the locked eigenvectors (they are converged to `tol` only).  "Nothing below" is a
- * HEURISTIC answer: the lowest Ritz value of the complement minus its residual must clear the level from the second restart
- * cycle on, with a falling residual -- a copy whose overlap with the start vector is at rounding level can still be missed.
+ * A single Krylov space sees ONE vector of an exactly degenerate level -- ARPACK included: sp_eigh returns further copies only when
+ * rounding happens to bring them up, while ED_DIAG.f90:234-244 keeps every state within gs_threshold of the minimum.  DEFAULT = what
+ * ARPACK does: one Krylov space, no extra work.  Option "eigh_degenerate" = 1 ASKS for the copies: once the wanted pairs have converged
+ * they are locked and the same iteration in their orthogonal complement looks for a state below the current neigen-th lowest value (a
+ * hidden copy), repeatedly -- about as many products again when there is nothing to find (C3: 220 + 220); every step of such a round
+ * removes the locked eigenvectors (they are converged to `tol` only).  "Nothing below" is a HEURISTIC answer: the lowest Ritz value of
+ * the complement minus its residual must clear the level from the second restart cycle on, with a falling residual -- a copy whose
+ * overlap with the start vector is at rounding level can still be missed.  *nmatvec counts both; hxv_get_option(h,
+ * "eigh_last_search_products" | "eigh_last_check_products") splits it.  Clusters with a non-abelian point group (the 2x2 plaquette: D4)
+ * DO have degenerate levels inside a sector: INTEGRATION.md section 3 says when to ask.
  * Split sectors: after hxv_comm_init (vectors = slabs).  If Dim <= ncv the Krylov space closes and all returned pairs are exact. */
 int hxv_eigh_lowest(hxv_handle *h, int32_t neigen, int32_t ncv, int32_t maxrestart, double tol, double *evals, void *d_evecs,
                     int32_t *nconv, int32_t *nmatvec);
@@ -366,7 +369,8 @@ int hxv_get_diag(const hxv_handle *h, double *diag);
  *   "real_vectors"    1 [default] = device Lanczos drivers run on real vectors when H and the start vector are real
  *   "lanczos_fused"   1 [default] = recurrence fused into the product's epilogue; 0 = separate vector kernels
  *   "lanczos_graph"   1 [default] = fixed-length tridiagonalisations run device-only, three iterations per hipGraph
- *   "eigh_degenerate" 1 [default] = hxv_eigh_lowest locks the converged pairs and looks for further copies of degenerate levels
+ *   "eigh_degenerate" 0 [default] = one Krylov space like ARPACK; 1 = hxv_eigh_lowest locks the converged pairs and looks for further copies of
+ *                     degenerate levels (about as many products again)
  *   "eigh_measure_all" 0 [default] = partial re-orthogonalisation (loss of orthogonality estimated by the omega recurrence, whole-basis
  *                     Gram-Schmidt only when needed); 1 = every projection measured at every step (round-1 behaviour)
  * Pass A as pipelined jobs (LDS-DMA tile ring, one workgroup per CU): "job_up" 2 [default: for the fused Lanczos product only] | 1 (always) | 0 (one tile per

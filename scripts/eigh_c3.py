@@ -12,6 +12,7 @@ sec = hxv.HxvSector.from_model(m, nup, ndw)
 sec.set_option("eigh_measure_all", int(os.environ.get("MEASURE_ALL", 0)))
 sec.set_option("lanczos_fused", int(os.environ.get("FUSED", 1)))
 sec.set_option("real_vectors", int(os.environ.get("REAL_VECTORS", 1)))
+sec.set_option("eigh_degenerate", int(os.environ.get("DEGENERATE", 0)))   # 1: plus the check rounds for hidden copies of degenerate levels
 if "KEEP" in os.environ:
     sec.set_option("eigh_keep_pct", int(os.environ["KEEP"]))
 neigen, ncv = int(os.environ.get("NEIGEN", 2)), int(os.environ.get("NCV", 20))
@@ -20,7 +21,9 @@ for rep in range(int(os.environ.get("REPS", 1))):  # (a second run finds the Kry
     ev, X, nconv, nmv = sec.eigh_lowest(neigen, ncv, native=True)
     torch.cuda.synchronize()
     dt = time.time() - t
-    print(f"{wl} eigh_lowest neigen={neigen} ncv={ncv}: E={ev} nconv={nconv} matvecs={nmv} {dt:.2f}s ({dt / nmv * 1e3:.1f} ms per Lanczos step)", flush=True)
+    print(f"{wl} eigh_lowest neigen={neigen} ncv={ncv} degenerate={sec.get_option('eigh_degenerate')}: E={ev} nconv={nconv} matvecs={nmv} "
+          f"(search {sec.get_option('eigh_last_search_products')} + check {sec.get_option('eigh_last_check_products')}) {dt:.2f}s ({dt / nmv * 1e3:.1f} ms per Lanczos step; "
+          f"Gram-Schmidt passes: {sec.get_option('eigh_last_full_passes')} whole-basis, {sec.get_option('eigh_last_local_passes')} local)", flush=True)
     if rep + 1 < int(os.environ.get("REPS", 1)):
         del X
 hv = sec.apply_device(X[0].contiguous())

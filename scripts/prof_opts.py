@@ -11,7 +11,21 @@ for kv in (sys.argv[1] if len(sys.argv) > 1 else "").split(","):
     if kv:
         k, val = kv.split("="); sec.set_option(k, int(val))
 nrep = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-v = torch.randn(sec.fullElems, dtype=torch.float64, device="cuda") + 1j * torch.randn(sec.fullElems, dtype=torch.float64, device="cuda")
-hv = torch.empty_like(v)
-torch.cuda.synchronize()
-print("ms", sec.time_apply(v, hv, nrep))
+if os.environ.get("REAL", "0") == "1":
+    # REAL-vector product (real H): the kernels that carry hxv_lanczos_eigh / hxv_eigh_lowest / the real Green's-function channels
+    v = sec.pad_real(torch.randn(sec.Dim, dtype=torch.float64, device="cuda"))
+    hv = torch.empty_like(v)
+    sec.apply_device_real(v, hv)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(nrep):
+        sec.apply_device_real(v, hv)
+    e1.record()
+    torch.cuda.synchronize()
+    print("ms (real vectors)", e0.elapsed_time(e1) / nrep)
+else:
+    v = torch.randn(sec.fullElems, dtype=torch.float64, device="cuda") + 1j * torch.randn(sec.fullElems, dtype=torch.float64, device="cuda")
+    hv = torch.empty_like(v)
+    torch.cuda.synchronize()
+    print("ms", sec.time_apply(v, hv, nrep))

@@ -252,10 +252,12 @@ def test_eigh_lowest_vs_lapack(built, case, neigen, ncv):
     else:
         m, (nup, ndw) = models.bhz_2d(Nbath=0), (4, 4)
     sec = hxv.HxvSector.from_model(m, nup, ndw)
+    sec.set_option("eigh_degenerate", 1)        # compared with a DENSE spectrum: every copy of a degenerate level is wanted (default: ARPACK's single Krylov space)
     Hd = OracleSector(m, nup, ndw).dense()
     ref = np.linalg.eigvalsh(Hd)
     ev, X, nconv, nmv = sec.eigh_lowest(neigen, ncv)
     assert nconv == neigen and nmv > 0
+    assert nmv == sec.get_option("eigh_last_search_products") + sec.get_option("eigh_last_check_products")
     assert np.abs(ev - ref[:neigen]).max() < 1e-10                      # BASELINE: E within 1e-10 of the CPU reference
     X = X.cpu().numpy().T                                               # (Dim, neigen)
     assert np.abs(X.conj().T @ X - np.eye(neigen)).max() < 1e-11
@@ -280,11 +282,15 @@ def test_eigh_lowest_matches_numpy_restatement_and_arpack_C2(built):
 
     m = models.hm_1dchain()
     sec = hxv.HxvSector.from_model(m, 6, 6)
-    ev_d, _, nconv_d, nmv_d = sec.eigh_lowest(2, 20, want_vectors=False)   # default: plus the check round for hidden copies
+    assert sec.get_option("eigh_degenerate") == 0                           # default: one Krylov space, like ARPACK
+    sec.set_option("eigh_degenerate", 1)                                    # asked for: plus the check round for hidden copies
+    ev_d, _, nconv_d, nmv_d = sec.eigh_lowest(2, 20, want_vectors=False)
+    n_search, n_check = sec.get_option("eigh_last_search_products"), sec.get_option("eigh_last_check_products")
     sec.set_option("eigh_degenerate", 0)                                    # the bare algorithm of the numpy restatement
     ev, X, nconv, nmv = sec.eigh_lowest(2, 20)
     assert nconv == 2 and nconv_d == 2 and np.abs(ev_d - ev).max() < 1e-11
     assert nmv < nmv_d <= 2 * nmv                                           # the check round stops once the residual bound clears E_2
+    assert n_search == nmv and n_check == nmv_d - nmv and sec.get_option("eigh_last_check_products") == 0
     H = oracle_full_matrix(OracleSector(m, 6, 6))
     ref = np.sort(sla.eigsh(H, k=2, which="SA", ncv=20, tol=1e-13)[0])
     assert np.abs(ev - ref).max() < 1e-10
@@ -357,6 +363,7 @@ def test_eigh_lowest_recovers_degenerate_levels(built):
     Hd = OracleSector(m, 4, 4).dense()
     ref = np.linalg.eigvalsh(Hd)
     assert abs(ref[1] - ref[2]) < 1e-10 and np.allclose(ref[:4], [-5.80307083, -5.69466351, -5.69466351, -5.61135083], atol=5e-9)
+    sec.set_option("eigh_degenerate", 1)                      # ask for the copies (default: ARPACK's single Krylov space)
     ev, vecs, nconv, nmv = sec.eigh_lowest(3, 20, 512, 0.0)
     assert nconv == 3 and np.abs(ev - ref[:3]).max() < 1e-10, (ev, ref[:4])
     X = vecs.cpu().numpy()                                    # [3, Dim]
@@ -372,6 +379,7 @@ def test_eigh_lowest_recovers_degenerate_levels(built):
     # no degeneracy: the extra round finds nothing below the wanted set and the result is unchanged
     m2 = models.hm_1dchain(eps_bath=[0.3, 0.6])
     s2 = hxv.HxvSector.from_model(m2, 6, 6)
+    s2.set_option("eigh_degenerate", 1)
     e1, _, n1, _ = s2.eigh_lowest(2, 20, 512, 0.0, want_vectors=False)
     s2.set_option("eigh_degenerate", 0)
     e0, _, n0, _ = s2.eigh_lowest(2, 20, 512, 0.0, want_vectors=False)
@@ -712,6 +720,7 @@ def test_eigh_lowest_loose_tolerance_returns_no_duplicate(built):
     sec = hxv.HxvSector.from_model(m, 3, 3)
     w = np.linalg.eigvalsh(OracleSector(m, 3, 3).dense())
     assert w[1] - w[0] > 1e-3 and w[2] - w[1] > 1e-3           # non-degenerate
+    sec.set_option("eigh_degenerate", 1)                       # the locking rounds are what this test is about
     for rv in (1, 0):
         sec.set_option("real_vectors", rv)
         for neigen in (2, 3):
@@ -835,6 +844,7 @@ def test_eigh_lowest_large_krylov_basis(built, neig, ncv, real_vectors, fused):
     sec = hxv.HxvSector.from_model(m, 6, 6)
     sec.set_option("real_vectors", real_vectors)
     sec.set_option("lanczos_fused", fused)
+    sec.set_option("eigh_degenerate", 1)                         # (the reference values hold every copy of a degenerate level)
     ev, X, nconv, nmv = sec.eigh_lowest(neig, ncv, 512, 0.0)
     Xh = X.cpu().numpy().T
     assert nconv == neig
