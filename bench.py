@@ -60,35 +60,70 @@ def host_cpu():
     return model, os.cpu_count() or len(allowed), len(allowed), max(1, ncores)
 
 
+def cgroup_cpu_limit():
+    """CPUs the container's cgroup grants this process (cpu.max of cgroup v2 / cfs quota of v1), or None without a quota: the GPU boxes
+    show all of the host's CPUs in the affinity mask but schedule a share of them."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return max(1, int(float(q) / float(per) + 0.999))
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return max(1, int(q / per + 0.999))
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def cpu_baseline(model, nup, ndw, budget_s=25.0):
     """Reference algorithm on the host: oracle spMatVec_mpi_main with one thread-rank per PHYSICAL core this process may
-    use -- no cap; the core count that ran, the CPU model and the host's totals are stated."""
+    use -- no fixed cap; the core count that ran, the CPU model and the host's totals are stated.  Where the affinity mask shows more
+    cores than the box schedules (a CPU share without a visible cgroup quota) a second sample with 16 thread-ranks is taken and the FASTER
+    of the two is the value; both are listed."""
     import numpy as np
     from oracle.oracle import OracleSector, spMatVec_mpi_main
 
     cpu_model, host_cpus, allowed, phys_cores = host_cpu()
-    P = phys_cores
-    t0 = time.time()
-    secs = [OracleSector(model, nup, ndw, r, P) for r in range(P)]
-    build_s = time.time() - t0
-    dim = secs[0].Dim
+    quota = cgroup_cpu_limit()
+    # one thread-rank per physical core this process may use; a cgroup CPU quota below that is the share the box really schedules (more
+    # thread-ranks than that only time-slice: 128 ranks on the pool's 16-CPU share measured HALF the rate of 16); HXV_CPU_BASELINE_RANKS overrides
+    P0 = phys_cores if quota is None else max(1, min(phys_cores, quota))
+    why = "" if P0 == phys_cores else f"; capped by the container's cgroup CPU quota of {quota}"
+    cands = [P0] + ([16] if quota is None and phys_cores > 16 else [])
+    if os.environ.get("HXV_CPU_BASELINE_RANKS"):
+        cands = [max(1, int(os.environ["HXV_CPU_BASELINE_RANKS"]))]
+        why = "; HXV_CPU_BASELINE_RANKS"
     rng = np.random.default_rng(0)
-    v = rng.standard_normal(dim) + 1j * rng.standard_normal(dim)
-    _, _ = spMatVec_mpi_main(model, nup, ndw, P, v, repeat=1, sectors=secs)  # warm-up
-    t0 = time.time()
-    n = 0
-    while True:
-        spMatVec_mpi_main(model, nup, ndw, P, v, repeat=1, sectors=secs)
-        n += 1
-        if time.time() - t0 > budget_s / 2 or n >= 5:
-            break
-    dt = (time.time() - t0) / n
-    for s in secs:
-        s.close()
-    return {"value": 32.0 * dim / dt / 1e9, "unit": "GB/s", "cores": P, "kind": "port", "cpu_model": cpu_model, "host_cores": host_cpus,
-            "cpus_allowed": allowed,
-            "sample": f"{n} full products of the same sector, {P} thread-ranks = the physical cores among the {allowed} CPUs this process may use "
-                      f"(reference spMatVec_mpi_main restated in oracle/hxv_oracle.c; matrix build {build_s:.1f}s untimed)", "s_per_matvec": dt}
+    samples, v = [], None
+    for P in cands:
+        t0 = time.time()
+        secs = [OracleSector(model, nup, ndw, r, P) for r in range(P)]
+        build_s = time.time() - t0
+        dim = secs[0].Dim
+        if v is None:
+            v = rng.standard_normal(dim) + 1j * rng.standard_normal(dim)
+        spMatVec_mpi_main(model, nup, ndw, P, v, repeat=1, sectors=secs)  # warm-up
+        t0 = time.time()
+        n = 0
+        while True:
+            spMatVec_mpi_main(model, nup, ndw, P, v, repeat=1, sectors=secs)
+            n += 1
+            if time.time() - t0 > budget_s / (2 * len(cands)) or n >= 5:
+                break
+        dt = (time.time() - t0) / n
+        for s in secs:
+            s.close()
+        samples.append({"thread_ranks": P, "products": n, "s_per_matvec": dt, "GBs": 32.0 * dim / dt / 1e9, "matrix_build_s": round(build_s, 1)})
+    best = max(samples, key=lambda x: x["GBs"])
+    return {"value": best["GBs"], "unit": "GB/s", "cores": best["thread_ranks"], "kind": "port", "cpu_model": cpu_model, "host_cores": host_cpus,
+            "cpus_allowed": allowed, "physical_cores_allowed": phys_cores, "cgroup_cpu_quota": quota, "samples": samples,
+            "sample": f"{best['products']} full products of the same sector, {best['thread_ranks']} thread-ranks (physical cores among the {allowed} CPUs of the "
+                      f"affinity mask: {phys_cores}{why}; reference spMatVec_mpi_main restated in oracle/hxv_oracle.c; matrix build {best['matrix_build_s']}s untimed)",
+            "s_per_matvec": best["s_per_matvec"]}
 
 
 def copy_rate_gbs(dev, nbytes=1 << 30, reps=5):

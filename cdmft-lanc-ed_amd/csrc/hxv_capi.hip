@@ -619,6 +619,10 @@ int hxv_set_option(hxv_handle* h, const char* name, int64_t value) {
     h->eigh_degenerate = value ? 1 : 0;
     return HXV_OK;
   }
+  if (!strcmp(name, "eigh_fuse_restart")) {
+    h->eigh_fuse_restart = value ? 1 : 0;
+    return HXV_OK;
+  }
   if (!strcmp(name, "eigh_measure_all")) {
     h->eigh_measure_all = value ? 1 : 0;
     return HXV_OK;
@@ -717,6 +721,7 @@ int64_t hxv_get_option(const hxv_handle* h, const char* name) {
   if (!strcmp(name, "open_cache_hit")) return h->open_cache_hit;
   if (!strcmp(name, "lanczos_graph")) return h->lz_graph;
   if (!strcmp(name, "eigh_degenerate")) return h->eigh_degenerate;
+  if (!strcmp(name, "eigh_fuse_restart")) return h->eigh_fuse_restart;
   if (!strcmp(name, "eigh_keep_pct")) return h->eigh_keep_pct;
   if (!strcmp(name, "eigh_measure_all")) return h->eigh_measure_all;
   if (!strcmp(name, "eigh_last_full_passes")) return h->eigh_last_full;

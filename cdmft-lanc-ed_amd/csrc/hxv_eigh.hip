@@ -191,6 +191,117 @@ void launch_rotate(int grid, hipStream_t st, int64_t n, double2* V, int64_t stri
     hipLaunchKernelGGL(tr_rotate<MAXCV>, dim3(grid), dim3(256), 0, st, n, V, stride, m, k, S);
 }
 
+// First step of a restart cycle, one pass instead of two: x = a*w - sum_{l<nv} c_l V_l (the arrow of T taken out with its KNOWN coefficients;
+// c_l = 0 for vectors that are only measured), stored back to w, and partial[blockIdx][2l..2l+1] = sum_i conj(V_l[i]) x[i] for all l < nv --
+// the measurement the following Gram-Schmidt pass needs.  Every V_l[i] is loaded once for both.  nv <= NJ.
+template <int NJ>
+__global__ void __launch_bounds__(256) tr_axpy_mdot(int64_t n, const double2* __restrict__ V, int64_t stride, int nv, const double* __restrict__ coef,
+                                                    double a, double2* __restrict__ w, double* __restrict__ partial) {
+  __shared__ double sc[NJ];
+  if ((int)threadIdx.x < NJ) sc[threadIdx.x] = (int)threadIdx.x < nv ? coef[threadIdx.x] : 0.0;
+  __syncthreads();
+  double re[NJ], im[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) re[j] = im[j] = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    double2 y[NJ];
+    double2 x = w[i];
+    x.x *= a;
+    x.y *= a;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+      if (j < nv) {
+        y[j] = V[(int64_t)j * stride + i];
+        x.x -= sc[j] * y[j].x;
+        x.y -= sc[j] * y[j].y;
+      }
+    w[i] = x;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+      if (j < nv) {
+        re[j] += y[j].x * x.x + y[j].y * x.y;
+        im[j] += y[j].x * x.y - y[j].y * x.x;
+      }
+  }
+  __shared__ double red[4][2 * NJ];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const double p = wave_sum(re[j]), q = wave_sum(im[j]);
+    if (lane == 0) {
+      red[wave][2 * j] = p;
+      red[wave][2 * j + 1] = q;
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < 2 * NJ)
+    partial[(int64_t)blockIdx.x * 2 * NJ + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// The restart rotation (tr_rotate) that also brings the residual vector r = V[m] to its new place V[k] and measures it against the k new
+// Ritz vectors as they are formed: partial[blockIdx][2j..2j+1] = sum_i conj(y_j[i]) r[i].  Replaces rotation + copy + one multi-dot pass.  k <= KD.
+template <int MAXM, int KD>
+__global__ void __launch_bounds__(256) tr_rotate_dots(int64_t n, double2* __restrict__ V, int64_t stride, int m, int k, const double* __restrict__ S,
+                                                      double* __restrict__ partial) {
+  __shared__ double sS[MAXM * KD];
+  for (int t = threadIdx.x; t < m * k; t += 256) sS[t] = S[t];
+  __syncthreads();
+  double re[KD], im[KD];
+#pragma unroll
+  for (int j = 0; j < KD; ++j) re[j] = im[j] = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    double2 x[MAXM];
+#pragma unroll
+    for (int l = 0; l < MAXM; ++l)
+      if (l < m) x[l] = V[(int64_t)l * stride + i];
+    const double2 r = V[(int64_t)m * stride + i];
+#pragma unroll
+    for (int j = 0; j < KD; ++j)
+      if (j < k) {
+        double yr = 0.0, yi = 0.0;
+#pragma unroll
+        for (int l = 0; l < MAXM; ++l)
+          if (l < m) {
+            const double sv = sS[l + j * m];
+            yr += sv * x[l].x;
+            yi += sv * x[l].y;
+          }
+        V[(int64_t)j * stride + i] = make_double2(yr, yi);
+        re[j] += yr * r.x + yi * r.y;
+        im[j] += yr * r.y - yi * r.x;
+      }
+    V[(int64_t)k * stride + i] = r;
+  }
+  __shared__ double red[4][2 * KD];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int j = 0; j < KD; ++j) {
+    const double p = wave_sum(re[j]), q = wave_sum(im[j]);
+    if (lane == 0) {
+      red[wave][2 * j] = p;
+      red[wave][2 * j + 1] = q;
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < 2 * KD)
+    partial[(int64_t)blockIdx.x * 2 * KD + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+constexpr int FUSE_NJ = 16;  // most vectors the two fused restart kernels handle (larger kept sets take the separate passes)
+
+bool launch_rotate_dots(int grid, hipStream_t st, int64_t n, double2* V, int64_t stride, int m, int k, const double* S, double* partial) {
+  if (k > FUSE_NJ) return false;
+  if (m <= 8)
+    hipLaunchKernelGGL((tr_rotate_dots<8, FUSE_NJ>), dim3(grid), dim3(256), 0, st, n, V, stride, m, k, S, partial);
+  else if (m <= 16)
+    hipLaunchKernelGGL((tr_rotate_dots<16, FUSE_NJ>), dim3(grid), dim3(256), 0, st, n, V, stride, m, k, S, partial);
+  else if (m <= 32)
+    hipLaunchKernelGGL((tr_rotate_dots<32, FUSE_NJ>), dim3(grid), dim3(256), 0, st, n, V, stride, m, k, S, partial);
+  else
+    hipLaunchKernelGGL((tr_rotate_dots<MAXCV, FUSE_NJ>), dim3(grid), dim3(256), 0, st, n, V, stride, m, k, S, partial);
+  return true;
+}
+
 // Cyclic Jacobi for a small dense real symmetric matrix (column-major n x n in A, destroyed).
 // On exit w = eigenvalues ascending, Z[:, i] = eigenvector i.
 bool jacobi_eigh(int n, std::vector<double>& A, std::vector<double>& w, std::vector<double>& Z) {
@@ -327,7 +438,7 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
   }
   mem.pooled.push_back(V);
   HIPCHK(hipMemsetAsync(V, 0, need, h->stream));  // pad rows must be zero: the products never write them, the dots read them
-  HIPCHK(hipMalloc((void**)&d_part, (size_t)TR_BLOCKS * (2 * JB + 1) * sizeof(double)));
+  HIPCHK(hipMalloc((void**)&d_part, (size_t)TR_BLOCKS * (2 * FUSE_NJ + 1) * sizeof(double)));  // ([blocks][2*JB] of tr_mdot or [blocks][2*FUSE_NJ] of the fused kernels, + [blocks] norms)
   mem.p.push_back(d_part);
   HIPCHK(hipMalloc((void**)&d_coef, (size_t)(2 * (MAXCV + 1) + 2) * sizeof(double)));
   mem.p.push_back(d_coef);
@@ -339,7 +450,7 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
   mem.p.push_back(d_csel);
   HIPCHK(hipMalloc((void**)&d_isel, (size_t)(MAXCV + 1) * sizeof(int)));
   mem.p.push_back(d_isel);
-  double* d_npart = d_part + (size_t)TR_BLOCKS * 2 * JB;
+  double* d_npart = d_part + (size_t)TR_BLOCKS * 2 * FUSE_NJ;
   double* d_nrm = d_coef + 2 * (MAXCV + 1);
   hipStream_t st = h->stream;
   auto vec = [&](int j) { return V + (int64_t)j * n; };
@@ -358,9 +469,10 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
   std::vector<double> nv(MAXCV + 2, 1.0);
   std::vector<double> c(2 * (MAXCV + 1)), csel(2 * (MAXCV + 1));
   std::vector<int> isel(MAXCV + 1);
-  auto gs_pass = [&](int jt, int nlock, bool all, double* nrm2_after) -> int {
+  // (dots_ready: d_coef already holds the raw sums <V_i, w> of all jt+1 vectors -- a fused kernel measured them on its way)
+  auto gs_pass = [&](int jt, int nlock, bool all, double* nrm2_after, bool dots_ready = false) -> int {
     const int nj = jt + 1;
-    for (int g0 = 0; g0 < nj; g0 += JB) {
+    for (int g0 = 0; g0 < nj && !dots_ready; g0 += JB) {
       const int nb = std::min(JB, nj - g0);
       hipLaunchKernelGGL(tr_mdot, dim3(g), dim3(256), 0, st, n, vec(g0), n, nb, vec(jt + 1), d_part);
       hipLaunchKernelGGL(tr_colsum, dim3(1), dim3(256), 0, st, d_part, g, 2 * JB, 2 * nb, d_coef + 2 * g0, real ? 1 : 0);
@@ -555,6 +667,7 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
         const bool fused_local = local_fused && !h->eigh_measure_all && j > k;
         int rc;
         double w2 = 0.0, arrow2 = 0.0;  // arrow2: squared length of what the first step of a cycle takes out with the known coefficients
+        bool first_dots_ready = false;  // the fused first step has measured the projections already
         if (fused_local) {
           double al = 0.0, nw = 0.0;
           rc = lanczos_local_step(h, real, av(j), nv[jt], av(j - 1), nv[jt - 1], t_at(j, j - 1), av(j + 1), nlock == 0, &al, &nw);
@@ -568,7 +681,9 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
           else if ((rc = gs_locked_alpha(jt, nlock, al, &w2)))
             return rc;
         } else {
-          normalise_slot(jt);
+          // (the first step of a cycle can take its input as stored: the fused kernel below divides by its length)
+          const bool fuse_first = j == k && k > 0 && !h->eigh_measure_all && jt + 1 <= FUSE_NJ && h->eigh_fuse_restart;
+          if (!fuse_first) normalise_slot(jt);
           rc = real ? apply_slab_real(h, (const double*)av(j), (double*)av(j + 1), st) : apply_slab(h, av(j), av(j + 1), st);
           if (rc) return rc;
           if (j == k && k > 0 && !h->eigh_measure_all) {
@@ -577,16 +692,28 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
             // projections).  One classical pass over "H q_k" would instead measure a projection BEFORE the others are subtracted, and the
             // kept Ritz vectors are orthogonal to each other only as far as the old basis was: the new vector would inherit
             // sum_l s_l <y_b, y_l> against each of them -- above the estimates' starting level after a long cycle.
-            for (int l = 0; l < k; ++l) {
-              isel[l] = nlock + l;
-              csel[2 * l] = s_keep[l] / (nv[nlock + l] * nv[nlock + l]);
-              csel[2 * l + 1] = 0.0;
-              arrow2 += s_keep[l] * s_keep[l];
+            for (int l = 0; l < k; ++l) arrow2 += s_keep[l] * s_keep[l];
+            if (fuse_first) {
+              // ONE pass: w = H(stored q_k) / |stored q_k| - arrow, and the projections of that w on all jt + 1 vectors (round 5; was an
+              // update pass plus a multi-dot pass)
+              std::vector<double> cf(FUSE_NJ, 0.0);
+              for (int l = 0; l < k; ++l) cf[nlock + l] = s_keep[l] / (nv[nlock + l] * nv[nlock + l]);
+              HIPCHK(hipMemcpyAsync(d_csel, cf.data(), (size_t)FUSE_NJ * sizeof(double), hipMemcpyHostToDevice, st));
+              hipLaunchKernelGGL((tr_axpy_mdot<FUSE_NJ>), dim3(g), dim3(256), 0, st, n, V, n, jt + 1, d_csel, 1.0 / nv[jt], av(j + 1), d_part);
+              hipLaunchKernelGGL(tr_colsum, dim3(1), dim3(256), 0, st, d_part, g, 2 * FUSE_NJ, 2 * (jt + 1), d_coef, real ? 1 : 0);
+              HIPCHK(hipStreamSynchronize(st));  // (cf is a host buffer)
+              first_dots_ready = true;
+            } else {
+              for (int l = 0; l < k; ++l) {
+                isel[l] = nlock + l;
+                csel[2 * l] = s_keep[l] / (nv[nlock + l] * nv[nlock + l]);
+                csel[2 * l + 1] = 0.0;
+              }
+              HIPCHK(hipMemcpyAsync(d_csel, csel.data(), (size_t)2 * k * sizeof(double), hipMemcpyHostToDevice, st));
+              HIPCHK(hipMemcpyAsync(d_isel, isel.data(), (size_t)k * sizeof(int), hipMemcpyHostToDevice, st));
+              hipLaunchKernelGGL(tr_maxpy, dim3(g), dim3(256), 0, st, n, V, n, k, d_isel, d_csel, av(j + 1), d_npart);
+              HIPCHK(hipStreamSynchronize(st));  // (csel / isel are host buffers the pass below reuses)
             }
-            HIPCHK(hipMemcpyAsync(d_csel, csel.data(), (size_t)2 * k * sizeof(double), hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(d_isel, isel.data(), (size_t)k * sizeof(int), hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(tr_maxpy, dim3(g), dim3(256), 0, st, n, V, n, k, d_isel, d_csel, av(j + 1), d_npart);
-            HIPCHK(hipStreamSynchronize(st));  // (csel / isel are host buffers the pass below reuses)
           }
         }
         ++nmv;
@@ -598,7 +725,7 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
         const bool first_after_restart = j == k;
         bool full = h->eigh_measure_all || first_after_restart;
         if (full) {
-          rc = gs_pass(jt, nlock, first_after_restart, &w2);
+          rc = gs_pass(jt, nlock, first_after_restart, &w2, first_dots_ready);
           ++n_full;
         } else if (fused_local) {
           ++n_local;
@@ -741,8 +868,15 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
       for (int i = 0; i < k; ++i)
         for (int l = 0; l < ma; ++l) Ssc[l + (size_t)i * ma] /= nv[nlock + l];
       HIPCHK(hipMemcpyAsync(d_S, Ssc.data(), (size_t)ma * k * sizeof(double), hipMemcpyHostToDevice, st));
-      launch_rotate(g, st, n, Va, n, ma, k, d_S);
-      HIPCHK(hipMemcpyAsync(av(k), av(ma), (size_t)n * sizeof(double2), hipMemcpyDeviceToDevice, st));
+      // (round 5) with nothing locked the rotation kernel also moves the residual vector to its new place and measures it against the Ritz
+      // vectors it forms: rotation + copy + one multi-dot pass in one pass over the basis
+      const bool fuse_rot = nlock == 0 && !h->eigh_measure_all && h->eigh_fuse_restart && launch_rotate_dots(g, st, n, Va, n, ma, k, d_S, d_part);
+      if (fuse_rot) {
+        hipLaunchKernelGGL(tr_colsum, dim3(1), dim3(256), 0, st, d_part, g, 2 * FUSE_NJ, 2 * k, d_coef, real ? 1 : 0);
+      } else {
+        launch_rotate(g, st, n, Va, n, ma, k, d_S);
+        HIPCHK(hipMemcpyAsync(av(k), av(ma), (size_t)n * sizeof(double2), hipMemcpyDeviceToDevice, st));
+      }
       HIPCHK(hipStreamSynchronize(st));  // Ssc (host) is reused at the next restart
       for (int i = 0; i < k; ++i) nv[nlock + i] = 1.0;
       nv[nlock + k] = nv[nlock + ma];
@@ -751,7 +885,7 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
         // the kept Ritz vectors: clean it once per restart, so that the estimates of the new cycle start from rounding
         // level for every pair they track
         double r2 = 0.0;
-        int rcr = gs_pass(nlock + k - 1, nlock, true, &r2);
+        int rcr = gs_pass(nlock + k - 1, nlock, true, &r2, fuse_rot);
         if (rcr) return rcr;
         ++n_full;
         if (r2 > 0.0) nv[nlock + k] = std::sqrt(r2);  // (its length after the clean-up; it stays unnormalised)

@@ -143,6 +143,7 @@ struct hxv_handle {
   int eigh_measure_all = 0;        // option "eigh_measure_all": hxv_eigh_lowest measures every projection at every step (round-1 behaviour)
   int64_t eigh_last_full = 0, eigh_last_local = 0;  // Gram-Schmidt passes of the last hxv_eigh_lowest: whole basis / local only
   int64_t eigh_last_search = 0, eigh_last_check = 0;  // products of the last hxv_eigh_lowest: the search / the check rounds for hidden copies
+  int eigh_fuse_restart = 1;       // option "eigh_fuse_restart": the restart rotation measures the residual vector, the first step of a cycle removes the arrow and measures in one pass
   int eigh_keep_pct = 20;          // option "eigh_keep_pct": share of the basis beyond the wanted pairs that a thick restart keeps
   int eigh_degenerate = 0;         // option "eigh_degenerate": 1 = hxv_eigh_lowest looks for further copies of degenerate levels (locking rounds; about
                                    // as many products again); 0 [default] = one Krylov space, what ARPACK (the call this replaces) does

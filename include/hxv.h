@@ -364,38 +364,47 @@ int hxv_get_csr(const hxv_handle *h, int32_t which, int64_t *rowptr, int32_t *co
 /* local diagonal (vecdim doubles; the engine requires a real diagonal) */
 int hxv_get_diag(const hxv_handle *h, double *diag);
 
-/* Options (name, value).  Behaviour:
- *   "kernel"          1 = tiled two-pass kernels [default], 0 = one thread per element (cross-check / fallback)
- *   "real_vectors"    1 [default] = device Lanczos drivers run on real vectors when H and the start vector are real
- *   "lanczos_fused"   1 [default] = recurrence fused into the product's epilogue; 0 = separate vector kernels
- *   "lanczos_graph"   1 [default] = fixed-length tridiagonalisations run device-only, three iterations per hipGraph
- *   "eigh_degenerate" 0 [default] = one Krylov space like ARPACK; 1 = hxv_eigh_lowest locks the converged pairs and looks for further copies of
- *                     degenerate levels (about as many products again)
- *   "eigh_measure_all" 0 [default] = partial re-orthogonalisation (loss of orthogonality estimated by the omega recurrence, whole-basis
- *                     Gram-Schmidt only when needed); 1 = every projection measured at every step (round-1 behaviour)
- * Pass A as pipelined jobs (LDS-DMA tile ring, one workgroup per CU): "job_up" 2 [default: for the fused Lanczos product only] | 1 (always) | 0 (one tile per
- *   workgroup), "job_groups" columns per job [about 100: equal runs per XCD], "job_cols" 1 (2: no jobs; the two-column kernels were slower and are not built), "job_stages" ring depth 2..8 [4, clamped
- *   to what fits the LDS].  The engine falls back to the one-tile kernels by itself where jobs do not apply (real vectors,
- *   stored diagonal, more than 24 in-block / 16 out-of-block entries per row, blocks over 960 rows).
- * Tile shape (changing one rebuilds the plan; invalid combinations are refused with a message):
- *   "cols_per_tile" 2|4|8 [4; complex vectors use at most 4 per tile], "rows_per_tile" 0|2|4|8 [0 = 4, or 8 for sectors whose row panels exceed the L2], "lds_budget_kb[_up|_dw]" 8..144 [64], "threads_up|_dw"
- *   256|512|1024 [1024], "sort_mode" 0..2 [0], "sort_mode_dw" 0|1 [1], "wt_cols" 2|4|8|16 [4], "tile_bits_up|_dw" (force the block bits),
- *   "lds_min_kb_up|_dw".
- * "lanczos_inplace" 0|1 [1]: on a split sector the device Lanczos vectors live in their slot of a gather buffer (three full-size
- *   buffers per rank instead of one plus three slabs; no slab copy per product; same numbers bit for bit); get "slab_copies" counts
- *   the exchanges that had to copy.
- * Scheduling knobs (results unchanged): "pair_rows" -1|0|1 [-1 = by sector size: pass B runs the two row groups of a 128-byte line
- *   back to back], "job_max_blocks" [32: pass A as jobs only up to this many blocks per spin], "fold_nd" 0|1 [1: spH0nd inside pass A],
- *   "eigh_keep_pct" 5..80 [20: share of the Krylov basis beyond the wanted pairs that a thick restart of hxv_eigh_lowest keeps],
- *   "exchange_overlap" 0|1 [0: exchange mode 2 of a split sector runs diagonal + up hops on a second stream WHILE the two transposes and the
- *   panel product are under way (the reference's order, ED_HAMILTONIAN_SPARSE_HxV.f90:250-296) and adds the dw part at the end; plain
- *   products only; 32 B per local state more HBM traffic than the fused form, for hiding pass A behind the links],
- *   "block_order" -1|0|1|2 [-1: dispatch order of a group's blocks in the tile kernels -- 1 by the particle number of the high orbitals
- *   (coupled blocks close together; the automatic choice where table classes are few), 0 largest block first, 2 natural].
- * Timing experiments (results are wrong or partial when set; refused unless HXV_EXPERIMENTS=1 is in the environment):
+/* Options (name, value), in three groups.  A maintainer needs group 1 only.
+ *
+ * 1. BEHAVIOUR (what the engine computes or which algorithm runs; results stay within the stated tolerances)
+ *   "kernel"            1 = tiled two-pass kernels [default], 0 = one thread per element (cross-check / fallback)
+ *   "real_vectors"      1 [default] = device Lanczos drivers run on real vectors when H and the start vector are real
+ *   "lanczos_fused"     1 [default] = recurrence fused into the product's epilogue; 0 = separate vector kernels
+ *   "lanczos_graph"     1 [default] = fixed-length tridiagonalisations run device-only, three iterations per hipGraph
+ *   "lanczos_inplace"   1 [default] = on a split sector the device Lanczos vectors live in their slot of a gather buffer (three full-size
+ *                       buffers per rank instead of one plus three slabs; no slab copy per product; same numbers bit for bit);
+ *                       get "slab_copies" counts the exchanges that had to copy
+ *   "eigh_degenerate"   0 [default] = one Krylov space like ARPACK; 1 = hxv_eigh_lowest locks the converged pairs and looks for further copies of
+ *                       degenerate levels (about as many products again)
+ *   "eigh_measure_all"  0 [default] = partial re-orthogonalisation (loss of orthogonality estimated by the omega recurrence, whole-basis
+ *                       Gram-Schmidt only when needed); 1 = every projection measured at every step
+ *   "eigh_keep_pct"     5..80 [20]: share of the Krylov basis beyond the wanted pairs that a thick restart of hxv_eigh_lowest keeps
+ *   "eigh_fuse_restart" 1 [default] = the restart rotation also measures the residual vector, the first step of a cycle removes the arrow and
+ *                       measures in one pass; 0 = separate passes (same algorithm)
+ *   "fold_nd"           1 [default] = spH0nd inside pass A; 0 = as its own pass over Hv
+ *   "exchange_overlap"  0 [default] | 1: exchange mode 2 of a split sector runs diagonal + up hops on a second stream WHILE the two transposes and
+ *                       the panel product are under way (the reference's order, ED_HAMILTONIAN_SPARSE_HxV.f90:250-296) and adds the dw part at the
+ *                       end; plain products only; 32 B per local state more HBM traffic, for hiding pass A behind the links
+ *
+ * 2. TILE SHAPE AND SCHEDULING (results unchanged up to summation order; changing a shape rebuilds a handle-private plan, the shared sector image
+ *    keeps the default one; invalid combinations are refused with a message)
+ *   "cols_per_tile" 2|4|8 [4; complex vectors use at most 4 per tile], "rows_per_tile" 0|2|4|8 [0 = 4, or 8 for sectors whose row panels exceed
+ *   the L2], "lds_budget_kb[_up|_dw]" 8..144 [64], "threads_up|_dw" 256|512|1024 [1024], "sort_mode" 0..2 [0], "sort_mode_dw" 0|1 [1],
+ *   "wt_cols" 2|4|8|16 [4], "tile_bits_up|_dw" (force the block bits), "lds_min_kb_up|_dw", "spread_banks" 0|1 [1].
+ *   Pass A as pipelined jobs (LDS-DMA tile ring, one workgroup per CU): "job_up" 2 [default: for the fused Lanczos product only] |
+ *   1 (always) | 0 (one tile per workgroup), "job_groups" columns per job [about 100], "job_cols" 1, "job_stages" ring depth 2..8 [4],
+ *   "job_max_blocks" [32].  The engine falls back to the one-tile kernels where jobs do not apply (real vectors, stored diagonal, more than
+ *   24 in-block / 16 out-of-block entries per row, blocks over 960 rows).
+ *   "pair_rows" -1|0|1 [-1 = by sector size: pass B runs the two row groups of a 128-byte line back to back],
+ *   "block_order" -1|0|1|2 [-1: dispatch order of a group's blocks -- 1 by the particle number of the high orbitals (coupled blocks close
+ *   together; the automatic choice where table classes are few), 0 largest block first, 2 natural].
+ *
+ * 3. TIMING EXPERIMENTS (results are wrong or partial when set; refused unless HXV_EXPERIMENTS=1 is in the environment)
  *   "passes" 1|2|3 [3], "debug" bit mask, "job_debug" bit mask.
- * hxv_get_option additionally reports plan statistics ("tile_bits_up", "nblocks_up", "slots_in_up_x100", "max_outer_up",
- *   "job_up_active", ..., "lanczos_real_last").                                                                  */
+ *
+ * hxv_get_option additionally reports plan statistics ("tile_bits_up", "nblocks_up", "slots_in_up_x100", "max_outer_up", "job_up_active", ...),
+ * driver read-backs ("lanczos_real_last", "eigh_last_full_passes", "eigh_last_local_passes", "eigh_last_search_products",
+ * "eigh_last_check_products", "slab_copies") and what the open cost ("open_cache_hit", "open_us_host|plan|upload|total").        */
 int hxv_set_option(hxv_handle *h, const char *name, int64_t value);
 int64_t hxv_get_option(const hxv_handle *h, const char *name);
 

@@ -13,6 +13,7 @@ sec.set_option("eigh_measure_all", int(os.environ.get("MEASURE_ALL", 0)))
 sec.set_option("lanczos_fused", int(os.environ.get("FUSED", 1)))
 sec.set_option("real_vectors", int(os.environ.get("REAL_VECTORS", 1)))
 sec.set_option("eigh_degenerate", int(os.environ.get("DEGENERATE", 0)))   # 1: plus the check rounds for hidden copies of degenerate levels
+sec.set_option("eigh_fuse_restart", int(os.environ.get("FUSE_RESTART", 1)))
 if "KEEP" in os.environ:
     sec.set_option("eigh_keep_pct", int(os.environ["KEEP"]))
 neigen, ncv = int(os.environ.get("NEIGEN", 2)), int(os.environ.get("NCV", 20))
