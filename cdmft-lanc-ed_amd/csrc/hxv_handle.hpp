@@ -145,8 +145,8 @@ struct hxv_handle {
   int64_t eigh_last_search = 0, eigh_last_check = 0;  // products of the last hxv_eigh_lowest: the search / the check rounds for hidden copies
   int eigh_fuse_restart = 1;       // option "eigh_fuse_restart": the restart rotation measures the residual vector, the first step of a cycle removes the arrow and measures in one pass
   int eigh_keep_pct = 20;          // option "eigh_keep_pct": share of the basis beyond the wanted pairs that a thick restart keeps
-  int eigh_degenerate = 0;         // option "eigh_degenerate": 1 = hxv_eigh_lowest looks for further copies of degenerate levels (locking rounds; about
-                                   // as many products again); 0 [default] = one Krylov space, what ARPACK (the call this replaces) does
+  int eigh_degenerate = 0;         // option "eigh_degenerate": 1 = hxv_eigh_lowest looks for further copies of degenerate levels (locking rounds; C3: +60
+                                   // products on 380); 0 [default] = one Krylov space, what ARPACK (the call this replaces) does
   int real_vectors = 1;            // option "real_vectors": device Lanczos drivers use real vectors when H and the start vector are real
   int lz_buf_mode = 0;             // layout the d_lz work vectors were last used in (0 complex, 1 real): the pad rows differ
   int last_real = 0;               // did the last device Lanczos run use real vectors (get_option "lanczos_real_last")

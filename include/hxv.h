@@ -290,7 +290,7 @@ int hxv_lanczos_tridiag_pair_host(hxv_handle *h, const void *vin_a_host, const v
  * rounding happens to bring them up, while ED_DIAG.f90:234-244 keeps every state within gs_threshold of the minimum.  DEFAULT = what
  * ARPACK does: one Krylov space, no extra work.  Option "eigh_degenerate" = 1 ASKS for the copies: once the wanted pairs have converged
  * they are locked and the same iteration in their orthogonal complement looks for a state below the current neigen-th lowest value (a
- * hidden copy), repeatedly -- about as many products again when there is nothing to find (C3: 220 + 220); every step of such a round
+ * hidden copy), repeatedly -- a round that finds nothing stops once the residual bound of its lowest Ritz value clears the level (C3: 380 products + 60; C2: up to as many again); every step of such a round
  * removes the locked eigenvectors (they are converged to `tol` only).  "Nothing below" is a HEURISTIC answer: the lowest Ritz value of
  * the complement minus its residual must clear the level from the second restart cycle on, with a falling residual -- a copy whose
  * overlap with the start vector is at rounding level can still be missed.  *nmatvec counts both; hxv_get_option(h,
@@ -375,7 +375,7 @@ int hxv_get_diag(const hxv_handle *h, double *diag);
  *                       buffers per rank instead of one plus three slabs; no slab copy per product; same numbers bit for bit);
  *                       get "slab_copies" counts the exchanges that had to copy
  *   "eigh_degenerate"   0 [default] = one Krylov space like ARPACK; 1 = hxv_eigh_lowest locks the converged pairs and looks for further copies of
- *                       degenerate levels (about as many products again)
+ *                       degenerate levels (C3: +60 products on 380; at worst as many again)
  *   "eigh_measure_all"  0 [default] = partial re-orthogonalisation (loss of orthogonality estimated by the omega recurrence, whole-basis
  *                       Gram-Schmidt only when needed); 1 = every projection measured at every step
  *   "eigh_keep_pct"     5..80 [20]: share of the Krylov basis beyond the wanted pairs that a thick restart of hxv_eigh_lowest keeps

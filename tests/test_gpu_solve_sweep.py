@@ -200,3 +200,46 @@ def test_green_function_channels_in_the_callers_order(built, symmetric):
         assert np.abs(a - r["alanc"][:25]).max() < 1e-9 and np.abs(b[1:] - r["blanc"][1:25]).max() < 1e-9, kd
     assert len(seen) == (4 if symmetric else 6)
     hxv.sector_cache_clear()
+
+
+def test_sector_cache_cap_and_switch(built):
+    """HXV_SECTOR_CACHE_MB caps the cached images (least recently used out first, open handles keep theirs alive); HXV_SECTOR_CACHE=0
+    turns the cache off.  Read once per process: checked in child processes."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = r"""
+import sys
+sys.path.insert(0, sys.argv[1] + "/cdmft-lanc-ed_amd")
+import numpy as np, torch, hxv
+from hxv import models
+m = models.hm_1dchain()
+v = None
+ref = {}
+held = hxv.HxvSector.from_model(m, 6, 6)                       # stays open while its image is evicted from the cache
+for rep in range(2):
+    for nup in (4, 5, 6, 7):
+        s = hxv.HxvSector.from_model(m, nup, 6)
+        x = torch.ones(s.Dim, dtype=torch.complex128, device="cuda") * (0.5 + 0.25j)
+        y = s.apply_device(x).cpu().numpy()
+        if rep == 0:
+            ref[nup] = y
+        else:
+            assert np.array_equal(ref[nup], y)
+        s.close()
+x = torch.ones(held.Dim, dtype=torch.complex128, device="cuda") * (0.5 + 0.25j)
+assert np.array_equal(held.apply_device(x).cpu().numpy(), ref[6])
+held.close()
+st = hxv.sector_cache_stats()
+print("STATS", st["entries"], st["bytes"], st["hits"], st["misses"])
+"""
+    for env_extra, check in (({"HXV_SECTOR_CACHE_MB": "2"}, lambda e, b, h, m: e <= 3 and b <= 2 << 20 and m >= 5 and h + m == 9),
+                             ({"HXV_SECTOR_CACHE": "0"}, lambda e, b, h, m: e == 0 and h == 0),
+                             ({}, lambda e, b, h, m: e == 4 and h == 4 and m == 5)):
+        env = dict(os.environ, **env_extra)
+        r = subprocess.run([sys.executable, "-c", prog, root], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, (env_extra, r.stdout[-500:], r.stderr[-2000:])
+        e, b, h, m = (int(x) for x in [l for l in r.stdout.splitlines() if l.startswith("STATS")][-1].split()[1:])
+        assert check(e, b, h, m), (env_extra, e, b, h, m)
