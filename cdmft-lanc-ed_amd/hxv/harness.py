@@ -101,7 +101,7 @@ def gf_solve(model, nup: int, ndw: int, nlanc: int = 200, symmetric: bool = Fals
     gs_ms = (time.perf_counter() - t0) * 1e3
     chans = channels if channels is not None else gf_channels(model, symmetric)
     real_ok = gs.real_vectors_available
-    recs, open_ms = [], []
+    recs, open_ms, open_hits = [], [], []
 
     def target(create):
         return (nup + 1, ndw) if (create and spin == 0) else (nup - 1, ndw) if spin == 0 else (nup, ndw + 1) if create else (nup, ndw - 1)
@@ -123,6 +123,7 @@ def gf_solve(model, nup: int, ndw: int, nlanc: int = 200, symmetric: bool = Fals
         t1 = time.perf_counter()
         open_ms.append((t1 - t0) * 1e3)
         hit = bool(sec.get_option("open_cache_hit"))
+        open_hits.append(hit)
         nl = min(sec.Dim, nlanc)                                         # :204-207
         vs = [start_vector(sec, ch) for ch in batch]
         _sync()
@@ -171,7 +172,7 @@ def gf_solve(model, nup: int, ndw: int, nlanc: int = 200, symmetric: bool = Fals
                "channels": len(recs), "channels_real": sum(1 for r in recs if r["kind"] != "mix_xi"), "channels_complex": sum(1 for r in recs if r["kind"] == "mix_xi"),
                "channels_paired": sum(1 for r in recs if r["paired"]), "sector_open_ms_mean": float(np.mean(open_ms)) if open_ms else 0.0,
                "sector_open_ms_max": float(np.max(open_ms)) if open_ms else 0.0, "sector_open_ms_first": float(open_ms[0]) if open_ms else 0.0,
-               "sector_opens": len(open_ms), "sector_open_cache_hits": sum(1 for r in recs if r["open_cache_hit"]),
+               "sector_opens": len(open_ms), "sector_open_cache_hits": int(sum(open_hits)),
                "real_channels_s": sum(r["tridiag_ms"] for r in recs if r["kind"] != "mix_xi") * 1e-3,
                "complex_channels_s": sum(r["tridiag_ms"] for r in recs if r["kind"] == "mix_xi") * 1e-3, "gf_solve_s": total_s}
     if keep_psi:
