@@ -119,7 +119,25 @@ def cpu_baseline(model, nup, ndw, budget_s=25.0):
             s.close()
         samples.append({"thread_ranks": P, "products": n, "s_per_matvec": dt, "GBs": 32.0 * dim / dt / 1e9, "matrix_build_s": round(build_s, 1)})
     best = max(samples, key=lambda x: x["GBs"])
-    return {"value": best["GBs"], "unit": "GB/s", "cores": best["thread_ranks"], "kind": "port", "cpu_model": cpu_model, "host_cores": host_cpus,
+    # SURVEY 8d asks for the C2 figure beside C3's: the same algorithm on the Ns=12 sector (6,6), same thread-rank count
+    c2 = None
+    try:
+        from hxv import models as _models
+
+        m2, P2 = _models.hm_1dchain(), min(best["thread_ranks"], 64)
+        secs = [OracleSector(m2, 6, 6, r, P2) for r in range(P2)]
+        d2 = secs[0].Dim
+        v2 = rng.standard_normal(d2) + 1j * rng.standard_normal(d2)
+        spMatVec_mpi_main(m2, 6, 6, P2, v2, repeat=2, sectors=secs)
+        t0 = time.time()
+        spMatVec_mpi_main(m2, 6, 6, P2, v2, repeat=20, sectors=secs)
+        dt2 = (time.time() - t0) / 20
+        for s in secs:
+            s.close()
+        c2 = {"workload": f"C2: {m2.name} sector (6,6) Dim={d2}", "thread_ranks": P2, "s_per_matvec": dt2, "GBs": 32.0 * d2 / dt2 / 1e9}
+    except Exception as e:  # (context only)
+        c2 = {"failed": str(e)}
+    return {"value": best["GBs"], "unit": "GB/s", "cores": best["thread_ranks"], "kind": "port", "cpu_model": cpu_model, "host_cores": host_cpus, "c2": c2,
             "cpus_allowed": allowed, "physical_cores_allowed": phys_cores, "cgroup_cpu_quota": quota, "samples": samples,
             "sample": f"{best['products']} full products of the same sector, {best['thread_ranks']} thread-ranks (physical cores among the {allowed} CPUs of the "
                       f"affinity mask: {phys_cores}{why}; reference spMatVec_mpi_main restated in oracle/hxv_oracle.c; matrix build {best['matrix_build_s']}s untimed)",
