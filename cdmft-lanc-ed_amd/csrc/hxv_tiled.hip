@@ -17,6 +17,10 @@
 
 #include "hxv_tile_dev.hpp"
 
+#ifndef HXV_PAIR_LDS
+#define HXV_PAIR_LDS 1  // (0: A/B builds only -- the real-vector pass A with one 8-byte LDS element per column)
+#endif
+
 namespace hxv {
 
 // ---------------------------------------------------------------------------------------
@@ -64,10 +68,25 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
   const int nc = min(C, s.qdw - c0);
   CT* lcoef = reinterpret_cast<CT*>(lds + C * n);
   const VT* __restrict__ vcol0 = v + (int64_t)(s.slab0 + c0) * s.pitch;
+  // REAL vectors (round 5): the columns of a tile are independent batch entries here (the up hops act on rows), so two adjacent columns
+  // share one 16-byte LDS element: an in-block hop costs C/2 ds_read_b128 instead of C ds_read_b64 -- the LDS access pattern of the
+  // complex kernel, for which the hop lists were dealt over the banks.  Same FMAs in the same order: bit-identical results.
+  constexpr bool PL = HXV_PAIR_LDS && sizeof(VT) == 8 && (C % 2 == 0);
+  auto lidx = [&](int cc, int r) -> int { return PL ? ((((cc >> 1) * n + r) << 1) + (cc & 1)) : cc * n + r; };
+  if constexpr (PL) {
+    double2* l2 = reinterpret_cast<double2*>(lds);
 #pragma unroll
-  for (int cc = 0; cc < C; ++cc) {
-    const VT* __restrict__ src = vcol0 + (int64_t)min(cc, nc - 1) * s.pitch + r0;
-    for (int r = threadIdx.x; r < n; r += T) lds[cc * n + r] = src[r];
+    for (int pc = 0; pc < C / 2; ++pc) {
+      const VT* __restrict__ sa = vcol0 + (int64_t)min(2 * pc, nc - 1) * s.pitch + r0;
+      const VT* __restrict__ sb = vcol0 + (int64_t)min(2 * pc + 1, nc - 1) * s.pitch + r0;
+      for (int r = threadIdx.x; r < n; r += T) l2[pc * n + r] = make_double2((double)sa[r], (double)sb[r]);
+    }
+  } else {
+#pragma unroll
+    for (int cc = 0; cc < C; ++cc) {
+      const VT* __restrict__ src = vcol0 + (int64_t)min(cc, nc - 1) * s.pitch + r0;
+      for (int r = threadIdx.x; r < n; r += T) lds[cc * n + r] = src[r];
+    }
   }
   for (int q = threadIdx.x; q < t.nscoef; q += T) lcoef[q] = Coef<REAL>::from(t.scoef[q]);
   uint32_t* lrq = reinterpret_cast<uint32_t*>(lcoef + t.nscoef);  // (ND only; the launcher adds the bytes)
@@ -118,6 +137,15 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
         const VT* __restrict__ wcol = wb + (int64_t)c0 * wstr + wrow;
 #pragma unroll
         for (int cc = 0; cc < C; ++cc) acc[cc] = wcol[(int64_t)min(cc, nc - 1) * wstr];
+      } else if (wt && wc < 0) {
+        // REAL vectors whose pass B ran on PAIRS of rows (launch_tiled_vt: the complex kernel on the vector viewed as DimUp/2 rows of
+        // double2 -- rows are independent in pass B): the scratch is wt[group][row pair][-wc][row parity]
+        if constexpr (sizeof(VT) == 8) {
+          const int wcp = -wc, row = r0 + p;
+          const VT* __restrict__ wrow = wt + ((((int64_t)(c0 / wcp) * ((s.dimup + 1) >> 1) + (row >> 1)) * wcp + (c0 % wcp)) << 1) + (row & 1);
+#pragma unroll
+          for (int cc = 0; cc < C; ++cc) acc[cc] = wrow[2 * min(cc, nc - 1)];
+        }
       } else if (wt) {
         const VT* __restrict__ wrow = wt + ((int64_t)(c0 / wc) * s.dimup + r0 + p) * wc + (c0 % wc);
 #pragma unroll
@@ -140,7 +168,7 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
     const int kin = (int)(packed & 0xFFFFu);
     if (LZ) {
 #pragma unroll
-      for (int cc = 0; cc < C; ++cc) xq[LZ ? cc : 0] = lds[cc * n + p];
+      for (int cc = 0; cc < C; ++cc) xq[LZ ? cc : 0] = lds[lidx(cc, p)];
     }
     const int i = r0 + p;  // pass A visits the rows in natural order: every global access stays coalesced
     const int r = p;
@@ -148,13 +176,13 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
 #pragma unroll
       for (int cc = 0; cc < C; ++cc) {
         const double d = diag_value<NORB1>(s.diag, au, mu, s.dw0 + min(c0 + cc, s.qdw - 1));
-        Coef<true>::fma(acc[cc], d, lds[cc * n + r]);
+        Coef<true>::fma(acc[cc], d, lds[lidx(cc, r)]);
       }
     } else {
 #pragma unroll
       for (int cc = 0; cc < C; ++cc) {
         const double d = s.diag.stored[(int64_t)min(c0 + cc, s.qdw - 1) * s.dimup + i];
-        Coef<true>::fma(acc[cc], d, lds[cc * n + r]);
+        Coef<true>::fma(acc[cc], d, lds[lidx(cc, r)]);
       }
     }
     // hops that leave the block, same columns, other rows: from global memory (L2 of this XCD)
@@ -256,8 +284,18 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
             off = (int)(e[u] & TILE_OFF_MASK);
           }
           const CT cf = lcoef[ci];
+          if constexpr (PL) {
+            const double2* l2 = reinterpret_cast<const double2*>(lds);
 #pragma unroll
-          for (int cc = 0; cc < C; ++cc) Coef<REAL>::fma(acc[cc], cf, lds[cc * n + off]);
+            for (int pc = 0; pc < C / 2; ++pc) {
+              const double2 x2 = l2[pc * n + off];
+              Coef<REAL>::fma(acc[2 * pc], cf, x2.x);
+              Coef<REAL>::fma(acc[2 * pc + 1], cf, x2.y);
+            }
+          } else {
+#pragma unroll
+            for (int cc = 0; cc < C; ++cc) Coef<REAL>::fma(acc[cc], cf, lds[cc * n + off]);
+          }
         }
       }
     }
@@ -1273,12 +1311,34 @@ static hipError_t launch_tiled_vt(const DevSector& s, const TilePlan& plan, cons
   const int ta = plan.opt.threads_up, tb = plan.opt.threads_dw;
   const bool norb1 = s.diag.mode == 0 && s.diag.cross.norb == 1;
   hipError_t e = hipSuccess;
-  if (passes & 2) switch (R) {
-      case 2: e = launch_dw<2, VT>(s, td, plan.dw.max_block, lds_b, tb, wc, v, wt, st); break;
-      case 4: e = launch_dw<4, VT>(s, td, plan.dw.max_block, lds_b, tb, wc, v, wt, st); break;
-      default: e = launch_dw<8, VT>(s, td, plan.dw.max_block, lds_b, tb, wc, v, wt, st); break;
+  // REAL vectors: pass B treats rows as independent batch entries (the dw hops act on columns), so a real vector IS a complex vector of
+  // DimUp/2 rows with real coefficients: the complex kernel does one table decode and one 16-byte LDS gather where the double kernel
+  // does two of each (round 5: 1.23 -> ~1.0 ms at C3; option "real_dw_pairs").  The scratch then holds row PAIRS, which pass A's
+  // accumulator init reads with a stride (negative wc tells it); natural-layout outputs (row panels of exchange mode 2) are unchanged.
+  bool dw_pairs = false;
+  if constexpr (RV) dw_pairs = plan.opt.real_dw_pairs && (passes & 2) && (s.pitch % 2 == 0);
+  if (passes & 2) {
+    if constexpr (RV) {
+      if (dw_pairs) {
+        DevSector sp = s;
+        sp.dimup = (s.dimup + 1) / 2;
+        sp.pitch = s.pitch / 2;
+        const double2* v2 = reinterpret_cast<const double2*>(v);
+        double2* w2 = reinterpret_cast<double2*>(wt);
+        if (R == 4)
+          e = launch_dw<2, double2>(sp, td, plan.dw.max_block, lds_b, tb, wc, v2, w2, st);
+        else
+          e = launch_dw<4, double2>(sp, td, plan.dw.max_block, lds_b, tb, wc, v2, w2, st);
+      }
     }
+    if (!dw_pairs) switch (R) {
+        case 2: e = launch_dw<2, VT>(s, td, plan.dw.max_block, lds_b, tb, wc, v, wt, st); break;
+        case 4: e = launch_dw<4, VT>(s, td, plan.dw.max_block, lds_b, tb, wc, v, wt, st); break;
+        default: e = launch_dw<8, VT>(s, td, plan.dw.max_block, lds_b, tb, wc, v, wt, st); break;
+      }
+  }
   if (e != hipSuccess) return e;
+  if (dw_pairs && wc > 0) wc = -wc;  // (pass A: the blocked scratch holds row pairs)
   const VT* wta = ((passes & 2) || only_pass == 1) ? wt : nullptr;
   if constexpr (!RV) {
     if (job_a) return launch_up_job(s, plan, tu, wc, v, wta, hv, lz, st);
