@@ -2,6 +2,7 @@
 // that implement the C-ABI (hxv_capi.hip: handles + products; hxv_lanczos.hip: Lanczos recurrences; hxv_eigh.hip: thick-restart eigensolver).
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -153,7 +154,7 @@ struct hxv_handle {
   int kernel = 1;
   // split sector: RCCL communicator over the nranks handles (hxv_comm_init) and the gathered vector
   void* comm = nullptr;          // ncclComm_t
-  int comm_aborted = 0;          // hxv_comm_abort has run on `comm` (freed by ncclCommAbort: never destroyed again, never used again)
+  std::atomic<int> comm_aborted{0};  // hxv_comm_abort has run (from ANOTHER host thread while this rank's own sits in a collective) on `comm` (freed by ncclCommAbort: never destroyed again, never used again)
   void* comm_api = nullptr;      // the RCCL entry points that communicator was created with (hxv_comm.cpp: the system's librccl, or HXV_RCCL_LIB)
   void* lgroup = nullptr;        // thread ranks of one process (hxv_comm_init_local): the group object, see hxv_comm.cpp
   const char* xfer_send = nullptr;         // thread ranks: what this rank offers in the column exchange under way (comm_sendrecv_cols)
