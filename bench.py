@@ -31,7 +31,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT / "cdmft-lanc-ed_amd"))
 sys.path.insert(0, str(ROOT))
 
-KERNELS_STAMP = "r04-a"   # bumped whenever the product kernels change: profiles/traffic.json is quoted only for the same stamp
+KERNELS_STAMP = "r05-a"   # bumped whenever the product kernels change: profiles/traffic.json is quoted only for the same stamp
 XGMI_LINK_GBS = 153.0  # one xGMI link, per direction (7 links per GPU: SURVEY.md 8e)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 

@@ -644,6 +644,10 @@ int hxv_set_option(hxv_handle* h, const char* name, int64_t value) {
     h->plan.opt.real_dw_pairs = value ? 1 : 0;
     return HXV_OK;
   }
+  if (!strcmp(name, "wt_colmajor")) {
+    h->plan.opt.wt_colmajor = value ? 1 : 0;
+    return HXV_OK;
+  }
   if (!strcmp(name, "block_order")) {
     if (value < -1 || value > 2) return fail(HXV_ERR_ARG, "block_order must be -1, 0, 1 or 2");
     h->plan.opt.block_order = (int)value;
@@ -740,6 +744,7 @@ int64_t hxv_get_option(const hxv_handle* h, const char* name) {
   if (!strcmp(name, "tile_bits_up")) return h->plan.up.lowbits;
   if (!strcmp(name, "tile_bits_dw")) return h->plan.dw.lowbits;
   if (!strcmp(name, "real_dw_pairs")) return h->plan.opt.real_dw_pairs;
+  if (!strcmp(name, "wt_colmajor")) return h->plan.opt.wt_colmajor;
   if (!strcmp(name, "cols_per_tile")) return h->plan.opt.cols_per_tile;
   if (!strcmp(name, "rows_per_tile")) return h->plan.opt.rows_per_tile;
   if (!strcmp(name, "p16_bits_up")) return h->plan.up.p16_bits;

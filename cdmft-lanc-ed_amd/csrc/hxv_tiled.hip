@@ -137,15 +137,16 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
         const VT* __restrict__ wcol = wb + (int64_t)c0 * wstr + wrow;
 #pragma unroll
         for (int cc = 0; cc < C; ++cc) acc[cc] = wcol[(int64_t)min(cc, nc - 1) * wstr];
-      } else if (wt && wc < 0) {
-        // REAL vectors whose pass B ran on PAIRS of rows (launch_tiled_vt: the complex kernel on the vector viewed as DimUp/2 rows of
-        // double2 -- rows are independent in pass B): the scratch is wt[group][row pair][-wc][row parity]
-        if constexpr (sizeof(VT) == 8) {
-          const int wcp = -wc, row = r0 + p;
-          const VT* __restrict__ wrow = wt + ((((int64_t)(c0 / wcp) * ((s.dimup + 1) >> 1) + (row >> 1)) * wcp + (c0 % wcp)) << 1) + (row & 1);
+      } else if (wt && (wc >> 8)) {
+        // blocked scratch with COLUMN-MAJOR patches (round 5): wt[group][patch of Rp rows][wcl columns][Rp rows], Rp = pass B's rows per tile in
+        // this kernel's element units.  Pass B still writes Rp*wcl*16 contiguous bytes per patch; here the Rp lanes of a patch read Rp*16
+        // contiguous bytes per column instead of each lane its own 64-byte stretch four (eight) times over: a quarter of the L1 accesses
+        // for the same lines.  (REAL vectors whose pass B ran on row pairs arrive in the same layout: a pair of rows IS two rows of it.)
+        const int wcl = wc & 0xFF, Rp = wc >> 8, row = r0 + p;
+        const int dR = (s.dimup + Rp - 1) & ~(Rp - 1);
+        const VT* __restrict__ wrow = wt + ((int64_t)(c0 / wcl) * dR + (row & ~(Rp - 1))) * wcl + (int64_t)(c0 % wcl) * Rp + (row & (Rp - 1));
 #pragma unroll
-          for (int cc = 0; cc < C; ++cc) acc[cc] = wrow[2 * min(cc, nc - 1)];
-        }
+        for (int cc = 0; cc < C; ++cc) acc[cc] = wrow[min(cc, nc - 1) * Rp];
       } else if (wt) {
         const VT* __restrict__ wrow = wt + ((int64_t)(c0 / wc) * s.dimup + r0 + p) * wc + (c0 % wc);
 #pragma unroll
@@ -594,20 +595,23 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_dw(DevSector s, DevTiles t, 
   // memory system -- and pass A later reads its whole tile of wt as one contiguous run.  A sweep of the workgroup covers
   // T/(R*wc) groups = T/R columns; uniform base and LDS address advance by constants from sweep to sweep.
   {
+    const bool cm = (wc & 0x100) != 0;       // column-major patches (pass A's tile kernel reads them with a quarter of the L1 accesses)
+    wc &= 0xFF;
     const int lw = 31 - __clz(wc);
     const int g0 = cl0 >> lw, g1 = (cl1 + wc - 1) >> lw;
     const int per = R << lw;                 // elements of one group's patch
     const int gstep = T >> (LR + lw);        // groups per sweep (T >= R*wc)
-    const int rem = tid & (per - 1);
-    const int r2 = rem >> lw, cc = rem & (wc - 1);
+    const int rem = tid & (per - 1);         // this thread's element of the patch = its place in the patch's contiguous bytes
+    const int r2 = cm ? (rem & (R - 1)) : (rem >> lw), cc = cm ? (rem >> LR) : (rem & (wc - 1));
     const int gi = tid >> (LR + lw);
     const bool rowok = i0 + r2 < s.dimup;
     int lc = ((g0 + gi) << lw) + cc;         // local column of this thread in the current sweep
-    const uint32_t so = (uint32_t)gi * ((uint32_t)s.dimup * per / R * VB) + (uint32_t)rem * VB;
+    const uint32_t drows = cm ? (uint32_t)((s.dimup + R - 1) & ~(R - 1)) : (uint32_t)s.dimup;  // rows of a group's stretch (whole patches when column-major)
+    const uint32_t so = (uint32_t)gi * (drows * per / R * VB) + (uint32_t)rem * VB;
     // LDS byte offset of (column, row); a sweep advances the column by T/R, which leaves its swizzle bits alone
     uint32_t lo = ltile + (uint32_t)(((lc + s.dw0 - cb0) << LTB) + ((r2 << LVB) ^ (int)swz_of((uint32_t)(lc + s.dw0 - cb0))));
-    char* __restrict__ dstb = reinterpret_cast<char*>(wt) + ((int64_t)g0 * s.dimup + i0) * ((int64_t)VB << lw);
-    const int64_t dstep = (int64_t)gstep * s.dimup * ((int64_t)VB << lw);
+    char* __restrict__ dstb = reinterpret_cast<char*>(wt) + ((int64_t)g0 * drows + i0) * ((int64_t)VB << lw);
+    const int64_t dstep = (int64_t)gstep * drows * ((int64_t)VB << lw);
     for (int g = g0; g < g1; g += gstep) {
       // streaming store: wt is read back once, by pass A, long after it has left L2; not letting it linger leaves the L2
       // to the tile lines that the out-of-block gathers of the neighbouring workgroups hit (-3 % on pass B, measured)
@@ -1230,7 +1234,7 @@ std::string make_tile_plan(const SectorHost& s, TilePlan& plan, const PlanUpload
 
 int64_t tiled_wt_elems(const DevSector& s, const TilePlan& plan) {
   const int wc = std::max(plan.opt.cols_per_tile, plan.opt.wt_cols);
-  return (int64_t)((s.qdw + wc - 1) / wc) * wc * s.dimup;
+  return (int64_t)((s.qdw + wc - 1) / wc) * wc * ((s.dimup + 15) & ~15);  // (whole patches of up to 8 complex / 16 real rows per group)
 }
 
 // Real-vector mode runs the same plans with twice the columns (pass A) / rows (pass B) per tile: the same tile bytes.
@@ -1313,10 +1317,14 @@ static hipError_t launch_tiled_vt(const DevSector& s, const TilePlan& plan, cons
   hipError_t e = hipSuccess;
   // REAL vectors: pass B treats rows as independent batch entries (the dw hops act on columns), so a real vector IS a complex vector of
   // DimUp/2 rows with real coefficients: the complex kernel does one table decode and one 16-byte LDS gather where the double kernel
-  // does two of each (round 5: 1.23 -> ~1.0 ms at C3; option "real_dw_pairs").  The scratch then holds row PAIRS, which pass A's
-  // accumulator init reads with a stride (negative wc tells it); natural-layout outputs (row panels of exchange mode 2) are unchanged.
+  // does two of each (round 5: 1.23 -> ~1.0 ms at C3; option "real_dw_pairs").  With column-major patches the scratch it writes is the
+  // real kernel's own layout (a pair of rows = two rows of a patch); natural-layout outputs (row panels of exchange mode 2) likewise.
   bool dw_pairs = false;
   if constexpr (RV) dw_pairs = plan.opt.real_dw_pairs && (passes & 2) && (s.pitch % 2 == 0);
+  // blocked scratch: column-major patches for the tile kernels (pass A reads them with a quarter of the L1 accesses); the job kernel's
+  // group buffers keep the row-major patches.  Row pairs need them (their scratch would otherwise interleave the two rows of a pair).
+  const bool cm = wc > 0 && !job_a && (plan.opt.wt_colmajor || dw_pairs);
+  const int wc_b = cm ? (wc | 0x100) : wc;
   if (passes & 2) {
     if constexpr (RV) {
       if (dw_pairs) {
@@ -1326,19 +1334,19 @@ static hipError_t launch_tiled_vt(const DevSector& s, const TilePlan& plan, cons
         const double2* v2 = reinterpret_cast<const double2*>(v);
         double2* w2 = reinterpret_cast<double2*>(wt);
         if (R == 4)
-          e = launch_dw<2, double2>(sp, td, plan.dw.max_block, lds_b, tb, wc, v2, w2, st);
+          e = launch_dw<2, double2>(sp, td, plan.dw.max_block, lds_b, tb, wc_b, v2, w2, st);
         else
-          e = launch_dw<4, double2>(sp, td, plan.dw.max_block, lds_b, tb, wc, v2, w2, st);
+          e = launch_dw<4, double2>(sp, td, plan.dw.max_block, lds_b, tb, wc_b, v2, w2, st);
       }
     }
     if (!dw_pairs) switch (R) {
-        case 2: e = launch_dw<2, VT>(s, td, plan.dw.max_block, lds_b, tb, wc, v, wt, st); break;
-        case 4: e = launch_dw<4, VT>(s, td, plan.dw.max_block, lds_b, tb, wc, v, wt, st); break;
-        default: e = launch_dw<8, VT>(s, td, plan.dw.max_block, lds_b, tb, wc, v, wt, st); break;
+        case 2: e = launch_dw<2, VT>(s, td, plan.dw.max_block, lds_b, tb, wc_b, v, wt, st); break;
+        case 4: e = launch_dw<4, VT>(s, td, plan.dw.max_block, lds_b, tb, wc_b, v, wt, st); break;
+        default: e = launch_dw<8, VT>(s, td, plan.dw.max_block, lds_b, tb, wc_b, v, wt, st); break;
       }
   }
   if (e != hipSuccess) return e;
-  if (dw_pairs && wc > 0) wc = -wc;  // (pass A: the blocked scratch holds row pairs)
+  if (cm) wc |= R << 8;  // (pass A: patch rows in ITS element units -- R real rows also when pass B ran on R/2 row pairs)
   const VT* wta = ((passes & 2) || only_pass == 1) ? wt : nullptr;
   if constexpr (!RV) {
     if (job_a) return launch_up_job(s, plan, tu, wc, v, wta, hv, lz, st);

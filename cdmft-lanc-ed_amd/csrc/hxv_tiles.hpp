@@ -73,6 +73,7 @@ struct TileOptions {
   int block_order = -1;  // dispatch order of a group's blocks in the tile kernels: 0 largest first (= by table class), 1 by the particle
                          // number of the high orbitals (coupled blocks close together: L2 hits of the out-of-block gathers), 2 natural,
                          // -1 automatic
+  int wt_colmajor = 1;    // blocked dw-hop scratch with column-major patches (tile kernels; the job kernel keeps row-major ones)
   int real_dw_pairs = 1;  // REAL vectors: pass B runs the complex kernel on pairs of rows (one decode and one 16-byte gather per two elements)
   int pair_rows = -1;  // pass B order: -1 automatic (paired row groups when two panels exceed the XCD's L2), 0 off, 1 on
   int job_max_blocks = 32;  // pass A runs as jobs only up to this many blocks per spin (beyond, one chunk's jobs no longer fit an XCD's CUs)

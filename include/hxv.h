@@ -395,6 +395,8 @@ int hxv_get_diag(const hxv_handle *h, double *diag);
  *   1 (always) | 0 (one tile per workgroup), "job_groups" columns per job [about 100], "job_cols" 1, "job_stages" ring depth 2..8 [4],
  *   "job_max_blocks" [32].  The engine falls back to the one-tile kernels where jobs do not apply (real vectors, stored diagonal, more than
  *   24 in-block / 16 out-of-block entries per row, blocks over 960 rows).
+ *   "wt_colmajor" 0|1 [1: the blocked dw-hop scratch holds column-major patches -- pass A's accumulator init reads R*16 contiguous bytes per column
+ *   and patch instead of every lane its own 64-byte stretch; bit-identical],
  *   "real_dw_pairs" 0|1 [1: pass B of the REAL-vector product runs the complex kernel on pairs of rows -- one table decode and one 16-byte LDS
  *   gather per two elements, bit-identical],
  *   "pair_rows" -1|0|1 [-1 = by sector size: pass B runs the two row groups of a 128-byte line back to back],
