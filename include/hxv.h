@@ -266,7 +266,11 @@ int hxv_lanczos_eigh_host(hxv_handle *h, int32_t nitermax, double threshold, dou
  * alanc_x/blanc_x[nlanc], *nsteps_x as in hxv_lanczos_tridiag.  Each component's numbers are bit-identical to
  * hxv_lanczos_tridiag on that start vector through the same kernels (option real_vectors = 0; any job_up).
  * Split sectors: slabs per rank, every sum all-reduced (any exchange).  The _host form takes the start vectors in the reference's
- * contiguous host layout.                                                                                                 */
+ * contiguous host layout.
+ * What does NOT pair: the (c^+_i + xi c^+_j)|gs>, (c_i - xi c_j)|gs> channels of the reference's default chan4 form (ED_GF_NORMAL.f90:746-780,
+ * :827-861) have COMPLEX start vectors even at real H -- 24 of the 56 runs of a 2x2 solve; they go through hxv_lanczos_tridiag on complex
+ * vectors (C3: 5.5 ms per step against 2.8 ms per paired real channel-step).  For real symmetric H they carry nothing the real channels do
+ * not; the reference's own ed_gf_symmetric (chan2) drops them: INTEGRATION.md section 4.                                            */
 int hxv_lanczos_tridiag_pair(hxv_handle *h, const void *d_vin_a, const void *d_vin_b, int32_t nlanc, double *alanc_a, double *blanc_a,
                              double *alanc_b, double *blanc_b, double threshold, int32_t *nsteps_a, int32_t *nsteps_b);
 int hxv_lanczos_tridiag_pair_host(hxv_handle *h, const void *vin_a_host, const void *vin_b_host, int32_t nlanc, double *alanc_a,
