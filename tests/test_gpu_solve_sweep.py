@@ -123,6 +123,27 @@ def test_every_sector_of_c2_against_the_oracle(built):
         assert err <= 1e-10, (r, g)
     nl = [r for r in recs if r["lanczos"]]
     assert len(nl) == sum(1 for g in ref.values() if g["dim"] > 1024)
+    # the edge sectors (nup or ndw in {0, Ns}: DimUp = 1 or DimDw = 1, one of the two passes has nothing to couple) through the PRODUCT as well:
+    # H x v against the oracle's spMatVec_main, tiled kernels and the one-thread-per-element cross-check
+    import torch
+    from hxv.models import deterministic_vector
+    from oracle.oracle import OracleSector
+
+    Ns, nedge = 12, 0
+    for nup in range(Ns + 1):
+        for ndw in range(Ns + 1):
+            if nup not in (0, Ns) and ndw not in (0, Ns):
+                continue
+            sec = hxv.HxvSector.from_model(m, nup, ndw)
+            v = deterministic_vector(sec.Dim)
+            want = OracleSector(m, nup, ndw).spMatVec_main(v)
+            for kern in (1, 0):
+                sec.set_option("kernel", kern)
+                got = sec.apply_device(torch.from_numpy(v).cuda()).cpu().numpy()
+                assert np.abs(got - want).max() <= 1e-13 * max(np.abs(want).max(), 1e-300), (nup, ndw, kern)
+            sec.close()
+            nedge += 1
+    assert nedge == 48
     print(f"C2 sweep: {len(recs)} sectors ({len(nl)} above the Lanczos threshold), worst |dE| {worst:.2e}, open {sum(r['open_ms'] for r in recs):.0f} ms, "
           f"solve {sum(r['solve_ms'] for r in recs):.0f} ms, close {sum(r['close_ms'] for r in recs):.0f} ms")
 
