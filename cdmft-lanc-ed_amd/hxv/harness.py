@@ -99,8 +99,16 @@ def gf_solve(model, nup: int, ndw: int, nlanc: int = 200, symmetric: bool = Fals
         e0, psi, gs_nmv = gs.lanczos_eigh(512, 1e-13, native=True)
     _sync()
     gs_ms = (time.perf_counter() - t0) * 1e3
-    chans = channels if channels is not None else gf_channels(model, symmetric)
+    # ED_DIAG closes the sector after the spectrum stage (delete_Hv_sector, ED_DIAG.f90:186); the Green's-function stage only needs its
+    # basis again (build_sector, ED_GF_NORMAL.f90:165).  Here: close and re-open -- the re-open shares the cached image and holds no
+    # Lanczos vectors or scratch (at Ns=18 those are 95 GB the channels need)
     real_ok = gs.real_vectors_available
+    gs.close()
+    from .engine import pool_trim
+    pool_trim(device)
+    torch.cuda.empty_cache()
+    gs = HxvSector.from_model(model, nup, ndw, device=device)
+    chans = channels if channels is not None else gf_channels(model, symmetric)
     recs, open_ms, open_hits = [], [], []
 
     def target(create):

@@ -3,9 +3,11 @@
   (a) every sector of C2 (Ns=12) in ED_DIAG's order: open -> sp_eigh(2, 20) -> close, against tests/golden/c2_sector_sweep.json;
   (b) the 56 Green's-function channels of one default solve at C3 (Ns=16, ground state in (8,8)), the target sector opened and closed
       around every channel as ED_GF_NORMAL.f90:208-222 does -- and the same with ed_gf_symmetric (32 real channels);
-  (c) DIAG16=1: every sector of C3 (289) through ED_DIAG's loop.
+  (c) every sector of C3 (289) through ED_DIAG's loop;
+  (d) Ns=18 (C5, Dim = 2.36e9, 37.8 GB per complex vector): ground state of (9,9) by the three-vector Lanczos (a Krylov basis of 21 real
+      vectors would need 397 GB), then the first channels of the list, paired, NLANC_C5 steps (default 40).
 Prints per-sector / per-channel open, solve and close times.   python scripts/solve_sweep.py > profiles/r05_solve_sweep.txt
-Environment: PARTS=abc (default ab), NLANC (200), SECTOR_CACHE is the library's HXV_SECTOR_CACHE."""
+Environment: PARTS=abcd (default ab), NLANC (200), SECTOR_CACHE is the library's HXV_SECTOR_CACHE."""
 import json
 import os
 import sys
@@ -68,3 +70,17 @@ if "c" in parts:
     t0 = time.time()
     recs = diag_sweep(m, small_too=False)
     table(recs, f"(c) C3 cdn_hm_2dsquare Ns=16: ED_DIAG's sector loop, {time.time() - t0:.1f} s (sectors at or below the threshold are opened and closed only)")
+
+if "d" in parts:
+    m = models.hm_ring(6, 2)
+    hxv.sector_cache_clear()
+    from hxv.harness import gf_channels
+    nl5 = int(os.environ.get("NLANC_C5", 40))
+    ch = [c for c in gf_channels(m, symmetric=True) if c["create"]][:4]      # c+_0, (c+_0 + c+_1), (c+_0 + c+_2), (c+_0 + c+_3): two pairs in sector (10,9)
+    recs, s = gf_solve(m, 9, 9, nlanc=nl5, symmetric=True, gs_method="lanczos", channels=ch)
+    print(f"\n## (d) C5 hm_ring Ns=18, ground state of (9,9) Dim=2363904400 by hxv_lanczos_eigh, then {len(ch)} real channels paired, nlanc {nl5}")
+    print(f"# ground state: open {s['gs_open_ms']:.1f} ms, {s['gs_nmatvec']} iterations (two passes) {s['gs_ms'] / 1e3:.2f} s, E0 = {s['e0']:.12f}")
+    for r in recs:
+        print(f"# channel {r['kind']} {'c+' if r['create'] else 'c'} {r['terms']} sector {r['sector']} dim {r['dim']}: open {r['open_ms']:.1f} ms (hit {int(r['open_cache_hit'])}), start vector {r['start_ms']:.1f} ms, "
+              f"{r['nsteps']} steps {r['tridiag_ms'] / 1e3:.2f} s = {r['tridiag_ms'] / max(r['nsteps'], 1):.2f} ms per channel-step (paired {int(r['paired'])})")
+    print(f"# total {s['gf_solve_s']:.1f} s")
