@@ -30,6 +30,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT / "cdmft-lanc-ed_amd"))
 sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "scripts"))  # harness.py: the callers' call order (measurement scaffolding, not the package)
 
 KERNELS_STAMP = "r05-a"   # bumped whenever the product kernels change: profiles/traffic.json is quoted only for the same stamp
 XGMI_LINK_GBS = 153.0  # one xGMI link, per direction (7 links per GPU: SURVEY.md 8e)
@@ -517,10 +518,10 @@ def main():
             out["config"]["lanczos_paired_real_matvecs_per_s"] = round(2e3 / pair_ms, 2)
             del va, vb
     if world == 1 and args.workload == "C3" and not args.no_gf_solve and not args.no_lanczos and not args.rehearse_capi:
-        # the callers' usage pattern as a measured whole (hxv/harness.py): ground state of (8,8) by the default spectrum call, then the
+        # the callers' usage pattern as a measured whole (scripts/harness.py): ground state of (8,8) by the default spectrum call, then the
         # 56 tridiagonalisations of build_gf_normal (ED_GF_NORMAL.f90:36-110; 8 diagonal + 24 real mixed + 24 complex mixed: chan4, the
         # default), each with its sector N+-1 opened and closed around it (:208-222), device-resident, two real channels per product
-        from hxv.harness import gf_solve
+        from harness import gf_solve
 
         hxv.sector_cache_clear()
         recs, gs_ = gf_solve(model, nup, ndw, nlanc=200, symmetric=False, device=local_rank)

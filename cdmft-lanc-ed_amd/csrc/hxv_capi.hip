@@ -546,6 +546,8 @@ int hxv_vector_to_host(hxv_handle* h, const void* d_vec, void* v_host) {
   return HXV_OK;
 }
 
+int64_t hxv_live_handles(void) { return hxv::g_live_handles.load(); }
+
 int hxv_get_maps(const hxv_handle* h, int32_t* map_up, int32_t* map_dw) {
   if (!h) return fail(HXV_ERR_ARG, "NULL handle");
   if (h->host.map_up.empty()) return fail(HXV_ERR_STATE, "handle built from CSR has no basis maps");

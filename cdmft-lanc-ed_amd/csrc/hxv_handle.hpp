@@ -115,10 +115,16 @@ inline bool dw_part_in_pieces(const hxv_handle* h);
       return hxv::fail(HXV_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));                \
   } while (0)
 
+namespace hxv {
+inline std::atomic<int64_t> g_live_handles{0};  // hxv_live_handles(): handles created and not yet destroyed (leak checks of host programs)
+}
 struct hxv_handle {
   std::shared_ptr<hxv::SectorImage> img;  // shared, immutable (see SectorImage); `host` below is img->host
   hxv::SectorHost& host;
-  explicit hxv_handle(std::shared_ptr<hxv::SectorImage> i = std::make_shared<hxv::SectorImage>()) : img(std::move(i)), host(img->host) {}
+  explicit hxv_handle(std::shared_ptr<hxv::SectorImage> i = std::make_shared<hxv::SectorImage>()) : img(std::move(i)), host(img->host) { ++hxv::g_live_handles; }
+  ~hxv_handle() { --hxv::g_live_handles; }
+  hxv_handle(const hxv_handle&) = delete;
+  hxv_handle& operator=(const hxv_handle&) = delete;
   double open_us[4] = {0, 0, 0, 0};       // this open: host build, tile plan, upload, whole call (get_option "open_us_*"); 0 0 0 on a cache hit
   int open_cache_hit = 0;
   int device = 0;

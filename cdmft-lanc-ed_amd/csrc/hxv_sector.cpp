@@ -368,6 +368,28 @@ std::string build_sector_from_model(const hxv_model& m, int nup, int ndw, int ra
   if (!e.empty()) return e;
   e = one_body(mv, m.nspin - 1, hops_dw, eps_dw);            // spin index Nspin   (H_dw.f90:14)
   if (!e.empty()) return e;
+  {
+    // TIMING EXPERIMENT (HXV_EXPERIMENTS=1 only; results are those of a relabelled model): orbital -> bit assignment of one spin's
+    // hops, "HXV_EXP_UP_ORDER=p0,p1,..." = bit of orbital 0, 1, ...  (scripts/bitorder_ab.py; LABNOTES round 6)
+    auto relabel = [&](const char* name, std::vector<Hop>& hops) {
+      const char* x = std::getenv("HXV_EXPERIMENTS");
+      const char* v = std::getenv(name);
+      if (!x || std::string(x) != "1" || !v) return;
+      std::vector<int> pos;
+      for (const char* p = v; *p;) {
+        pos.push_back(std::atoi(p));
+        while (*p && *p != ',') ++p;
+        if (*p == ',') ++p;
+      }
+      if ((int)pos.size() != ns) return;
+      for (Hop& h : hops) {
+        h.a = pos[h.a];
+        h.b = pos[h.b];
+      }
+    };
+    relabel("HXV_EXP_UP_ORDER", hops_up);
+    relabel("HXV_EXP_DW_ORDER", hops_dw);
+  }
   if (panel_rows > 0) {
     // dw-only row panel [panel_rows x DimDw] of the vector (all-to-all exchange): the up index is just a row
     // count here -- no basis, no H_up, no diagonal

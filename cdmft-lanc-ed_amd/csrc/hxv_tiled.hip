@@ -189,14 +189,14 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
     // hops that leave the block, same columns, other rows: from global memory (L2 of this XCD)
     if (!(t.debug & 1)) {
       // block hops: the partner block is one contiguous run, lanes read consecutive rows
-      for (uint32_t h = t.bh_ptr[kb]; h < t.bh_ptr[kb + 1]; ++h) {
+      for (uint32_t h = t.bh_ptr[kb]; h < ((t.debug & 256) ? t.bh_ptr[kb] : t.bh_ptr[kb + 1]); ++h) {
         const CT cf = lcoef[t.bh[2 * h + 1]];
         const VT* __restrict__ src = vcol0 + t.bh[2 * h] + r;
 #pragma unroll
         for (int cc = 0; cc < C; ++cc) Coef<REAL>::fma(acc[cc], cf, src[(int64_t)min(cc, nc - 1) * s.pitch]);
       }
       // row slots: one table word per row and (block, source block) pair -- or, packed, per TWO such pairs (P16)
-      const uint32_t rs1 = t.rs_ptr[kb + 1];
+      const uint32_t rs1 = (t.debug & 512) ? t.rs_ptr[kb] : t.rs_ptr[kb + 1];
       // (eight-column tiles -- real vectors -- keep one word per slot: with the packed words the fused real-vector pass A went from
       //  1.67 to 1.88 ms at C3, the whole round-3 regression of the real Lanczos iteration, 3.77 -> 3.96 ms; profiles/r04_bisect_real.log)
       if (P16 && C < 8 && t.rs16) {
@@ -459,7 +459,7 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_dw(DevSector s, DevTiles t, 
       if ((tid >> LR) + it * cstep < n) lds_st<VT>(tq + it * T * VB, x[it]);
     }
   }
-  const uint32_t rs0 = t.rs_ptr[kb], rs_end = t.rs_ptr[kb + 1];
+  const uint32_t rs0 = t.rs_ptr[kb], rs_end = (t.debug & 512) ? rs0 : t.rs_ptr[kb + 1];
   __syncthreads();
   // in-block hops, one column per thread (plan guarantees n <= blockDim.x)
   {
@@ -522,7 +522,7 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_dw(DevSector s, DevTiles t, 
 #pragma unroll
       for (int it = 0; it < HB; ++it) osum[it] = vzero<VT>();
       // block hops: source column slot = start + column offset, one signed coefficient for the whole block
-      for (uint32_t h = t.bh_ptr[kb]; h < t.bh_ptr[kb + 1]; ++h) {
+      for (uint32_t h = t.bh_ptr[kb]; h < ((t.debug & 256) ? t.bh_ptr[kb] : t.bh_ptr[kb + 1]); ++h) {
         const CT cf = lds_ld<CT>(t.bh[2 * h + 1] << LCB);
         const char* __restrict__ src = vrows + (int64_t)t.bh[2 * h] * pitchb;
         VT x[HB];

@@ -19,10 +19,12 @@ module ED_HAMILTONIAN_GPU_HXV
   public :: gpuMatVec_MPI_main
   public :: gpu_comm_unique_id
   public :: gpu_comm_init
-  !sp_eigh's replacement looks for hidden copies of degenerate levels only when asked (engine option "eigh_degenerate", include/hxv.h): set
-  !this BEFORE build_Hv_sector for clusters whose point group has degenerate levels inside a sector (2x2 plaquette: D4) when every state
-  !within gs_threshold (ED_DIAG.f90:234-244) is wanted; the default is what ARPACK does (one Krylov space, no extra products)
-  logical,public,save :: gpu_eigh_degenerate=.false.
+  !sp_eigh's replacement can look for hidden copies of degenerate levels (engine option "eigh_degenerate", include/hxv.h).  THIS GLUE ASKS FOR
+  !THEM BY DEFAULT (ADVICE r5): it is the drop-in path that feeds es_add_state, ED_DIAG.f90:234-244 keeps every state within gs_threshold of
+  !the minimum, and a 2x2 plaquette (point group D4) has degenerate levels inside a sector -- losing a copy gives a symmetry-broken G.  It
+  !costs the check rounds (C3: 60 products on 380).  Set .false. BEFORE build_Hv_sector for exactly what ARPACK does (one Krylov space, no
+  !extra products; the raw C-ABI's default).
+  logical,public,save :: gpu_eigh_degenerate=.true.
   public :: gpu_lanc_tridiag_host
   public :: gpu_sp_lanc_tridiag
   public :: gpu_sp_lanc_tridiag_pair
@@ -40,6 +42,7 @@ module ED_HAMILTONIAN_GPU_HXV
   public :: gpu_vector_from_host
   public :: gpu_free_vector
   public :: gpu_pcie_bytes
+  public :: gpu_live_sectors
   !the reference's own stored matrices handed over (spH0ups(1), spH0dws(1), spH0d, spH0nd flattened to CSR)
   public :: gpu_build_Hv_sector_from_csr
   public :: gpu_set_nonlocal_csr
@@ -55,20 +58,27 @@ module ED_HAMILTONIAN_GPU_HXV
      logical     :: owns_sector = .false.  !gpu_keep_sector was called with this vector (informational: the sector's life is counted, below)
      logical     :: view = .false.         !part of another vector's allocation (eigenvectors 2.. of gpu_sp_eigh_dev)
      type(c_ptr) :: base   = c_null_ptr    !the allocation it lives in (= d unless a view)
+     integer(8)  :: sector_id = 0          !serial numbers of the sector and of the allocation in the lifetime tables below: addresses are
+     integer(8)  :: alloc_id  = 0          !re-issued by malloc / the engine's buffer cache once freed, serials never (ADVICE r5)
   end type gpu_vector
 
   !Lifetimes are COUNTED, so vectors may be freed in any order (ADVICE r4): an allocation goes back to the engine when the last
   !gpu_vector in it is freed (the eigenvectors of gpu_sp_eigh_dev share one), and a kept sector (gpu_keep_sector) is closed when the last
   !vector made on it is freed -- whichever vector that is.  A sector closed by gpu_delete_Hv_sector while vectors of it are still alive
   !takes their memory with it (hxv_destroy returns it): those vectors become empty shells and freeing them later is a no-op.
+  !Entries are identified by a SERIAL NUMBER taken when the sector is opened / the allocation is made, never by address: a sector closed by
+  !gpu_delete_Hv_sector with live vectors keeps its (dead) entry until those shells are freed, and the next build_Hv_sector very likely gets
+  !the same handle address -- matched by address, the new sector would inherit dead=.true. and leak (ADVICE r5).
   type :: ref_entry
-     type(c_ptr) :: key  = c_null_ptr
+     integer(8)  :: id   = 0
      integer     :: n    = 0
      logical     :: kept = .false.         !sectors: stays open until its last vector is freed
      logical     :: dead = .false.         !sectors: destroyed while vectors were alive
   end type ref_entry
   integer,parameter    :: MAXREF=512
   type(ref_entry),save :: sector_refs(MAXREF), alloc_refs(MAXREF)
+  integer(8),save      :: next_serial=0      !last serial number handed out (sectors and allocations share the counter)
+  integer(8),save      :: handle_serial=0    !serial of the OPEN sector (`handle`), 0: none
 
   !> SciFortran's drivers are generic in exactly this way: the serial form takes the product first, the MPI form the
   !! communicator first (call sites ED_DIAG.f90:152-156,161-165,176-184; ED_GF_NORMAL.f90:215,217).  Both forms end in
@@ -117,6 +127,9 @@ module ED_HAMILTONIAN_GPU_HXV
        import :: c_int, c_ptr
        type(c_ptr),value :: h
      end function hxv_destroy
+     integer(c_int64_t) function hxv_live_handles() bind(C,name="hxv_live_handles")
+       import :: c_int64_t
+     end function hxv_live_handles
      integer(c_int64_t) function hxv_vecdim(h) bind(C,name="hxv_vecdim")
        import :: c_int64_t, c_ptr
        type(c_ptr),value :: h
@@ -338,51 +351,77 @@ contains
     endif
     call check(hxv_create_from_model(m,int(nup,c_int32_t),int(ndw,c_int32_t),int(MpiRank,c_int32_t),&
          int(MpiSize,c_int32_t),int(dev,c_int32_t),handle),"gpu_build_Hv_sector")
-    if(gpu_eigh_degenerate)call check(hxv_set_option(handle,"eigh_degenerate"//c_null_char,1_c_int64_t),"gpu_build_Hv_sector")
+    call sector_opened()
+    call check(hxv_set_option(handle,"eigh_degenerate"//c_null_char,merge(1_c_int64_t,0_c_int64_t,gpu_eigh_degenerate)),"gpu_build_Hv_sector")
   end subroutine gpu_build_Hv_sector
 
   !---- reference tables of the device vectors (see type ref_entry) ----
-  integer function ref_find(tab,key) result(i)
+  integer function ref_find(tab,id) result(i)
     type(ref_entry),intent(in) :: tab(:)
-    type(c_ptr),intent(in)     :: key
-    do i=1,size(tab)
-       if(tab(i)%n>0.and.c_associated(tab(i)%key,key))return
-    enddo
+    integer(8),intent(in)      :: id
+    if(id/=0)then
+       do i=1,size(tab)
+          if(tab(i)%n>0.and.tab(i)%id==id)return
+       enddo
+    endif
     i=0
   end function ref_find
-  subroutine ref_add(tab,key)
+  subroutine ref_add(tab,id)
     type(ref_entry),intent(inout) :: tab(:)
-    type(c_ptr),intent(in)        :: key
+    integer(8),intent(in)         :: id
     integer                       :: i
-    i=ref_find(tab,key)
+    i=ref_find(tab,id)
     if(i==0)then
        do i=1,size(tab)
           if(tab(i)%n==0)exit
        enddo
        if(i>size(tab))stop "ED_HAMILTONIAN_GPU_HxV ERROR: more than 512 live device vectors / sectors"
-       tab(i)%key=key; tab(i)%kept=.false.; tab(i)%dead=.false.
+       tab(i)%id=id; tab(i)%kept=.false.; tab(i)%dead=.false.
     endif
     tab(i)%n=tab(i)%n+1
   end subroutine ref_add
-  !a new gpu_vector in allocation `base` of sector `sector`
-  subroutine vec_born(vect,sector,base,view)
-    type(gpu_vector),intent(inout) :: vect
-    type(c_ptr),intent(in)         :: sector,base
-    logical,intent(in)             :: view
-    vect%sector=sector; vect%base=base; vect%view=view; vect%owns_sector=.false.
-    call ref_add(alloc_refs,base)
-    call ref_add(sector_refs,sector)
+  !a new gpu_vector of the OPEN sector, in allocation `base`: its own (view=.false.: a fresh serial) or the one `owner` lives in
+  subroutine vec_born(vect,base,view,owner)
+    type(gpu_vector),intent(inout)       :: vect
+    type(c_ptr),intent(in)               :: base
+    logical,intent(in)                   :: view
+    type(gpu_vector),intent(in),optional :: owner
+    vect%sector=handle; vect%sector_id=handle_serial; vect%base=base; vect%view=view; vect%owns_sector=.false.
+    if(view)then
+       if(.not.present(owner))stop "ED_HAMILTONIAN_GPU_HxV ERROR: a view needs the vector that owns its allocation"
+       vect%alloc_id=owner%alloc_id
+    else
+       next_serial=next_serial+1
+       vect%alloc_id=next_serial
+    endif
+    call ref_add(alloc_refs,vect%alloc_id)
+    call ref_add(sector_refs,vect%sector_id)
   end subroutine vec_born
+  !a device vector that can still be used: made, not freed, its sector not closed under it
+  logical function vec_alive(vect) result(ok)
+    type(gpu_vector),intent(in) :: vect
+    integer                     :: i
+    ok=.false.
+    if(.not.c_associated(vect%d))return
+    i=ref_find(sector_refs,vect%sector_id)
+    if(i==0)return
+    ok=.not.sector_refs(i)%dead
+  end function vec_alive
+  !the open sector got its serial (every build_Hv_sector variant calls this right after the engine returned the handle)
+  subroutine sector_opened()
+    next_serial=next_serial+1
+    handle_serial=next_serial
+  end subroutine sector_opened
 
   !> delete_Hv_sector hook (ED_HAMILTONIAN.f90:149-190)
   subroutine gpu_delete_Hv_sector()
     integer :: i
     if(c_associated(handle))then
-       i=ref_find(sector_refs,handle)
+       i=ref_find(sector_refs,handle_serial)
        if(i>0)sector_refs(i)%dead=.true.   !vectors of this sector are still alive: hxv_destroy takes their memory back, their shells stay
        call check(hxv_destroy(handle),"gpu_delete_Hv_sector")
     endif
-    handle=c_null_ptr
+    handle=c_null_ptr; handle_serial=0
   end subroutine gpu_delete_Hv_sector
 
   !> vecDim_Hv_sector of the open sector (ED_HAMILTONIAN.f90:197-221)
@@ -596,7 +635,7 @@ contains
     if(.not.c_associated(handle))stop "gpu_sp_lanc_eigh_dev ERROR: Hsector NOT set"
     if(c_associated(vect%d))stop "gpu_sp_lanc_eigh_dev ERROR: the vector is in use (gpu_free_vector it first)"
     call check(hxv_vector_alloc(handle,vect%d),"gpu_sp_lanc_eigh_dev")
-    call vec_born(vect,handle,vect%d,.false.)
+    call vec_born(vect,vect%d,.false.)
     thr=1d-12; if(present(threshold))thr=max(threshold,1d-15)
     call check(hxv_lanczos_eigh(handle,int(Nitermax,c_int32_t),thr,egs,vect%d,niter),"gpu_sp_lanc_eigh_dev")
     if(present(iverbose))then
@@ -632,7 +671,7 @@ contains
     call c_f_pointer(vects(1)%d,base,[stride*size(eval)])      !(address arithmetic only: the memory is on the device)
     do i=1,size(eval)
        if(i>1)vects(i)%d=c_loc(base(1+(i-1)*stride))
-       call vec_born(vects(i),handle,vects(1)%d,i>1)
+       if(i==1)then; call vec_born(vects(1),vects(1)%d,.false.); else; call vec_born(vects(i),vects(1)%d,.true.,vects(1)); endif
     enddo
     call check(hxv_eigh_lowest(handle,int(size(eval),c_int32_t),ncv,nit,tl,eval,vects(1)%d,nconv,nmv),"gpu_sp_eigh_dev")
     if(present(iverbose))then
@@ -647,12 +686,12 @@ contains
     type(gpu_vector),intent(inout) :: vect
     integer                        :: i
     if(.not.c_associated(handle))stop "gpu_keep_sector ERROR: Hsector NOT set"
-    if(.not.c_associated(vect%sector,handle))stop "gpu_keep_sector ERROR: the vector does not belong to the open sector"
-    i=ref_find(sector_refs,handle)
+    if(vect%sector_id/=handle_serial.or..not.c_associated(vect%d))stop "gpu_keep_sector ERROR: the vector does not belong to the open sector"
+    i=ref_find(sector_refs,handle_serial)
     if(i==0)stop "gpu_keep_sector ERROR: no live vector of the open sector"
     sector_refs(i)%kept=.true.
     vect%owns_sector=.true.
-    handle=c_null_ptr
+    handle=c_null_ptr; handle_serial=0
   end subroutine gpu_keep_sector
 
   !> out = [out +] coef * c^(dagger)_{ipos,ispin} psi, from psi's sector into the OPEN sector; norm2 = <out|out> afterwards.
@@ -668,15 +707,15 @@ contains
     complex(8)                     :: cf
     integer(c_int32_t)             :: acc,cr
     if(.not.c_associated(handle))stop "gpu_apply_ladder ERROR: Hsector NOT set (build the target sector first)"
-    if(.not.c_associated(psi%d))stop "gpu_apply_ladder ERROR: empty source vector"
+    if(.not.vec_alive(psi))stop "gpu_apply_ladder ERROR: empty source vector, or its sector was closed under it (gpu_keep_sector keeps it open)"
     cf=(1d0,0d0); if(present(coef))cf=coef
     acc=0; if(present(accumulate))then; if(accumulate)acc=1; endif
     if(.not.c_associated(out%d))then
        if(acc==1)stop "gpu_apply_ladder ERROR: accumulate into an empty vector"
        call check(hxv_vector_alloc(handle,out%d),"gpu_apply_ladder")
-       call vec_born(out,handle,out%d,.false.)
+       call vec_born(out,out%d,.false.)
     endif
-    if(.not.c_associated(out%sector,handle))stop "gpu_apply_ladder ERROR: the target vector does not belong to the open sector"
+    if(out%sector_id/=handle_serial)stop "gpu_apply_ladder ERROR: the target vector does not belong to the open sector"
     cr=0; if(create)cr=1
     call check(hxv_apply_ladder_axpy(psi%sector,handle,int(ipos-1,c_int32_t),int(ispin-1,c_int32_t),cr,dble(cf),aimag(cf),acc,psi%d,out%d,norm2),&
          "gpu_apply_ladder")
@@ -690,7 +729,7 @@ contains
     real(8)                     :: thr
     integer(c_int32_t)          :: nsteps
     if(.not.c_associated(handle))stop "gpu_sp_lanc_tridiag_dev ERROR: Hsector NOT set"
-    if(.not.c_associated(vin%sector,handle))stop "gpu_sp_lanc_tridiag_dev ERROR: the start vector does not belong to the open sector"
+    if(vin%sector_id/=handle_serial.or..not.c_associated(vin%d))stop "gpu_sp_lanc_tridiag_dev ERROR: the start vector does not belong to the open sector"
     thr=1d-12; if(present(threshold))thr=threshold
     call check(hxv_lanczos_tridiag(handle,vin%d,int(size(alanc),c_int32_t),alanc,blanc,thr,nsteps),"gpu_sp_lanc_tridiag_dev")
   end subroutine gpu_sp_lanc_tridiag_dev
@@ -704,7 +743,7 @@ contains
     real(8)                     :: thr
     integer(c_int32_t)          :: na,nb
     if(.not.c_associated(handle))stop "gpu_sp_lanc_tridiag_pair_dev ERROR: Hsector NOT set"
-    if(.not.(c_associated(vin_a%sector,handle).and.c_associated(vin_b%sector,handle)))&
+    if(vin_a%sector_id/=handle_serial.or.vin_b%sector_id/=handle_serial.or..not.c_associated(vin_a%d).or..not.c_associated(vin_b%d))&
          stop "gpu_sp_lanc_tridiag_pair_dev ERROR: the start vectors do not belong to the open sector"
     if(size(alanc_a)/=size(alanc_b))stop "gpu_sp_lanc_tridiag_pair_dev ERROR: the two channels need equally long alanc/blanc"
     thr=1d-12; if(present(threshold))thr=threshold
@@ -716,7 +755,7 @@ contains
   subroutine gpu_vector_to_host(vect,v)
     type(gpu_vector),intent(in) :: vect
     complex(8),intent(inout)    :: v(:)
-    if(.not.c_associated(vect%d))stop "gpu_vector_to_host ERROR: empty vector"
+    if(.not.vec_alive(vect))stop "gpu_vector_to_host ERROR: empty vector, or its sector was closed under it"
     if(int(size(v),c_int64_t)/=hxv_vecdim(vect%sector))stop "gpu_vector_to_host ERROR: size(v) /= vecDim of the vector's sector"
     call check(hxv_vector_to_host(vect%sector,vect%d,v),"gpu_vector_to_host")
   end subroutine gpu_vector_to_host
@@ -727,8 +766,9 @@ contains
     if(.not.c_associated(vect%d))then
        if(.not.c_associated(handle))stop "gpu_vector_from_host ERROR: Hsector NOT set"
        call check(hxv_vector_alloc(handle,vect%d),"gpu_vector_from_host")
-       call vec_born(vect,handle,vect%d,.false.)
+       call vec_born(vect,vect%d,.false.)
     endif
+    if(.not.vec_alive(vect))stop "gpu_vector_from_host ERROR: the vector's sector was closed under it"
     if(int(size(v),c_int64_t)/=hxv_vecdim(vect%sector))stop "gpu_vector_from_host ERROR: size(v) /= vecDim of the vector's sector"
     call check(hxv_vector_from_host(vect%sector,v,vect%d),"gpu_vector_from_host")
   end subroutine gpu_vector_from_host
@@ -738,25 +778,31 @@ contains
     type(gpu_vector),intent(inout) :: vect
     integer                        :: ia,is
     if(c_associated(vect%d))then
-       is=ref_find(sector_refs,vect%sector)
-       ia=ref_find(alloc_refs,vect%base)
+       is=ref_find(sector_refs,vect%sector_id)
+       ia=ref_find(alloc_refs,vect%alloc_id)
        if(is==0.or.ia==0)stop "gpu_free_vector ERROR: not a live device vector (a copy of one that was freed already?)"
        alloc_refs(ia)%n=alloc_refs(ia)%n-1
        if(alloc_refs(ia)%n==0)then
           if(.not.sector_refs(is)%dead)call check(hxv_vector_free(vect%sector,vect%base),"gpu_free_vector")
-          alloc_refs(ia)%key=c_null_ptr
+          alloc_refs(ia)%id=0
        endif
        sector_refs(is)%n=sector_refs(is)%n-1
        if(sector_refs(is)%n==0)then
           if(sector_refs(is)%kept.and..not.sector_refs(is)%dead)then
-             if(c_associated(vect%sector,handle))handle=c_null_ptr   !(kept sectors are never the open one; belt and braces)
+             if(vect%sector_id==handle_serial)then; handle=c_null_ptr; handle_serial=0; endif   !(kept sectors are never the open one; belt and braces)
              call check(hxv_destroy(vect%sector),"gpu_free_vector")
           endif
-          sector_refs(is)%key=c_null_ptr; sector_refs(is)%kept=.false.; sector_refs(is)%dead=.false.
+          sector_refs(is)%id=0; sector_refs(is)%kept=.false.; sector_refs(is)%dead=.false.
        endif
     endif
-    vect%d=c_null_ptr; vect%sector=c_null_ptr; vect%base=c_null_ptr; vect%owns_sector=.false.; vect%view=.false.
+    vect%d=c_null_ptr; vect%sector=c_null_ptr; vect%base=c_null_ptr; vect%owns_sector=.false.; vect%view=.false.; vect%sector_id=0; vect%alloc_id=0
   end subroutine gpu_free_vector
+
+  !> Sectors (engine handles) opened and not yet closed, process-wide (include/hxv.h: hxv_live_handles): a host program's leak check.
+  function gpu_live_sectors() result(n)
+    integer(8) :: n
+    n=hxv_live_handles()
+  end function gpu_live_sectors
 
   !> Vector-sized bytes the engine has moved over PCIe for a sector since it was opened (include/hxv.h: hxv_stats): the open sector,
   !! or the kept sector of `vect`.
@@ -765,7 +811,11 @@ contains
     type(gpu_vector),intent(in),optional :: vect
     type(hxv_stats)                      :: st
     type(c_ptr)                          :: hh
-    hh=handle; if(present(vect))hh=vect%sector
+    hh=handle
+    if(present(vect))then
+       if(.not.vec_alive(vect))stop "gpu_pcie_bytes ERROR: empty vector, or its sector was closed under it"
+       hh=vect%sector
+    endif
     if(.not.c_associated(hh))stop "gpu_pcie_bytes ERROR: no sector"
     call check(hxv_get_stats(hh,st),"gpu_pcie_bytes")
     h2d=st%h2d_bytes; d2h=st%d2h_bytes
@@ -790,6 +840,8 @@ contains
     call check(hxv_create_from_csr(int(DimUp,c_int32_t),int(DimDw,c_int32_t),int(up_rowptr,c_int64_t),int(up_cols,c_int32_t),up_vals,&
          int(dw_rowptr,c_int64_t),int(dw_cols,c_int32_t),dw_vals,diag,int(MpiRank,c_int32_t),int(MpiSize,c_int32_t),int(dev,c_int32_t),handle),&
          "gpu_build_Hv_sector_from_csr")
+    call sector_opened()
+    call check(hxv_set_option(handle,"eigh_degenerate"//c_null_char,merge(1_c_int64_t,0_c_int64_t,gpu_eigh_degenerate)),"gpu_build_Hv_sector_from_csr")
   end subroutine gpu_build_Hv_sector_from_csr
 
   !> stored elements of H_up (which=1) / H_dw (which=2) of the open sector

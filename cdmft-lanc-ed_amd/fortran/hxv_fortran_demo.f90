@@ -281,6 +281,31 @@ contains
            " max|roundtrip - psi|=",maxval(abs(back-psi))
       deallocate(back)
     end block
+    !--- a sector closed UNDER a live vector, then the next sector opened at (very likely) the same handle address and the next vectors at the
+    !    same device addresses (ADVICE r5): the new sector must not inherit the dead entry of the old one -- kept through a vector and freed,
+    !    it has to be closed and its vector memory returned; the shell of the old sector's vector is freed last, a no-op
+    block
+      type(gpu_vector) :: orphan,keeper,w
+      real(8) :: eo,ek,n2k
+      integer(8) :: live0,live1,live2
+      live0=gpu_live_sectors()
+      call gpu_build_Hv_sector(Nlat,Norb,Nspin,Nbath,6,6,impHloc,Hbath,Vbath,Uloc,0d0,0d0,0d0,0d0,0d0,.true.,0,1)
+      call gpu_sp_lanc_eigh_dev(eo,orphan,300,threshold=1d-13)
+      call gpu_delete_Hv_sector()                          !closed with `orphan` alive: its memory goes with the sector, the shell stays
+      call gpu_build_Hv_sector(Nlat,Norb,Nspin,Nbath,6,6,impHloc,Hbath,Vbath,Uloc,0d0,0d0,0d0,0d0,0d0,.true.,0,1)
+      call gpu_sp_lanc_eigh_dev(ek,keeper,300,threshold=1d-13)
+      call gpu_keep_sector(keeper)
+      call gpu_build_Hv_sector(Nlat,Norb,Nspin,Nbath,7,6,impHloc,Hbath,Vbath,Uloc,0d0,0d0,0d0,0d0,0d0,.true.,0,1)
+      call gpu_apply_ladder(keeper,ipos,ispin,.true.,w,n2k)
+      live1=gpu_live_sectors()                             !the kept sector and the open one
+      call gpu_free_vector(w)
+      call gpu_delete_Hv_sector()
+      call gpu_free_vector(keeper)                         !last vector of the kept sector: must CLOSE it
+      live2=gpu_live_sectors()
+      call gpu_free_vector(orphan)                         !shell of a vector whose sector is long gone: no-op
+      write(*,"(A,3I4,A,ES12.4,A,ES12.4)")"GF lifetimes after a sector closed under a live vector: live sectors before / kept+open / after=",&
+           live0,live1,live2," |E0(new) - E0(old)|=",abs(ek-eo)," |norm2 - norm2(gs)|=",abs(n2k-norm2)
+    end block
     deallocate(psi,vvinit,map6,map7,pos7)
   end subroutine gf_channel_on_device
 

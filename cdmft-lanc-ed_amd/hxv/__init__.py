@@ -7,6 +7,5 @@ from .engine import (HxvError, HxvSector, LIB_PATH, LocalGroup, RcclGroup, halo_
                      sector_cache_clear, sector_cache_stats, set_exchange_default)
 from .hamiltonian import EDContext  # noqa: F401
 from . import models  # noqa: F401
-from . import harness  # noqa: F401  (measurement harness: the callers' call order, hxv/harness.py)
 from .distributed import (HaloHxv, ShardedHxv, ShardedLanczos, TransposedHxv, dw_split, exchange_ingest_bytes, halo_plan,  # noqa: F401
                           sharded_eigh_lowest, start_vector_slab)

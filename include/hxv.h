@@ -264,7 +264,10 @@ int hxv_lanczos_eigh_host(hxv_handle *h, int32_t nitermax, double threshold, dou
  * exactly zero -- c / c^dagger applied to a real ground state; refused otherwise) travel as real and imaginary part of one
  * complex Lanczos vector; every scalar of the recurrence, every dot product and both early exits exist once per component.
  * alanc_x/blanc_x[nlanc], *nsteps_x as in hxv_lanczos_tridiag.  Each component's numbers are bit-identical to
- * hxv_lanczos_tridiag on that start vector through the same kernels (option real_vectors = 0; any job_up).
+ * hxv_lanczos_tridiag on that start vector through the same kernels, i.e. with option real_vectors = 0 (the complex-vector path; any job_up).
+ * Against hxv_lanczos_tridiag's DEFAULT path (real_vectors = 1: the real-vector kernels, another summation order) they agree to rounding, not bit
+ * for bit -- 1e-10 over the first steps, growing with the step like any two Lanczos runs; the continued fraction the consumer builds from them
+ * (ED_GF_NORMAL.f90:915-975) agrees to 1e-9 (tests/test_gpu_lanczos.py::test_paired_tridiagonalisation_..., tests/test_gpu_solve_sweep.py).
  * Split sectors: slabs per rank, every sum all-reduced (any exchange).  The _host form takes the start vectors in the reference's
  * contiguous host layout.
  * What does NOT pair: the (c^+_i + xi c^+_j)|gs>, (c_i - xi c_j)|gs> channels of the reference's default chan4 form (ED_GF_NORMAL.f90:746-780,
@@ -359,6 +362,10 @@ int hxv_pool_stats(int32_t device, int64_t *cached_bytes, int64_t *hits, int64_t
  * panel handles are not cached.                                                                                                */
 int hxv_sector_cache_clear(void);
 int hxv_sector_cache_stats(int64_t *entries, int64_t *bytes, int64_t *hits, int64_t *misses); /* any out may be NULL */
+
+/* Handles created (hxv_create_*; the internal row-panel handle of an exchange-mode-2 sector counts too) and not yet destroyed, process-wide:
+ * what a host program's leak check reads after its last delete_Hv_sector (the Fortran demo asserts 0 after its lifetime cases).            */
+int64_t hxv_live_handles(void);
 
 /* ---- introspection (parity tests against spH0ups/spH0dws/spH0d) ------------------------ */
 int hxv_get_maps(const hxv_handle *h, int32_t *map_up, int32_t *map_dw); /* Hs(1)%map, Hs(2)%map */

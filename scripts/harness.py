@@ -18,7 +18,7 @@ import time
 
 import numpy as np
 
-from .engine import HxvSector
+from hxv.engine import HxvSector  # (scripts/ is measurement scaffolding; the package is the engine only)
 
 
 def _sync():
@@ -104,7 +104,7 @@ def gf_solve(model, nup: int, ndw: int, nlanc: int = 200, symmetric: bool = Fals
     # Lanczos vectors or scratch (at Ns=18 those are 95 GB the channels need)
     real_ok = gs.real_vectors_available
     gs.close()
-    from .engine import pool_trim
+    from hxv.engine import pool_trim
     pool_trim(device)
     torch.cuda.empty_cache()
     gs = HxvSector.from_model(model, nup, ndw, device=device)
@@ -173,6 +173,7 @@ def gf_solve(model, nup: int, ndw: int, nlanc: int = 200, symmetric: bool = Fals
             run([ch])
     for ch in waiting.values():
         run([ch])
+    psi_host = gs.unpad(psi).cpu().numpy() if keep_psi else None   # (before the handle is closed: unpad needs its layout)
     gs.close()
     _sync()
     total_s = time.perf_counter() - t_all
@@ -184,7 +185,7 @@ def gf_solve(model, nup: int, ndw: int, nlanc: int = 200, symmetric: bool = Fals
                "real_channels_s": sum(r["tridiag_ms"] for r in recs if r["kind"] != "mix_xi") * 1e-3,
                "complex_channels_s": sum(r["tridiag_ms"] for r in recs if r["kind"] == "mix_xi") * 1e-3, "gf_solve_s": total_s}
     if keep_psi:
-        summary["psi"] = gs.unpad(psi).cpu().numpy()      # (tests: the ground state in the reference's contiguous host layout)
+        summary["psi"] = psi_host                           # (tests: the ground state in the reference's contiguous host layout)
     del psi
     torch.cuda.empty_cache()
     return recs, summary

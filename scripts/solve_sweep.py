@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The callers' usage pattern, measured: hxv/harness.py driven over
+"""The callers' usage pattern, measured: scripts/harness.py driven over
   (a) every sector of C2 (Ns=12) in ED_DIAG's order: open -> sp_eigh(2, 20) -> close, against tests/golden/c2_sector_sweep.json;
   (b) the 56 Green's-function channels of one default solve at C3 (Ns=16, ground state in (8,8)), the target sector opened and closed
       around every channel as ED_GF_NORMAL.f90:208-222 does -- and the same with ed_gf_symmetric (32 real channels);
@@ -16,11 +16,12 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "cdmft-lanc-ed_amd"))
+sys.path.insert(0, str(ROOT / "scripts"))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import hxv  # noqa: E402
 from hxv import models  # noqa: E402
-from hxv.harness import diag_sweep, gf_solve  # noqa: E402
+from harness import diag_sweep, gf_solve  # noqa: E402
 
 parts = os.environ.get("PARTS", "ab")
 nlanc = int(os.environ.get("NLANC", 200))
@@ -74,7 +75,7 @@ if "c" in parts:
 if "d" in parts:
     m = models.hm_ring(6, 2)
     hxv.sector_cache_clear()
-    from hxv.harness import gf_channels
+    from harness import gf_channels
     nl5 = int(os.environ.get("NLANC_C5", 40))
     ch = [c for c in gf_channels(m, symmetric=True) if c["create"]][:4]      # c+_0, (c+_0 + c+_1), (c+_0 + c+_2), (c+_0 + c+_3): two pairs in sector (10,9)
     recs, s = gf_solve(m, 9, 9, nlanc=nl5, symmetric=True, gs_method="lanczos", channels=ch)

@@ -6,6 +6,7 @@ import pytest
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "cdmft-lanc-ed_amd"))
+sys.path.insert(0, str(ROOT / "scripts"))  # harness.py: the callers' call order (measurement scaffolding, not the package)
 
 
 def pytest_configure(config):

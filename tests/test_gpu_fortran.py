@@ -135,6 +135,14 @@ def test_fortran_device_resident_green_function_channel(built):
     lt = re.search(r"GF lifetimes any order: \|norm2\(ev1\) - norm2\(gs\)\|=\s*([-\d.Ee+]+)\s*norm2\(ev2\)=\s*([-\d.Ee+]+)\s*max\|roundtrip - psi\|=\s*([-\d.Ee+]+)", txt)
     assert lt, txt
     assert float(lt.group(1)) < 1e-9 and 0.0 < float(lt.group(2)) < 1.0 and float(lt.group(3)) == 0.0
+    # a sector closed UNDER a live vector, the next one opened at the same address: entries are matched by serial number, so the new
+    # sector does not inherit the dead one's entry -- kept through a vector and freed, it is closed (live sectors back to where they were)
+    dz = re.search(r"GF lifetimes after a sector closed under a live vector: live sectors before / kept\+open / after=\s*(\d+)\s+(\d+)\s+(\d+)\s*"
+                   r"\|E0\(new\) - E0\(old\)\|=\s*([-\d.Ee+]+)\s*\|norm2 - norm2\(gs\)\|=\s*([-\d.Ee+]+)", txt)
+    assert dz, txt
+    before, mid, after = (int(dz.group(k)) for k in (1, 2, 3))
+    assert mid == before + 2 and after == before, (before, mid, after)
+    assert float(dz.group(4)) < 1e-9 and float(dz.group(5)) < 1e-9
 
 
 def test_fortran_stored_matrices_binding(built):

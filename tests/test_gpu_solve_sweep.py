@@ -1,6 +1,6 @@
 """The callers' usage pattern as a whole: every sector of a model opened, solved and closed the way ED_DIAG.f90:78-260
 does, every Green's-function channel of build_gf_normal (ED_GF_NORMAL.f90:36-110) with its sector opened and closed around it, and the
-sector-image cache that serves the re-opens.  The harness (hxv/harness.py) only drives the C-ABI; the numbers are compared with the CPU
+sector-image cache that serves the re-opens.  The harness (scripts/harness.py) only drives the C-ABI; the numbers are compared with the CPU
 oracle's matrices (tests/golden/c2_sector_sweep.json, scripts/make_golden_c2_sweep.py) and with the oracle's own Lanczos."""
 import json
 from pathlib import Path
@@ -68,7 +68,8 @@ def test_reopened_sector_shares_its_image_and_multiplies_bit_for_bit(built):
 
 
 def test_reopening_the_headline_sector_costs_milliseconds(built):
-    """re-open of a cached Ns=16 sector <= 15 ms (~165 ms before), identical products."""
+    """a re-open of a cached Ns=16 sector is served by the image (no host build, no plan build; ~0.3 ms against 20 ms cold,
+    printed), identical products."""
     import time
     import torch
     import hxv
@@ -88,13 +89,14 @@ def test_reopening_the_headline_sector_costs_milliseconds(built):
         t0 = time.perf_counter()
         b = hxv.HxvSector.from_model(m, 9, 8)
         times.append((time.perf_counter() - t0) * 1e3)
-        assert b.get_option("open_cache_hit") == 1
+        # a re-open builds nothing: no host description, no tile plan (the image of the first open serves it)
+        assert b.get_option("open_cache_hit") == 1 and b.get_option("open_us_host") == 0 and b.get_option("open_us_plan") == 0
         hb = b.apply_device(v)
         torch.cuda.synchronize()
         assert torch.equal(ha, hb)
         b.close()
+    # (wall-clock is printed, not asserted: a shared box must not turn a correct cache red; what a re-open may not do is asserted below)
     print(f"Ns=16 sector (9,8): cold open {cold_ms:.1f} ms, cached re-opens {['%.2f' % t for t in times]} ms")
-    assert max(times) <= 15.0, times
     hxv.sector_cache_clear()
 
 
@@ -104,7 +106,7 @@ def test_every_sector_of_c2_against_the_oracle(built):
     the sectors the reference would hand to LAPACK (Dim <= 1024) included."""
     import hxv
     from hxv import models
-    from hxv.harness import diag_sweep
+    from harness import diag_sweep
 
     gold = json.loads((GOLD / "c2_sector_sweep.json").read_text())
     ref = {(r["nup"], r["ndw"]): r for r in gold["sectors"]}
@@ -178,7 +180,7 @@ def test_green_function_channels_in_the_callers_order(built, symmetric):
     against unpaired runs, and the re-opens served by the cache."""
     import hxv
     from hxv import models
-    from hxv.harness import gf_solve, gf_channels
+    from harness import gf_solve, gf_channels
     from oracle.oracle import OracleSector
 
     hxv.sector_cache_clear()
@@ -288,7 +290,7 @@ def test_green_function_channels_of_a_complex_two_orbital_model(built, spin):
     tests/test_gpu_lanczos.py::test_impurity_green_function_vs_lehmann)."""
     import hxv
     from hxv import models
-    from hxv.harness import gf_solve, gf_channels
+    from harness import gf_solve, gf_channels
     from oracle.oracle import OracleSector
 
     hxv.sector_cache_clear()
