@@ -32,7 +32,10 @@ sys.path.insert(0, str(ROOT / "cdmft-lanc-ed_amd"))
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "scripts"))  # harness.py: the callers' call order (measurement scaffolding, not the package)
 
-KERNELS_STAMP = "r05-a"   # bumped whenever the product kernels change: profiles/traffic.json is quoted only for the same stamp
+KERNELS_STAMP = "r06-a"   # bumped whenever the product kernels OR what they run on (tables, device row order) change: profiles/traffic.json and
+                          # profiles/kernel_trace.json are quoted only for the same stamp (r06-a: round 5's kernels on the device row order)
+HBM_COPY_GBS = 6290.0     # what a float4 copy measures on MI355X (MI355X_MICROARCH.md, "HBM3E peak BW ... 6.29 TB/s measured"): the FIXED yardstick
+                          # of the two-pass design's floor; the box's own copy rate is reported beside it, not used for it
 XGMI_LINK_GBS = 153.0  # one xGMI link, per direction (7 links per GPU: SURVEY.md 8e)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
@@ -190,6 +193,21 @@ def time_other_workload(name, dev, reps):
     return out
 
 
+def exchange_link_figures(sec, world, exchange):
+    """(bytes one GPU receives per product, link-bound ms) of an open split sector under `exchange` (xGMI is point to point --
+    every peer's bytes arrive over that peer's own link, 153 GB/s each way, 7 links per GPU -- so the bound is the LARGEST per-peer ingest
+    over one link's rate).  all-gather: one slab per peer; two transposes: 2 x slab/world per peer; halo: the busiest peer's columns."""
+    slab = 16 * (-(-sec.DimDw // world)) * sec.pitch
+    if exchange == "halo" and sec.exchange_mode == "halo":
+        cols = sec.halo_lists(world)[0]          # (the engine's own receive lists)
+        ingest, per_peer = 16 * sec.pitch * int(cols.sum()), 16 * sec.pitch * int(cols.max())
+    elif exchange == "alltoall":
+        ingest, per_peer = 2 * (world - 1) * slab // world, 2 * slab // world
+    else:
+        ingest, per_peer = (world - 1) * slab, slab
+    return ingest, per_peer / (XGMI_LINK_GBS * 1e9) * 1e3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -219,6 +237,8 @@ def main():
                     help="N>1 with --backend gloo: keep the C-ABI exchange (hxv_comm_init + hxv_apply_device_slab) for the data path and use gloo "
                          "for the control plane only -- with HXV_RCCL_LIB pointing at tests/rccl_double/_build/librccl_double_mp.so this is how N "
                          "processes on ONE GPU rehearse the driver's launch line through the engine's RCCL branches")
+    ap.add_argument("--no-other-exchanges", action="store_true", help="N>1 through the C-ABI: do not open, check and time the two exchanges that were not asked for (config.other_exchanges)")
+    ap.add_argument("--no-apply-host", action="store_true", help="skip the host-array leg (N=1): hxv_apply_host with its two PCIe copies against the box's own link rates (config.apply_host)")
     ap.add_argument("--no-check", action="store_true", help="N>1: skip the one checked product before the warm-up (split vs unsplit product on every rank)")
     ap.add_argument("--check", action="store_true", help="(kept for old command lines: the check is the default now)")
     args = ap.parse_args()
@@ -396,17 +416,33 @@ def main():
                 traffic_src = f"profiles/traffic.json (rocprofv3 --pmc, kernels {KERNELS_STAMP})"
         except Exception:
             traffic = None
-    # the two-pass design's own floor: 80 B per basis state (pass B 32, pass A 48) at the copy rate this box measures
+    # the two-pass design's own floor: 80 B per basis state (pass B 32, pass A 48) at the guide's measured copy rate, 6.29 TB/s -- a FIXED
+    # yardstick (the box's own copy rate moved the fraction between runs); that rate is reported beside it
     copy_gbs = copy_rate_gbs(dev)
-    floor_ms = 80.0 * sec.vecDim / (copy_gbs * 1e9) * 1e3
+    floor_ms = 80.0 * sec.vecDim / (HBM_COPY_GBS * 1e9) * 1e3
+    # the rocprofv3 --kernel-trace summary of this command, quoted only when it was collected on THIS kernel build (profiles/kernel_trace.json)
+    trace = None
+    kt = ROOT / "profiles" / "kernel_trace.json"
+    if kt.exists():
+        try:
+            kj = json.loads(kt.read_text())
+            if kj.get("workload") == args.workload and kj.get("n_gpus", 1) == world and kj.get("kernels_stamp") == KERNELS_STAMP:
+                trace = {"file": kj.get("file"), "avg_ms": kj.get("avg_ms"), "product_ms": kj.get("product_ms")}
+        except Exception:
+            trace = None
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "design_floor_ms": round(floor_ms, 4), "frac_of_design_floor": round(floor_ms / k_ms, 4), "copy_rate_GBs": round(copy_gbs, 1),
+                "design_floor_ms": round(floor_ms, 4), "frac_of_design_floor": round(floor_ms / k_ms, 4), "design_floor_rate_GBs": HBM_COPY_GBS,
+                "copy_rate_GBs": round(copy_gbs, 1), "kernels_stamp": KERNELS_STAMP, "rocprof_kernel_trace": trace,
                 "traffic": traffic, "traffic_source": traffic_src, "kernel": ("hxv_up_job" if sec.get_option("job_up_active") else "hxv_pass_up") + " + hxv_pass_dw (one product)", "kernel_ms": round(k_ms, 4),
                 "algorithmic_bytes": 32 * sec.vecDim}
     if step_ev_ms is not None:
         roofline["slab_product_ms_on_stream"] = round(step_ev_ms, 4)   # exchange + kernels of this rank, HIP events (hxv_time_apply_slab)
         # what the exchange costs each rank: the slab product on the stream minus its kernels; min / max over the ranks
-        ex_ms = step_ev_ms - k_ms
+        # (overlapped mode 2 runs pass A on a second stream BESIDE the exchange: that part of kernel_ms is not subtracted -- ADVICE r5)
+        k_ovl = sec.get_option("time_kernels_overlapped_us") * 1e-3
+        if k_ovl > 0:
+            roofline["kernel_ms_overlapped"] = round(k_ovl, 4)
+        ex_ms = step_ev_ms - (k_ms - k_ovl)
         if multi:
             t2 = torch.tensor([ex_ms, -ex_ms], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
             dist.all_reduce(t2, op=dist.ReduceOp.MAX)
@@ -414,11 +450,78 @@ def main():
         else:
             roofline["exchange_ms"] = {"this_rank": round(ex_ms, 4), "max": round(ex_ms, 4), "min": round(ex_ms, 4)}
 
+    # FIRST CONTACT WITH N GPUs RECORDS EVERY EXCHANGE: `value` above is the exchange asked for (default: the all-gather
+    # BASELINE mandates); the other two are opened, checked and timed in the same launch -- the sector re-opened under the other layout
+    # (hxv_set_exchange_default), joined through hxv_comm_init (the process's communicator serves it: no second ncclCommInitRank), ONE product
+    # compared with the checked product of the main exchange on every rank, then warm-up + timed steps + the kernels' share like above.
+    other_exchanges = None
+    if capi_exchange and world > 1 and not args.no_other_exchanges:
+        other_exchanges = {}
+        cpu_or_dev = dev if args.backend == "nccl" else "cpu"
+        step()                                                   # hv_local = the main exchange's product of v_local (checked above)
+        torch.cuda.synchronize()
+        hv_ref = hv_local.clone()
+        v_ref = v_local.clone()
+        for mode in ("allgather", "alltoall", "halo"):
+            if mode == args.exchange:
+                continue
+            hxv.set_exchange_default(mode)
+            s2 = hxv.HxvSector.from_model(model, nup, ndw, rank=rank, nranks=world, device=local_rank)
+            hxv.set_exchange_default("allgather")
+            if s2.exchange_mode != mode:
+                other_exchanges[mode] = {"skipped": f"the sector opens with the {s2.exchange_mode} exchange (spH0nd block or a tiny sector)"}
+                s2.close()
+                continue
+            ident2 = [hxv.HxvSector.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ident2, src=0)
+            s2.comm_init(ident2[0])
+            v2 = v_ref
+            if s2.exchange_mode != "alltoall":
+                v2 = s2.slab_home()
+                v2.copy_(v_ref)
+            hv2 = torch.empty_like(hv_ref)
+            s2.apply_device_slab(v2, hv2)
+            torch.cuda.synchronize()
+            a, b = (x.view(-1, s2.pitch)[:, : s2.DimUp] for x in (hv_ref, hv2))
+            err = (a - b).abs().max().item() / max(a.abs().max().item(), 1e-300)
+            t = torch.tensor([err], dtype=torch.float64, device=cpu_or_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            err = float(t.item())
+            if err > 1e-13:
+                raise SystemExit(f"bench.py: the {mode} exchange's product differs from the checked {args.exchange} one (max rel err over ranks {err:.2e}); no number reported")
+            n_o = max(3, min(args.steps, 20))
+            for _ in range(max(1, min(args.warmup, 5))):
+                s2.apply_device_slab(v2, hv2)
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n_o):
+                s2.apply_device_slab(v2, hv2)
+            torch.cuda.synchronize()
+            dist.barrier()
+            dt2 = time.perf_counter() - t0
+            t = torch.tensor([dt2], dtype=torch.float64, device=cpu_or_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ms2 = float(t.item()) / n_o * 1e3
+            ev_ms, k2_ms = s2.time_apply_slab(v2, hv2, max(3, min(n_o, 10)))
+            ex2 = ev_ms - k2_ms
+            t2 = torch.tensor([ex2, -ex2], dtype=torch.float64, device=cpu_or_dev)
+            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+            ingest2, lb2 = exchange_link_figures(s2, world, mode)
+            other_exchanges[mode] = {"ms_per_step": round(ms2, 4), "GBs": round(32.0 * Dim / (ms2 * 1e-3) / 1e9, 1), "steps": n_o, "check_rel_err_vs_main": err,
+                                     "link_bound_ms": round(lb2, 4), "exchange_ingest_bytes_per_gpu": ingest2, "kernel_ms": round(k2_ms, 4),
+                                     "exchange_ms": {"this_rank": round(ex2, 4), "max": round(float(t2[0].item()), 4), "min": round(-float(t2[1].item()), 4)}}
+            s2.close()
+            del hv2, v2
+            torch.cuda.empty_cache()
+        del hv_ref, v_ref
+
     ns = {"C2": 12, "C3": 16, "C4": 16, "C5": 18}[args.workload]
     out = {"metric": f"sector-HxV achieved HBM GB/s (algorithmic 32 B x Dim per product), Ns={ns} half-filled sector", "value": round(value, 1),
            "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
            "higher_is_better": True, "scaling": "weak" if by_sector else "strong", "vs_baseline": None, "dtype": "complex128 (f64)", "data": "synthetic",
            "config": {"workload": f"{args.workload}: {model.name} sector ({nup},{ndw}) Dim={Dim}", "DimUp": sec.DimUp, "DimDw": sec.DimDw,
+                      "device_row_order": sec.row_perm is not None,
                       "parallelism": f"{world} independent sectors, one per GPU, no exchange" if by_sector else f"DimDw split x{world}" + ({"allgather": " + RCCL allgather per product", "halo": " + RCCL send/recv of the columns H_dw couples across ranks",
                                                                   "alltoall": " + 2 RCCL all-to-all transposes per product"}[args.exchange] if world > 1 else ""),
                       "matvecs_per_s": round((world if by_sector else 1) * 1e3 / ms_step, 2)},
@@ -435,28 +538,71 @@ def main():
             out["config"]["rccl_libs_mapped"] = []
     if world > 1 and not by_sector:
         # what the exchange moves into every GPU per product: the xGMI links, not HBM, bound the N>1 product
-        slab = 16 * (-(-sec.DimDw // world)) * sec.pitch
         out["config"]["exchange"] = args.exchange
-        halo_cols = int(sec.halo_lists(world)[0].sum()) if sec.exchange_mode == "halo" else 0   # (the engine's own receive lists)
-        out["config"]["exchange_ingest_bytes_per_gpu"] = ((world - 1) * slab if args.exchange == "allgather" else
-                                                          16 * sec.pitch * halo_cols if args.exchange == "halo" else 2 * (world - 1) * slab // world)
-        # First-contact fields ("the result JSON should carry the link-bound alongside the measurement").  xGMI is point to point:
-        # every peer's bytes arrive over that peer's own link (153 GB/s each way, 7 links per GPU), so the bound is the LARGEST per-peer ingest
-        # over one link's rate.  all-gather: one slab per peer; two transposes: 2 x slab/world per peer; halo: the busiest peer's columns.
-        if args.exchange == "halo" and sec.exchange_mode == "halo":
-            per_peer = 16 * sec.pitch * int(sec.halo_lists(world)[0].max())
-        elif args.exchange == "alltoall":
-            per_peer = 2 * slab // world
-        else:
-            per_peer = slab
+        ingest, lb_ms = exchange_link_figures(sec, world, args.exchange)
+        out["config"]["exchange_ingest_bytes_per_gpu"] = ingest
+        # First-contact fields ("the result JSON should carry the link-bound alongside the measurement"): exchange_link_figures
         out["config"]["link_GBs_assumed"] = XGMI_LINK_GBS
-        out["config"]["link_bound_ms"] = round(per_peer / (XGMI_LINK_GBS * 1e9) * 1e3, 4)
+        out["config"]["link_bound_ms"] = round(lb_ms, 4)
         out["config"]["link_bound_note"] = "largest per-peer ingest of one product / one xGMI link (point to point, 7 links per GPU); compute overlaps none of it in the default exchanges"
+        if other_exchanges is not None:
+            out["config"]["other_exchanges"] = other_exchanges
+            out["config"]["comm_cache"] = hxv.comm_cache_stats()   # one ncclCommInitRank served every sector this process opened
     if world == 1 and not args.rehearse_capi:
         # what each of the three exchanges would move into one GPU per product at 8 ranks
         rp, cols, _ = sec.csr("dw")
         need8, _ = hxv.halo_plan(rp, cols - 1, sec.DimDw, 8)
         out["config"]["exchange_ingest_bytes_per_gpu_at_8_ranks"] = hxv.exchange_ingest_bytes(sec.DimUp, sec.DimDw, 8, need8)
+    if world == 1 and not args.rehearse_capi and not args.no_apply_host:
+        # THE DROP-IN SURFACE ITSELF: north_star keeps spHtimesV_p on HOST arrays (cc_sparse_HxV, ED_VARS_GLOBAL.f90:72-78; caller
+        # ED_DIAG.f90:145,152) -- hxv_apply_host = H2D of v, the product, D2H of Hv.  Host arrays page-locked ONCE (hxv_host_register), then three
+        # products; the floor beside it = the same bytes at this box's own H2D and D2H rates (plain pinned copies of the same size) + the kernels.
+        import numpy as np
+
+        nb = 16 * sec.vecDim
+        vh = np.empty(sec.vecDim, dtype=np.complex128)
+        hh = np.empty(sec.vecDim, dtype=np.complex128)
+        vh.real[:] = 1.0 / np.sqrt(sec.vecDim)
+        vh.imag[:] = 0.0
+        t0 = time.perf_counter()
+        sec.apply_host(vh, hh)                                  # pageable arrays (what an unmodified host hands over), first call: staging buffers
+        t_first = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        sec.apply_host(vh, hh)
+        t_page = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        hxv.host_register(vh)
+        hxv.host_register(hh)
+        t_reg = time.perf_counter() - t0
+        sec.apply_host(vh, hh)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            sec.apply_host(vh, hh)
+        t_pin = (time.perf_counter() - t0) / 3
+        # the box's own link rates for the same byte count: plain copies between a page-locked host buffer and the device, each way, twice
+        dbuf = torch.empty(sec.vecDim, dtype=torch.complex128, device=dev)
+        pbuf = torch.empty(sec.vecDim, dtype=torch.complex128, pin_memory=True)
+        rates = {}
+        for name, dst, src in (("h2d", dbuf, pbuf), ("d2h", pbuf, dbuf)):
+            dst.copy_(src, non_blocking=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                dst.copy_(src, non_blocking=True)
+            torch.cuda.synchronize()
+            rates[name] = nb * 2 / (time.perf_counter() - t0) / 1e9
+        del pbuf
+        del dbuf
+        hxv.host_unregister(vh)
+        hxv.host_unregister(hh)
+        del vh, hh
+        floor_h = nb / (rates["h2d"] * 1e9) * 1e3 + k_ms + nb / (rates["d2h"] * 1e9) * 1e3
+        out["config"]["apply_host"] = {"what": "hxv_apply_host on host arrays (the spHtimesV_p surface itself): H2D of v + product + D2H of Hv, arrays page-locked once",
+                                       "ms_per_product": round(t_pin * 1e3, 2), "h2d_GBs": round(rates["h2d"], 1), "d2h_GBs": round(rates["d2h"], 1),
+                                       "pcie_floor_ms": round(floor_h, 2), "ratio_to_floor": round(t_pin * 1e3 / floor_h, 3),
+                                       "bytes_each_way": nb, "kernels_ms": round(k_ms, 3), "ms_per_product_pageable": round(t_page * 1e3, 2),
+                                       "first_call_ms": round(t_first * 1e3, 1), "host_register_ms": round(t_reg * 1e3, 1),
+                                       "GBs_algorithmic": round(32.0 * sec.vecDim / t_pin / 1e9, 1)}
     if not args.no_lanczos and world == 1 and not args.rehearse_capi:
         # full iterations: product + fused recurrence + 2 reductions, vectors in HBM.  Headline = complex(8) vectors, the
         # reference's data type; when H is real (C2, C3) the device drivers also run on real vectors (half the bytes).
@@ -470,7 +616,7 @@ def main():
         lz_bytes = 96 * sec.vecDim
         roofline["lanczos"] = {"bytes_per_state": 96, "bytes": lz_bytes, "ms_per_iter": round(lz_ms, 4), "achieved": round(lz_bytes / (lz_ms * 1e-3) / 1e9, 1),
                                "unit": "GB/s", "frac": round(lz_bytes / (lz_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "design_bytes_per_state": 144,
-                               "frac_of_design_floor": round(144.0 * sec.vecDim / (copy_gbs * 1e9) * 1e3 / lz_ms, 4)}
+                               "frac_of_design_floor": round(144.0 * sec.vecDim / (HBM_COPY_GBS * 1e9) * 1e3 / lz_ms, 4)}
         sec.set_option("real_vectors", 1)
         if sec.real_vectors_available:
             lzr_ms = sec.time_lanczos(20)
@@ -494,7 +640,7 @@ def main():
             rb, rlz = 16 * sec.vecDim, 48 * sec.vecDim
             roofline["real_vectors"] = {"product_bytes_per_state": 16, "product_ms": round(pr_ms, 4), "product_achieved": round(rb / (pr_ms * 1e-3) / 1e9, 1),
                                         "product_frac": round(rb / (pr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                        "product_frac_of_design_floor": round(40.0 * sec.vecDim / (copy_gbs * 1e9) * 1e3 / pr_ms, 4),
+                                        "product_frac_of_design_floor": round(40.0 * sec.vecDim / (HBM_COPY_GBS * 1e9) * 1e3 / pr_ms, 4),
                                         "lanczos_bytes_per_state": 48, "lanczos_ms_per_iter": round(lzr_ms, 4), "lanczos_achieved": round(rlz / (lzr_ms * 1e-3) / 1e9, 1),
                                         "lanczos_frac": round(rlz / (lzr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "unit": "GB/s"}
         if sec.real_vectors_available:

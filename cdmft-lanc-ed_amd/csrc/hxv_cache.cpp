@@ -73,6 +73,7 @@ std::string sector_cache_key(const hxv_model& m, int nup, int ndw, int rank, int
   for (double u : m.uloc) put(k, u);
   put(k, m.ust); put(k, m.jh); put(k, m.jx); put(k, m.jp); put(k, m.xmu);
   put(k, nup); put(k, ndw); put(k, rank); put(k, nranks); put(k, device); put(k, exchange);
+  k.append(row_order_env_key());  // (HXV_ROW_ORDER...: the image holds the tables of ONE device row order)
   k.append(reinterpret_cast<const char*>(m.imphloc), 16 * nloc);
   if (m.nbath > 0) {
     k.append(reinterpret_cast<const char*>(m.hbath), 16 * nloc * (size_t)m.nbath);

@@ -53,13 +53,17 @@ int64_t host_bytes_of(const SectorHost& s) {
   auto vb = [](const auto& v) { return (int64_t)(v.capacity() * sizeof(v[0])); };
   auto sp = [&](const SpinOp& o) { return vb(o.rowptr) + vb(o.cols) + vb(o.vals) + vb(o.ell) + vb(o.coef); };
   return sp(s.up) + sp(s.dw) + vb(s.vcol) + vb(s.map_up) + vb(s.map_dw) + vb(s.a_up) + vb(s.a_dw) + vb(s.diag_stored) + vb(s.nd_up) + vb(s.nd_dw) +
-         vb(s.halo_cols) + vb(s.send_cols);
+         vb(s.halo_cols) + vb(s.send_cols) + sp(s.up_dev) + vb(s.up_perm) + vb(s.up_iperm) + vb(s.up_sign) + vb(s.key_up) + vb(s.map_up_dev) + vb(s.a_up_dev) +
+         vb(s.nd_up_dev);
 }
 }  // namespace
 // the staged tables of an image whose host half is done (SectorImage::pending)
 struct SectorImage::Pending {
   TableArena ar;
   uint32_t *ell_up = nullptr, *ell_dw = nullptr, *vcol = nullptr, *map_up = nullptr, *map_dw = nullptr, *ndu = nullptr, *ndd = nullptr;
+  uint32_t* map_up_ref = nullptr;   // device row order only: the reference's sorted up configurations (ladder operators look sources up in it)
+  int32_t *up_perm = nullptr, *up_iperm = nullptr;
+  uint8_t* up_sign = nullptr;
   double2 *coef_up = nullptr, *coef_dw = nullptr;
   double *a_up = nullptr, *a_dw = nullptr, *stored = nullptr;
 };
@@ -70,25 +74,32 @@ int prepare_image(SectorImage& im) {
   const auto t0 = std::chrono::steady_clock::now();
   auto pd = std::make_shared<SectorImage::Pending>();
   TableArena& ar = pd->ar;
-  ar.add(s.up.ell, &pd->ell_up);
+  const SpinOp& sup = s.dev_up();   // (H_up between DEVICE rows: SectorHost::up_perm)
+  ar.add(sup.ell, &pd->ell_up);
   ar.add(translate_ell_src(s.dw.ell, s.vcol), &pd->ell_dw);
   ar.add(s.vcol, &pd->vcol);
-  std::vector<double2> cu(s.up.coef.size()), cd(s.dw.coef.size());
-  for (size_t i = 0; i < cu.size(); ++i) cu[i] = make_double2(s.up.coef[i].real(), s.up.coef[i].imag());
+  std::vector<double2> cu(sup.coef.size()), cd(s.dw.coef.size());
+  for (size_t i = 0; i < cu.size(); ++i) cu[i] = make_double2(sup.coef[i].real(), sup.coef[i].imag());
   for (size_t i = 0; i < cd.size(); ++i) cd[i] = make_double2(s.dw.coef[i].real(), s.dw.coef[i].imag());
   ar.add(cu, &pd->coef_up);
   ar.add(cd, &pd->coef_dw);
   if (s.separable_diag) {
-    ar.add(s.map_up, &pd->map_up);
+    ar.add(s.dev_map_up(), &pd->map_up);
     ar.add(s.map_dw, &pd->map_dw);
-    ar.add(s.a_up, &pd->a_up);
+    ar.add(s.dev_a_up(), &pd->a_up);
     ar.add(s.a_dw, &pd->a_dw);
   } else {
     ar.add(s.diag_stored, &pd->stored);
   }
   if (!s.nd_up.empty()) {
-    ar.add(s.nd_up, &pd->ndu);
+    ar.add(s.dev_nd_up(), &pd->ndu);
     ar.add(s.nd_dw, &pd->ndd);
+  }
+  if (s.row_order()) {
+    ar.add(s.map_up, &pd->map_up_ref);
+    ar.add(s.up_perm, &pd->up_perm);
+    ar.add(s.up_iperm, &pd->up_iperm);
+    ar.add(s.up_sign, &pd->up_sign);
   }
   PlanUploader pu{[&ar](const std::vector<uint32_t>& v, uint32_t** p) { return ar.add(v, p); },
                   [&ar](const std::vector<double2>& v, double2** p) { return ar.add(v, p); }};
@@ -119,7 +130,11 @@ int upload_image(SectorImage& im, int device) {
   im.device = device;
   if (e != hipSuccess) return fail(HXV_ERR_HIP, std::string("upload of the sector tables: ") + hipGetErrorString(e));
   DevSector& d = im.dev;
-  d.up = DevSpin{pd.ell_up, pd.coef_up, s.up.K, s.up.dim};
+  d.up = DevSpin{pd.ell_up, pd.coef_up, s.dev_up().K, s.dev_up().dim};
+  d.map_up_ref = pd.map_up_ref;
+  d.up_perm = pd.up_perm;
+  d.up_iperm = pd.up_iperm;
+  d.up_sign = pd.up_sign;
   d.dw = DevSpin{pd.ell_dw, pd.coef_dw, s.dw.K, s.dw.dim};
   d.diag.mode = s.separable_diag ? 0 : 1;
   d.diag.a_up = pd.a_up;
@@ -142,7 +157,7 @@ int upload_image(SectorImage& im, int device) {
   d.ndcsr_rowptr = nullptr;
   d.ndcsr_cols = nullptr;
   d.ndcsr_vals = nullptr;
-  d.real_h = (s.up.real_vals && s.dw.real_vals) ? 1 : 0;
+  d.real_h = (s.dev_up().real_vals && s.dw.real_vals) ? 1 : 0;
   im.pending.reset();
   im.us_upload = us_since(t0);
   im.uploaded = true;
@@ -450,6 +465,89 @@ int hxv_apply_up_add(hxv_handle* h, const void* d_v_local, const void* d_w, void
   return HXV_OK;
 }
 
+}  // extern "C"
+
+namespace hxv {
+namespace {
+// contiguous reference layout [ncols][dimup] -> device layout [ncols][pitch]: device row d holds reference row iperm[d], times the basis sign
+__global__ void __launch_bounds__(256) rows_ref_to_dev(const double2* __restrict__ src, double2* __restrict__ dst, const int32_t* __restrict__ iperm,
+                                                       const uint8_t* __restrict__ sign, int dimup, int pitch, int64_t n) {
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (int64_t)gridDim.x * 256) {
+    const int64_t c = t / pitch;
+    const int d = (int)(t - c * pitch);
+    double2 x = make_double2(0.0, 0.0);   // (pad rows are zero in every device vector)
+    if (d < dimup) {
+      x = src[c * dimup + iperm[d]];
+      if (sign[d]) x = make_double2(-x.x, -x.y);
+    }
+    dst[t] = x;
+  }
+}
+// device layout -> contiguous reference layout: reference row i sits at device row perm[i]
+__global__ void __launch_bounds__(256) rows_dev_to_ref(const double2* __restrict__ src, double2* __restrict__ dst, const int32_t* __restrict__ perm,
+                                                       const uint8_t* __restrict__ sign, int dimup, int pitch, int64_t n) {
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (int64_t)gridDim.x * 256) {
+    const int64_t c = t / dimup;
+    const int i = (int)(t - c * dimup);
+    const int d = perm[i];
+    double2 x = src[c * pitch + d];
+    if (sign[d]) x = make_double2(-x.x, -x.y);
+    dst[t] = x;
+  }
+}
+}  // namespace
+
+int slab_from_host(hxv_handle* h, const void* v_host, double2* d_vec) {
+  const SectorHost& s = h->host;
+  const size_t col = (size_t)s.dimup * sizeof(double2), pit = (size_t)s.pitch * sizeof(double2);
+  if (s.qdw <= 0) return HXV_OK;
+  if (!s.row_order()) {
+    HIPCHK(hipMemcpy2DAsync(d_vec, pit, v_host, col, col, (size_t)s.qdw, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  } else {
+    double2* tmp = nullptr;
+    HIPCHK(pool_alloc(h->device, col * (size_t)s.qdw, (void**)&tmp));
+    hipError_t e = hipMemcpyAsync(tmp, v_host, col * (size_t)s.qdw, hipMemcpyHostToDevice, h->stream);
+    const int64_t n = (int64_t)s.pitch * s.qdw;
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(rows_ref_to_dev, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 65536)), dim3(256), 0, h->stream, tmp, d_vec, h->dev.up_iperm,
+                         h->dev.up_sign, s.dimup, s.pitch, n);
+      e = hipGetLastError();
+    }
+    const hipError_t e2 = hipStreamSynchronize(h->stream);
+    pool_free(h->device, tmp);
+    if (e != hipSuccess || e2 != hipSuccess) return fail(HXV_ERR_HIP, std::string("host -> device vector: ") + hipGetErrorString(e != hipSuccess ? e : e2));
+  }
+  h->h2d_bytes += (int64_t)(col * s.qdw);
+  return HXV_OK;
+}
+
+int slab_to_host(hxv_handle* h, const double2* d_vec, void* v_host) {
+  const SectorHost& s = h->host;
+  const size_t col = (size_t)s.dimup * sizeof(double2), pit = (size_t)s.pitch * sizeof(double2);
+  if (s.qdw <= 0) return HXV_OK;
+  if (!s.row_order()) {
+    HIPCHK(hipMemcpy2DAsync(v_host, col, d_vec, pit, col, (size_t)s.qdw, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  } else {
+    double2* tmp = nullptr;
+    HIPCHK(pool_alloc(h->device, col * (size_t)s.qdw, (void**)&tmp));
+    const int64_t n = (int64_t)s.dimup * s.qdw;
+    hipLaunchKernelGGL(rows_dev_to_ref, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 65536)), dim3(256), 0, h->stream, d_vec, tmp, h->dev.up_perm,
+                       h->dev.up_sign, s.dimup, s.pitch, n);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(v_host, tmp, col * (size_t)s.qdw, hipMemcpyDeviceToHost, h->stream);
+    const hipError_t e2 = hipStreamSynchronize(h->stream);
+    pool_free(h->device, tmp);
+    if (e != hipSuccess || e2 != hipSuccess) return fail(HXV_ERR_HIP, std::string("device -> host vector: ") + hipGetErrorString(e != hipSuccess ? e : e2));
+  }
+  h->d2h_bytes += (int64_t)(col * s.qdw);
+  return HXV_OK;
+}
+}  // namespace hxv
+
+extern "C" {
+
 int hxv_apply_host(hxv_handle* h, int64_t nloc, const void* v, void* hv) {
   if (!h || !v || !hv) return fail(HXV_ERR_ARG, "hxv_apply_host: NULL argument");
   if (h->host.panel_rows > 0) return fail(HXV_ERR_STATE, "hxv_apply_host: panel handles only do hxv_apply_dw_panel");
@@ -469,13 +567,34 @@ int hxv_apply_host(hxv_handle* h, int64_t nloc, const void* v, void* hv) {
     HIPCHK(hipMemsetAsync(h->d_stage_hv, 0, bytes, h->stream));
     h->device_bytes += 2 * (int64_t)bytes;
   }
-  if (h->host.qdw > 0) HIPCHK(hipMemcpy2DAsync(h->d_stage_v, pit, v, col, col, (size_t)h->host.qdw, hipMemcpyHostToDevice, h->stream));
-  int rc = apply_slab(h, h->d_stage_v, h->d_stage_hv, h->stream);
+  (void)col;
+  int rc = slab_from_host(h, v, h->d_stage_v);
   if (rc) return rc;
-  if (h->host.qdw > 0) HIPCHK(hipMemcpy2DAsync(hv, col, h->d_stage_hv, pit, col, (size_t)h->host.qdw, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  h->h2d_bytes += (int64_t)(col * h->host.qdw);
-  h->d2h_bytes += (int64_t)(col * h->host.qdw);
+  rc = apply_slab(h, h->d_stage_v, h->d_stage_hv, h->stream);
+  if (rc) return rc;
+  return slab_to_host(h, h->d_stage_hv, hv);
+}
+
+// Page-lock a host array the host program keeps passing to hxv_apply_host / the *_host drivers (the Lanczos work vectors of ED_DIAG): a
+// pinned array is copied by DMA at the link's rate, a pageable one through the runtime's staging buffers.  hipHostRegister costs ~0.1 s per
+// GB: once per array, not per product.
+int hxv_host_register(void* ptr, int64_t bytes) {
+  if (!ptr || bytes <= 0) return fail(HXV_ERR_ARG, "hxv_host_register: bad argument");
+  hipError_t e = hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault);
+  if (e == hipErrorHostMemoryAlreadyRegistered) {
+    (void)hipGetLastError();
+    return HXV_OK;
+  }
+  if (e != hipSuccess) return fail(HXV_ERR_HIP, std::string("hipHostRegister: ") + hipGetErrorString(e));
+  return HXV_OK;
+}
+int hxv_host_unregister(void* ptr) {
+  if (!ptr) return HXV_OK;
+  hipError_t e = hipHostUnregister(ptr);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(HXV_ERR_HIP, std::string("hipHostUnregister: ") + hipGetErrorString(e));
+  }
   return HXV_OK;
 }
 
@@ -529,24 +648,26 @@ int hxv_vector_free(hxv_handle* h, void* d_vec) {
 int hxv_vector_from_host(hxv_handle* h, const void* v_host, void* d_vec) {
   if (!h || !v_host || !d_vec) return fail(HXV_ERR_ARG, "hxv_vector_from_host: NULL argument");
   HIPCHK(hipSetDevice(h->device));
-  const size_t col = (size_t)h->host.dimup * sizeof(double2), pit = (size_t)h->host.pitch * sizeof(double2);
-  if (h->host.qdw > 0) HIPCHK(hipMemcpy2DAsync(d_vec, pit, v_host, col, col, (size_t)h->host.qdw, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  h->h2d_bytes += (int64_t)(col * h->host.qdw);
-  return HXV_OK;
+  return slab_from_host(h, v_host, (double2*)d_vec);
 }
 
 int hxv_vector_to_host(hxv_handle* h, const void* d_vec, void* v_host) {
   if (!h || !v_host || !d_vec) return fail(HXV_ERR_ARG, "hxv_vector_to_host: NULL argument");
   HIPCHK(hipSetDevice(h->device));
-  const size_t col = (size_t)h->host.dimup * sizeof(double2), pit = (size_t)h->host.pitch * sizeof(double2);
-  if (h->host.qdw > 0) HIPCHK(hipMemcpy2DAsync(v_host, col, d_vec, pit, col, (size_t)h->host.qdw, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  h->d2h_bytes += (int64_t)(col * h->host.qdw);
-  return HXV_OK;
+  return slab_to_host(h, (const double2*)d_vec, v_host);
 }
 
 int64_t hxv_live_handles(void) { return hxv::g_live_handles.load(); }
+
+int hxv_row_order(const hxv_handle* h, int32_t* perm, int8_t* sign) {
+  if (!h) return -1;
+  const SectorHost& s = h->host;
+  if (perm)
+    for (int i = 0; i < s.dimup; ++i) perm[i] = s.row_order() ? s.up_perm[i] : i;
+  if (sign)
+    for (int i = 0; i < s.dimup; ++i) sign[i] = (s.row_order() && s.up_sign[s.up_perm[i]]) ? (int8_t)-1 : (int8_t)1;
+  return s.row_order() ? 1 : 0;
+}
 
 int hxv_get_maps(const hxv_handle* h, int32_t* map_up, int32_t* map_dw) {
   if (!h) return fail(HXV_ERR_ARG, "NULL handle");
@@ -743,6 +864,7 @@ int64_t hxv_get_option(const hxv_handle* h, const char* name) {
   if (!strcmp(name, "lanczos_inplace")) return h->lz_inplace;
   if (!strcmp(name, "exchange_overlap")) return h->a2a_overlap;
   if (!strcmp(name, "kernel")) return h->kernel;
+  if (!strcmp(name, "time_kernels_overlapped_us")) return h->last_overlapped_us;
   if (!strcmp(name, "tile_bits_up")) return h->plan.up.lowbits;
   if (!strcmp(name, "tile_bits_dw")) return h->plan.dw.lowbits;
   if (!strcmp(name, "real_dw_pairs")) return h->plan.opt.real_dw_pairs;

@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
@@ -100,6 +101,52 @@ Rccl* rccl() {
 Rccl* api(const hxv_handle* h) { return static_cast<Rccl*>(h->comm_api); }
 int nccl_fail(const Rccl* r, const char* what, ncclResult_t e) {
   return fail(HXV_ERR_HIP, std::string(what) + ": " + (r && r->GetErrorString ? r->GetErrorString(e) : "RCCL error"));
+}
+
+// ---- ONE communicator per process, not per sector ---------------------------------------------------------
+// The reference sets MpiComm once per solve (ED_VARS_GLOBAL.f90:365-380, ed_set_MpiComm) and derives a sub-communicator only for sectors with
+// DimDw < MpiSize (ED_HAMILTONIAN.f90:63-89); its callers open 289 sectors per ED_DIAG sweep (ED_DIAG.f90:142-190) and 56 per Green's-function
+// stage (ED_GF_NORMAL.f90:208-222).  ncclCommInitRank is a collective that builds rings and channels over xGMI -- hundreds of milliseconds on a
+// node -- so the engine builds it ONCE per (library, nranks, rank, device) and every later hxv_comm_init with the same key binds the handle to
+// that communicator (the id it is given is then not consumed: all ranks take the same branch, because all ranks have made the same calls).
+// A sector with DimDw < nranks is opened by the first DimDw ranks with nranks' = DimDw: another key, built once as well.
+// HXV_COMM_CACHE=0: one communicator per handle, as before round 6.  An aborted communicator leaves the cache.
+struct ProcComm {
+  ncclComm_t c = nullptr;
+  Rccl* api = nullptr;
+  int nranks = 0, rank = 0, device = 0;
+  bool cached = false;            // lives in g_comms until hxv_comm_cache_clear (else: owned by the one handle that made it)
+  std::atomic<int> users{0};      // handles bound to it
+  std::atomic<int> aborted{0};
+};
+struct CommCache {
+  std::mutex mu;
+  std::vector<ProcComm*> all;     // cached communicators of this process
+  int64_t inits = 0, reuses = 0;  // ncclCommInitRank calls made / hxv_comm_init calls served by a cached communicator
+};
+CommCache& comm_cache() {
+  static CommCache c;
+  return c;
+}
+bool comm_cache_on() {
+  const char* e = getenv("HXV_COMM_CACHE");
+  return !(e && e[0] == '0');
+}
+ProcComm* pc(const hxv_handle* h) { return static_cast<ProcComm*>(h->comm_shared); }
+void proc_comm_destroy(ProcComm* p) {
+  if (!p) return;
+  if (p->c && !p->aborted) (void)p->api->CommDestroy(p->c);  // (ncclCommAbort has freed an aborted communicator)
+  delete p;
+}
+// A collective on the handle's communicator has FAILED (a peer aborted, a link went down): the communicator must not serve the next sector.
+// It leaves the cache (the next hxv_comm_init builds a new one from its id); the handles bound to it keep it until they are closed.
+int comm_failed(hxv_handle* h, const char* what, ncclResult_t e) {
+  if (ProcComm* p = pc(h)) {
+    std::lock_guard<std::mutex> lk(comm_cache().mu);
+    auto& all = comm_cache().all;
+    all.erase(std::remove(all.begin(), all.end(), p), all.end());
+  }
+  return nccl_fail(api(h), what, e);
 }
 
 // ---- thread ranks: the ranks of a sector are host threads of this process -----------------------------------------
@@ -214,7 +261,7 @@ int comm_sendrecv_cols(hxv_handle* h, const void* send_v, const int64_t* send_pt
     if (nr && e == ncclSuccess) e = r->Recv(recv + (size_t)recv_ptr[p] * cb, nr, ncclFloat64, p, (ncclComm_t)h->comm, st);
   }
   ncclResult_t e2 = r->GroupEnd();
-  if (e != ncclSuccess || e2 != ncclSuccess) return nccl_fail(r, "grouped send/recv", e != ncclSuccess ? e : e2);
+  if (e != ncclSuccess || e2 != ncclSuccess) return comm_failed(h, "grouped send/recv", e != ncclSuccess ? e : e2);
   return HXV_OK;
 }
 }  // namespace hxv
@@ -275,7 +322,7 @@ int exchange(hxv_handle* h, const void* d_v_local, bool real, hipStream_t st) {
     if (rc) return rc;
   } else {
     ncclResult_t e = api(h)->AllGather(mine, gather, slot / sizeof(double), ncclFloat64, (ncclComm_t)h->comm, st);
-    if (e != ncclSuccess) return nccl_fail(api(h), "ncclAllGather", e);
+    if (e != ncclSuccess) return comm_failed(h, "ncclAllGather", e);
   }
   h->n_exchange++;
   return HXV_OK;
@@ -284,7 +331,10 @@ int exchange(hxv_handle* h, const void* d_v_local, bool real, hipStream_t st) {
 
 namespace hxv {
 
-bool comm_ready(const hxv_handle* h) { return (h->comm != nullptr && !h->comm_aborted) || h->lgroup != nullptr; }
+bool comm_ready(const hxv_handle* h) {
+  const bool gone = h->comm_aborted || (h->comm_shared && static_cast<const ProcComm*>(h->comm_shared)->aborted);
+  return (h->comm != nullptr && !gone) || h->lgroup != nullptr;
+}
 
 // Does p point into one of the handle's gather buffers (hxv_slab_home hands out a slot of the first)?  The device Lanczos drivers zero
 // the slab's place in all three before they read their start vector: a start vector that lives there is staged first.
@@ -371,7 +421,7 @@ int comm_allreduce_sum(hxv_handle* h, double* d_buf, size_t count, hipStream_t s
   }
   if (!h->comm) return HXV_OK;  // serial: nothing to add
   ncclResult_t e = api(h)->AllReduce(d_buf, d_buf, count, ncclFloat64, ncclSum, (ncclComm_t)h->comm, st);
-  if (e != ncclSuccess) return nccl_fail(api(h), "ncclAllReduce", e);
+  if (e != ncclSuccess) return comm_failed(h, "ncclAllReduce", e);
   return HXV_OK;
 }
 
@@ -704,8 +754,19 @@ int apply_slab_real(hxv_handle* h, const double* d_v_local, double* d_hv_local, 
 
 void comm_release(hxv_handle* h) {
   if (h->comm) {
-    if (!h->comm_aborted) (void)api(h)->CommDestroy((ncclComm_t)h->comm);  // (ncclCommAbort has freed an aborted communicator)
+    // the communicator belongs to the process (cache) or to this handle alone (HXV_COMM_CACHE=0 / taken out of the cache by an abort)
+    ProcComm* p = pc(h);
+    if (p) {
+      const int left = --p->users;
+      bool in_cache = false;
+      if (p->cached) {
+        std::lock_guard<std::mutex> lk(comm_cache().mu);
+        for (ProcComm* q : comm_cache().all) in_cache = in_cache || q == p;
+      }
+      if (!in_cache && left == 0) proc_comm_destroy(p);
+    }
     h->comm = nullptr;
+    h->comm_shared = nullptr;
     h->comm_api = nullptr;
     h->comm_aborted = 0;
   }
@@ -760,13 +821,71 @@ int hxv_comm_init(hxv_handle* h, const void* id128) {
   Rccl* r = rccl();
   if (!r->err.empty()) return fail(HXV_ERR_UNSUPPORTED, r->err);
   HIPCHK(hipSetDevice(h->device));
+  const bool use_cache = comm_cache_on();
+  CommCache& cc = comm_cache();
+  if (use_cache) {
+    std::lock_guard<std::mutex> lk(cc.mu);
+    for (ProcComm* p : cc.all)
+      if (p->api == r && p->nranks == h->host.nranks && p->rank == h->host.rank && p->device == h->device && !p->aborted) {
+        ++p->users;
+        ++cc.reuses;
+        h->comm = p->c;
+        h->comm_shared = p;
+        h->comm_api = r;
+        return HXV_OK;
+      }
+  }
   ncclUniqueId id;
   std::memcpy(&id, id128, sizeof(id));
   ncclComm_t c = nullptr;
   ncclResult_t e = r->CommInitRank(&c, h->host.nranks, id, h->host.rank);
   if (e != ncclSuccess) return nccl_fail(r, "ncclCommInitRank", e);
+  ProcComm* p = new ProcComm();
+  p->c = c;
+  p->api = r;
+  p->nranks = h->host.nranks;
+  p->rank = h->host.rank;
+  p->device = h->device;
+  p->cached = use_cache;
+  p->users = 1;
+  {
+    std::lock_guard<std::mutex> lk(cc.mu);
+    ++cc.inits;
+    if (use_cache) cc.all.push_back(p);
+  }
   h->comm = c;
+  h->comm_shared = p;
   h->comm_api = r;
+  return HXV_OK;
+}
+
+// The cached communicators of this process (see ProcComm): *entries alive, *inits = ncclCommInitRank calls made since the process started,
+// *reuses = hxv_comm_init calls that bound a handle to a communicator that existed already.  Any out may be NULL.
+int hxv_comm_cache_stats(int64_t* entries, int64_t* inits, int64_t* reuses) {
+  CommCache& cc = comm_cache();
+  std::lock_guard<std::mutex> lk(cc.mu);
+  if (entries) *entries = (int64_t)cc.all.size();
+  if (inits) *inits = cc.inits;
+  if (reuses) *reuses = cc.reuses;
+  return HXV_OK;
+}
+
+// ncclCommDestroy of every cached communicator no handle is bound to (collective in the RCCL sense: every rank of a communicator calls it at the
+// same point of the program -- the end of a solve); communicators still in use stay.  Returns the number destroyed through *destroyed.
+int hxv_comm_cache_clear(int64_t* destroyed) {
+  CommCache& cc = comm_cache();
+  std::vector<ProcComm*> gone;
+  {
+    std::lock_guard<std::mutex> lk(cc.mu);
+    std::vector<ProcComm*> keep;
+    for (ProcComm* p : cc.all) (p->users == 0 ? gone : keep).push_back(p);
+    cc.all.swap(keep);
+  }
+  for (ProcComm* p : gone) {
+    (void)hipSetDevice(p->device);
+    proc_comm_destroy(p);
+  }
+  if (destroyed) *destroyed = (int64_t)gone.size();
   return HXV_OK;
 }
 
@@ -810,11 +929,23 @@ int hxv_comm_abort(hxv_handle* h) {
     G->cv.notify_all();
     return HXV_OK;
   }
-  if (!h->comm || h->comm_aborted) return HXV_OK;
-  Rccl* r = api(h);
+  // (not to be raced with hxv_destroy / hxv_comm_free of the SAME handle: the caller joins or serialises -- hxv/engine.py takes a per-sector
+  //  lock around both; the handle's fields are read once, up front)
+  void* const comm = h->comm;
+  ProcComm* const p = pc(h);
+  Rccl* const r = api(h);
+  if (!comm || h->comm_aborted || (p && p->aborted)) return HXV_OK;
   if (!r || !r->CommAbort) return fail(HXV_ERR_UNSUPPORTED, "hxv_comm_abort: the RCCL library in use exports no ncclCommAbort");
   h->comm_aborted = 1;
-  ncclResult_t e = r->CommAbort((ncclComm_t)h->comm);
+  if (p) {
+    // the communicator is shared by every sector of this process: all of them lose it, and the cache forgets it (the next hxv_comm_init
+    // builds a new one from the id it is given -- every rank's, because an aborted communicator fails its collectives on every rank)
+    if (p->aborted.exchange(1)) return HXV_OK;
+    std::lock_guard<std::mutex> lk(comm_cache().mu);
+    auto& all = comm_cache().all;
+    all.erase(std::remove(all.begin(), all.end(), p), all.end());
+  }
+  ncclResult_t e = r->CommAbort((ncclComm_t)comm);
   if (e != ncclSuccess) return nccl_fail(r, "ncclCommAbort", e);
   return HXV_OK;
 }
@@ -883,7 +1014,7 @@ int hxv_time_apply_slab(hxv_handle* h, const void* d_v_local, void* d_hv_local, 
     if (!e) HIPCHK(hipEventCreate(&e));
   const bool two = h->host.exchange == 2 && h->host.nranks > 1;
   const bool ov = two && h->a2a_overlap && h->plan.usable;  // overlapped mode 2: pass A runs on the second stream, between kt_ev[4] and [5]
-  double tot = 0.0, ker = 0.0;
+  double tot = 0.0, ker = 0.0, ovl = 0.0;
   int rc = HXV_OK;
   h->kt_on = 1;
   for (int i = 0; i < nrep && rc == HXV_OK; ++i) {
@@ -901,7 +1032,10 @@ int hxv_time_apply_slab(hxv_handle* h, const void* d_v_local, void* d_hv_local, 
     if (e != hipSuccess) rc = fail(HXV_ERR_HIP, std::string("hxv_time_apply_slab: ") + hipGetErrorString(e));
     tot += a;
     ker += b + c + d;  // (the kernels' own time: with the overlap, more than their share of the step)
+    ovl += d;          // (the part that ran on the SECOND stream, beside the exchange: not to be subtracted from the step when the exchange's
+                       //  share is computed -- get_option "time_kernels_overlapped_us")
   }
+  h->last_overlapped_us = (int64_t)(ovl / nrep * 1e3);
   h->kt_on = 0;
   if (rc) return rc;
   *ms_step = (float)(tot / nrep);

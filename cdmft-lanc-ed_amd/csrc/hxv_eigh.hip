@@ -130,7 +130,8 @@ __global__ void __launch_bounds__(256) tr_scale_nrm(int64_t n, double2* __restri
 }
 
 // deterministic start vector (same hash as the single-vector Lanczos in hxv_lanczos.hip): pad rows stay zero
-__global__ void __launch_bounds__(256) tr_init(int64_t n, double2* __restrict__ q, uint64_t seed, int dimup, int pitch, int col0) {
+__global__ void __launch_bounds__(256) tr_init(int64_t n, double2* __restrict__ q, uint64_t seed, int dimup, int pitch, int col0,
+                                               const int32_t* __restrict__ iperm, const uint8_t* __restrict__ sign) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const int64_t lcol = i / pitch;
     const int row = (int)(i - lcol * pitch);
@@ -139,7 +140,10 @@ __global__ void __launch_bounds__(256) tr_init(int64_t n, double2* __restrict__ 
       q[i] = make_double2(0.0, 0.0);
       continue;
     }
-    const uint64_t z = (uint64_t)(col * dimup + row) * 2 + seed;
+    // (device row order: the vector is defined on the reference index, see lz_init)
+    const int rrow = iperm ? iperm[row] : row;
+    const double sgn = (sign && sign[row]) ? -1.0 : 1.0;
+    const uint64_t z = (uint64_t)(col * dimup + rrow) * 2 + seed;
     double r[2];
     for (int k = 0; k < 2; ++k) {
       uint64_t x = z + (uint64_t)k + 0x9E3779B97F4A7C15ull;
@@ -148,7 +152,7 @@ __global__ void __launch_bounds__(256) tr_init(int64_t n, double2* __restrict__ 
       x = x ^ (x >> 31);
       r[k] = (double)(x >> 11) * (1.0 / 9007199254740992.0) - 0.5;
     }
-    q[i] = make_double2(r[0], r[1]);
+    q[i] = make_double2(sgn * r[0], sgn * r[1]);
   }
 }
 
@@ -633,7 +637,7 @@ int hxv_eigh_lowest(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t maxresta
     if (real)
       launch_init_real(h, (double*)av(0), seed, st);
     else
-      hipLaunchKernelGGL(tr_init, dim3(g), dim3(256), 0, st, n, av(0), seed, h->host.dimup, h->host.pitch, h->host.dw0);
+      hipLaunchKernelGGL(tr_init, dim3(g), dim3(256), 0, st, n, av(0), seed, h->host.dimup, h->host.pitch, h->host.dw0, h->dev.up_iperm, h->dev.up_sign);
     double nrm2 = 0.0;
     if (nlock > 0) {
       for (int pass = 0; pass < 2; ++pass) {  // V[nlock] plays w: project the locked vectors out, twice
@@ -999,13 +1003,10 @@ int hxv_eigh_lowest_host(hxv_handle* h, int32_t neigen, int32_t ncv, int32_t max
   int rc = hxv_eigh_lowest(h, neigen, ncv, maxrestart, tol, evals, d, nconv_out, nmatvec_out);
   if (rc) return rc;
   // eig_basis(vecDim, Neigen) in the reference's layout: columns unpadded, eigenvectors consecutive (ED_DIAG.f90:145)
-  const size_t col = (size_t)h->host.dimup * sizeof(double2), pit = (size_t)h->host.pitch * sizeof(double2);
-  for (int i = 0; i < neigen; ++i)
-    if (h->host.qdw > 0)
-      HIPCHK(hipMemcpy2DAsync((char*)evecs_host + (size_t)i * vecdim * sizeof(double2), col, d + (int64_t)i * n, pit, col,
-                              (size_t)h->host.qdw, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  h->d2h_bytes += (int64_t)neigen * (int64_t)(col * h->host.qdw);
+  for (int i = 0; i < neigen; ++i) {
+    rc = slab_to_host(h, d + (int64_t)i * n, (char*)evecs_host + (size_t)i * vecdim * sizeof(double2));
+    if (rc) return rc;
+  }
   return HXV_OK;
 }
 

@@ -39,6 +39,12 @@ void launch_to_complex(const hxv_handle* h, const double* src, double2* dst, hip
 void launch_init_real(const hxv_handle* h, double* q, uint64_t seed, hipStream_t st);
 // one Lanczos step on normalised vectors through the fused product (hxv_lanczos.hip): w = H q - beta*qm, alpha = <q,w>, w -= alpha*q, |w|
 int comm_lz_homes(hxv_handle* h, bool real, double2* out[3]);
+// this rank's slab between a HOST array in the reference's layout (contiguous columns of DimUp, the reference's row order) and a DEVICE vector
+// (columns padded to pitch, rows in the device row order with the basis signs of SectorHost::up_perm).  Synchronous: returns when the copy is
+// done.  The reference's order on the device: one 2-D copy; a device row order: one contiguous copy + one permuting pass through a buffer from
+// the engine's cache.
+int slab_from_host(hxv_handle* h, const void* v_host, double2* d_vec);
+int slab_to_host(hxv_handle* h, const double2* d_vec, void* v_host);
 int finish_create(hxv_handle* h, int device, hxv_handle** out);  // builds the tile plan, uploads the tables of h->img (hxv_capi.hip); deletes h on failure
 
 // Device tables of a sector travel in ONE allocation and ONE host-to-device copy: a sector has ~50 of them (maps, ELL tables, tile
@@ -160,6 +166,9 @@ struct hxv_handle {
   int kernel = 1;
   // split sector: RCCL communicator over the nranks handles (hxv_comm_init) and the gathered vector
   void* comm = nullptr;          // ncclComm_t
+  void* comm_shared = nullptr;   // hxv_comm.cpp ProcComm: the PROCESS-level communicator `comm` belongs to (one ncclCommInitRank per process and
+                                 // (nranks, rank, device, library), shared by every sector the process opens; ED_VARS_GLOBAL.f90:365-380 sets MpiComm once
+                                 // per solve); null: thread ranks / none
   std::atomic<int> comm_aborted{0};  // hxv_comm_abort has run (from ANOTHER host thread while this rank's own sits in a collective) on `comm` (freed by ncclCommAbort: never destroyed again, never used again)
   void* comm_api = nullptr;      // the RCCL entry points that communicator was created with (hxv_comm.cpp: the system's librccl, or HXV_RCCL_LIB)
   void* lgroup = nullptr;        // thread ranks of one process (hxv_comm_init_local): the group object, see hxv_comm.cpp
@@ -183,6 +192,7 @@ struct hxv_handle {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t kt_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // hxv_time_apply_slab: events around the kernels of a slab product (two regions in exchange mode 2; [4], [5]: pass A on the second stream of its overlapped form)
   int kt_on = 0;
+  int64_t last_overlapped_us = 0;  // last hxv_time_apply_slab: mean time of the kernels that ran on the second stream beside the exchange (overlapped mode 2), microseconds
 
   template <typename T>
   hipError_t alloc(T** p, size_t n) {

@@ -4,7 +4,9 @@
 
 #include <complex>
 #include <cstdint>
+#include <exception>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/hxv.h"
@@ -83,6 +85,55 @@ struct SectorHost {
   // (il,x,y) of state i = c^+_{il,y} c_{il,x}|i>: target index | sign << 31, ND_INVALID if not applicable
   // (dw targets are column SLOTS of the gather layout).  Empty: the kernel falls back to searching the basis.
   std::vector<uint32_t> nd_up, nd_dw;
+
+  // ---- DEVICE ROW ORDER (round 6).  The rows of every device vector -- the up index -- are NOT stored in the reference's order (orbital p
+  // <-> bit p-1, ascending integers, ED_SETUP.f90:720-775) when up_perm is set, but in the order of the up configurations written with orbital
+  // o at bit up_pos[o], ascending.  The orbitals that hop into the HIGH orbitals of pass A's prefix blocks take the highest low bits, so a row
+  // slot's live rows and their sources are long contiguous runs: pass A's out-of-block gathers touch a third fewer cache lines at C3
+  // (scripts/bitorder_sim.py; LABNOTES round 6).  The basis vectors change sign with the order of their creation operators:
+  //     v_dev[up_perm[i]] = (up_sign: -1 : +1) * v_ref[i],      H_dev = S P H P^T S  = H written with the relabelled orbitals.
+  // Everything the reference sees stays in ITS order (map_up, up, a_up, nd_up above: hxv_get_maps / _csr / _diag; host vectors are converted
+  // at the boundary, hxv_capi.hip); the *_dev members below are what is uploaded and tiled.  Empty up_perm = the reference's order.
+  std::vector<int32_t> up_pos;        // [ns] orbital -> bit
+  std::vector<int32_t> up_perm;       // [dimup] reference row -> device row
+  std::vector<int32_t> up_iperm;      // [dimup] device row -> reference row
+  std::vector<uint8_t> up_sign;       // [dimup] by DEVICE row: 1 = that basis state carries a minus sign
+  std::vector<uint32_t> key_up;       // [dimup] the configurations in up_pos numbering, ascending: the prefix blocks of pass A
+  SpinOp up_dev;                      // H_up between device rows
+  std::vector<uint32_t> map_up_dev;   // reference bit strings by device row (diagonal, ladder operators)
+  std::vector<double> a_up_dev;
+  std::vector<uint32_t> nd_up_dev;
+  bool row_order() const { return !up_perm.empty(); }
+  const SpinOp& dev_up() const { return row_order() ? up_dev : up; }
+  const std::vector<uint32_t>& dev_map_up() const { return row_order() ? map_up_dev : map_up; }
+  const std::vector<uint32_t>& dev_key_up() const { return row_order() ? key_up : map_up; }
+  const std::vector<double>& dev_a_up() const { return row_order() ? a_up_dev : a_up; }
+  const std::vector<uint32_t>& dev_nd_up() const { return row_order() ? nd_up_dev : nd_up; }
+};
+
+// A host worker thread whose body cannot take the process down: an exception inside the thread -- bad_alloc from the
+// multi-hundred-MB tables of an Ns=18 sector -- would end in std::terminate, and an exception on the CALLING side while the thread is
+// still joinable would do the same from std::thread's destructor.  run() catches into `err` (the builders' error-string channel),
+// the destructor joins.
+struct GuardedThread {
+  std::thread th;
+  std::string err;
+  template <typename F>
+  void run(F f) {
+    th = std::thread([this, f]() mutable {
+      try {
+        f();
+      } catch (const std::exception& e) {
+        err = std::string("host worker thread: ") + e.what();
+      } catch (...) {
+        err = "host worker thread: unknown exception";
+      }
+    });
+  }
+  void join() {
+    if (th.joinable()) th.join();
+  }
+  ~GuardedThread() { join(); }
 };
 
 // host builders (hxv_sector.cpp); return "" on success, else an error message
@@ -96,6 +147,9 @@ void make_vcol(SectorHost& s);
 std::string make_panel_host(const SectorHost& main, int nrows, SectorHost& panel);  // the row panel of the all-to-all exchange
 // needs s.dw (CSR); replaces the all-gather layout by the halo layout (more_*: further referenced columns per column, CSR-like)
 void make_halo(SectorHost& s, const std::vector<int64_t>* more_ptr = nullptr, const std::vector<int32_t>* more_cols = nullptr);
+int default_lowbits_up(int ns, int npart, int ncoef);  // the block bits the DEFAULT plan gives pass A (hxv_tiled.hip): decides the device row order
+bool row_order_enabled();         // HXV_ROW_ORDER=0 keeps the reference's row order on the device
+std::string row_order_env_key();  // (for the sector-image cache key)
 int default_exchange();            // hxv_set_exchange_default / HXV_EXCHANGE=halo
 void set_default_exchange(int mode);
 std::vector<uint32_t> translate_ell_src(const std::vector<uint32_t>& ell, const std::vector<uint32_t>& vcol);
@@ -131,6 +185,12 @@ struct DevSector {
   const uint32_t* vcol;   // [dimdw] column -> column slot (identity when nranks==1)
   int vcol_identity;
   NonLocalParams nd;
+  // device row order (SectorHost::up_perm): null = the reference's order.  map_up_ref: the reference's sorted up configurations; up_perm:
+  // reference row -> device row; up_iperm: device row -> reference row; up_sign: by device row, 1 = the basis state carries a minus sign
+  const uint32_t* map_up_ref;
+  const int32_t* up_perm;
+  const int32_t* up_iperm;
+  const uint8_t* up_sign;
   const uint32_t* nd_up;  // move tables of the spH0nd block (SectorHost::nd_up / nd_dw), null: search the basis instead
   const uint32_t* nd_dw;
   // spH0nd as STORED by the caller (hxv_set_nonlocal_csr): local rows, global 1-based columns; null: none
@@ -145,7 +205,8 @@ struct TilePlan;  // opaque tiling data for the two-pass kernels
 hipError_t launch_hxv_naive(const DevSector& s, const double2* v_full, double2* hv_local, hipStream_t st);
 hipError_t launch_ladder(const uint32_t* map_from, int dim_from, const uint32_t* map_to, int dim_to, int pitch_from, int dimup_to,
                          int pitch_to, int dimdw_to, int orbital, int spin, int create, const double2* psi, double2* out, hipStream_t st,
-                         double2 coef = double2{1.0, 0.0}, int accumulate = 0);
+                         double2 coef = double2{1.0, 0.0}, int accumulate = 0, const int32_t* perm_from = nullptr, const uint8_t* sign_from = nullptr,
+                         const uint8_t* sign_to = nullptr);
 // d_out[k*pitch + i] = d_in[cols[k]*pitch + i]: the columns a peer needs, packed for the halo exchange
 struct WtRange;
 // hv(row, c) += the dw part handed over in row ranges (exchange mode 2, overlapped form); hv: [ncols][pitch] elements of double2 or double

@@ -255,10 +255,14 @@ hipError_t launch_hxv_nonlocal(const DevSector& s, const double2* v_full, double
 // c / c^dagger on one orbital of one spin, between two sectors (ED_GF_NORMAL.f90:180-199:
 // vvinit(j) = sgn * state_cvec(i)).  One thread per TARGET element: it looks its source up.
 // ---------------------------------------------------------------------------------------
+// Device row order (SectorHost::up_perm; spin up only -- a dw operator leaves the row where it is): map_from is then the SORTED reference
+// map of the source sector and the source row found in it goes through perm_from to its device row; the two basis signs (by device row)
+// multiply the operator's own.  Null pointers = the reference's order.
 __global__ void __launch_bounds__(256) ladder_kernel(const uint32_t* __restrict__ map_from, int dim_from, const uint32_t* __restrict__ map_to,
                                                     int pitch_from, int dimup_to, int pitch_to, int dimdw_to, int orbital, int spin, int create,
                                                     const double2* __restrict__ psi, double2* __restrict__ out, double2 coef,
-                                                    int accumulate) {
+                                                    int accumulate, const int32_t* __restrict__ perm_from, const uint8_t* __restrict__ sign_from,
+                                                    const uint8_t* __restrict__ sign_to) {
   // out = (accumulate ? out : 0) + coef * c^(dagger) psi : the mixed channels of the Green's function start from
   // (c^dagger_i + c^dagger_j)|gs> and (c^dagger_i + xi c^dagger_j)|gs> (ED_GF_NORMAL.f90:370-406, 746-780)
   const int64_t n = (int64_t)dimup_to * dimdw_to;
@@ -270,8 +274,14 @@ __global__ void __launch_bounds__(256) ladder_kernel(const uint32_t* __restrict_
     // the target must have the orbital occupied after a creation / empty after a destruction
     if (((m_to & bit) != 0u) == (create != 0)) {
       const uint32_t m_from = m_to ^ bit;
-      const int j = rank_in_map(map_from, dim_from, m_from);
-      const double sg = par_below(m_from, orbital) ? -1.0 : 1.0;
+      int j = rank_in_map(map_from, dim_from, m_from);
+      int neg = par_below(m_from, orbital);
+      if (spin == 0) {
+        if (perm_from) j = perm_from[j];
+        if (sign_from) neg ^= (int)sign_from[j];
+        if (sign_to) neg ^= (int)sign_to[i];
+      }
+      const double sg = neg ? -1.0 : 1.0;
       const double2 x = spin == 0 ? psi[(int64_t)c * pitch_from + j] : psi[(int64_t)j * pitch_from + i];
       r = make_double2(sg * (coef.x * x.x - coef.y * x.y), sg * (coef.x * x.y + coef.y * x.x));
     }
@@ -286,14 +296,14 @@ __global__ void __launch_bounds__(256) ladder_kernel(const uint32_t* __restrict_
 
 hipError_t launch_ladder(const uint32_t* map_from, int dim_from, const uint32_t* map_to, int dim_to, int pitch_from, int dimup_to,
                          int pitch_to, int dimdw_to, int orbital, int spin, int create, const double2* psi, double2* out, hipStream_t st,
-                         double2 coef, int accumulate) {
+                         double2 coef, int accumulate, const int32_t* perm_from, const uint8_t* sign_from, const uint8_t* sign_to) {
   (void)dim_to;
   const int64_t n = (int64_t)dimup_to * dimdw_to;
   if (n == 0) return hipSuccess;
   int64_t blocks = (n + 255) / 256;
   if (blocks > 256 * 32) blocks = 256 * 32;
   hipLaunchKernelGGL(ladder_kernel, dim3((unsigned)blocks), dim3(256), 0, st, map_from, dim_from, map_to, pitch_from, dimup_to, pitch_to,
-                     dimdw_to, orbital, spin, create, psi, out, coef, accumulate);
+                     dimdw_to, orbital, spin, create, psi, out, coef, accumulate, perm_from, sign_from, sign_to);
   return hipGetLastError();
 }
 

@@ -193,7 +193,10 @@ __global__ void __launch_bounds__(256) lz_axpy(int64_t n, double2* __restrict__ 
 
 // deterministic start vector: splitmix64 hash of the global index -> uniform(-0.5,0.5) re and im
 // (col0 = first global column of this rank's slab: a split sector starts from the same global vector as the unsplit one)
-__global__ void __launch_bounds__(256) lz_init(int64_t n, double2* __restrict__ q, uint64_t seed, int dimup, int pitch, int col0) {
+// (device row order, SectorHost::up_perm: the vector is defined on the REFERENCE index -- device row `row` holds reference row iperm[row],
+//  times its basis sign -- so a sector starts from the same vector whatever order its rows are stored in)
+__global__ void __launch_bounds__(256) lz_init(int64_t n, double2* __restrict__ q, uint64_t seed, int dimup, int pitch, int col0,
+                                               const int32_t* __restrict__ iperm, const uint8_t* __restrict__ sign) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t lcol = i / pitch;
     const int row = (int)(i - lcol * pitch);
@@ -202,7 +205,9 @@ __global__ void __launch_bounds__(256) lz_init(int64_t n, double2* __restrict__ 
       q[i] = make_double2(0.0, 0.0);
       continue;
     }
-    uint64_t z = (uint64_t)(col * dimup + row) * 2 + seed;
+    const int rrow = iperm ? iperm[row] : row;
+    const double sgn = (sign && sign[row]) ? -1.0 : 1.0;
+    uint64_t z = (uint64_t)(col * dimup + rrow) * 2 + seed;
     double r[2];
     for (int k = 0; k < 2; ++k) {
       uint64_t x = z + (uint64_t)k + 0x9E3779B97F4A7C15ull;
@@ -211,7 +216,7 @@ __global__ void __launch_bounds__(256) lz_init(int64_t n, double2* __restrict__ 
       x = x ^ (x >> 31);
       r[k] = (double)(x >> 11) * (1.0 / 9007199254740992.0) - 0.5;
     }
-    q[i] = make_double2(r[0], r[1]);
+    q[i] = make_double2(sgn * r[0], sgn * r[1]);
   }
 }
 
@@ -256,7 +261,8 @@ __global__ void __launch_bounds__(256) lz_to_complex(int dimup, int dimdw, int p
 }
 
 // real start vector: the real part of lz_init's vector
-__global__ void __launch_bounds__(256) lz_init_real(int64_t n, double* __restrict__ q, uint64_t seed, int dimup, int pitch, int col0) {
+__global__ void __launch_bounds__(256) lz_init_real(int64_t n, double* __restrict__ q, uint64_t seed, int dimup, int pitch, int col0,
+                                                    const int32_t* __restrict__ iperm, const uint8_t* __restrict__ sign) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t lcol = i / pitch;
     const int row = (int)(i - lcol * pitch);
@@ -265,11 +271,13 @@ __global__ void __launch_bounds__(256) lz_init_real(int64_t n, double* __restric
       q[i] = 0.0;
       continue;
     }
-    uint64_t x = (uint64_t)(col * dimup + row) * 2 + seed + 0x9E3779B97F4A7C15ull;
+    const int rrow = iperm ? iperm[row] : row;
+    uint64_t x = (uint64_t)(col * dimup + rrow) * 2 + seed + 0x9E3779B97F4A7C15ull;
     x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
     x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
     x = x ^ (x >> 31);
-    q[i] = (double)(x >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+    const double r = (double)(x >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+    q[i] = (sign && sign[row]) ? -r : r;
   }
 }
 
@@ -677,7 +685,7 @@ int lanczos_local_step(hxv_handle* h, bool real, const double2* q, double sq, co
 
 void launch_init_real(const hxv_handle* h, double* q, uint64_t seed, hipStream_t st) {
   const int64_t n = (int64_t)pitch_real_of(h) * h->host.qdw;
-  hipLaunchKernelGGL(lz_init_real, dim3(grid_for(n)), dim3(256), 0, st, n, q, seed, h->host.dimup, pitch_real_of(h), h->host.dw0);
+  hipLaunchKernelGGL(lz_init_real, dim3(grid_for(n)), dim3(256), 0, st, n, q, seed, h->host.dimup, pitch_real_of(h), h->host.dw0, h->dev.up_iperm, h->dev.up_sign);
 }
 }  // namespace hxv
 
@@ -826,7 +834,7 @@ int hxv_lanczos_eigh(hxv_handle* h, int32_t nitermax, double threshold, double* 
     if (real)
       launch_init_real(h, (double*)lz.b.w, seed, h->stream);
     else
-      hipLaunchKernelGGL(lz_init, dim3(g), dim3(256), 0, h->stream, n, lz.b.w, seed, h->host.dimup, h->host.pitch, h->host.dw0);
+      hipLaunchKernelGGL(lz_init, dim3(g), dim3(256), 0, h->stream, n, lz.b.w, seed, h->host.dimup, h->host.pitch, h->host.dw0, h->dev.up_iperm, h->dev.up_sign);
     HIPCHK(hipMemsetAsync(h->d_scalars, 0, 8 * sizeof(double), h->stream));
     hipLaunchKernelGGL(lz_nrm, dim3(g), dim3(256), 0, h->stream, n, lz.b.w, h->d_partials + RED_BLOCKS);
     int rcn = reduce_scalar(h, h->d_partials + RED_BLOCKS, g, 1, 1);
@@ -1076,11 +1084,8 @@ int hxv_lanczos_tridiag_host(hxv_handle* h, const void* vin_host, int32_t nlanc,
   HIPCHK(hipSetDevice(h->device));
   int rc = ensure_stage(h);
   if (rc) return rc;
-  const size_t col = (size_t)h->host.dimup * sizeof(double2), pit = (size_t)h->host.pitch * sizeof(double2);
-  if (h->host.qdw > 0)
-    HIPCHK(hipMemcpy2DAsync(h->d_stage_v, pit, vin_host, col, col, (size_t)h->host.qdw, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  h->h2d_bytes += (int64_t)(col * h->host.qdw);
+  rc = slab_from_host(h, vin_host, h->d_stage_v);
+  if (rc) return rc;
   return hxv_lanczos_tridiag(h, h->d_stage_v, nlanc, alanc, blanc, threshold, nsteps);
 }
 
@@ -1090,13 +1095,10 @@ int hxv_lanczos_tridiag_pair_host(hxv_handle* h, const void* vin_a_host, const v
   HIPCHK(hipSetDevice(h->device));
   int rc = ensure_stage(h);
   if (rc) return rc;
-  const size_t col = (size_t)h->host.dimup * sizeof(double2), pit = (size_t)h->host.pitch * sizeof(double2);
-  if (h->host.qdw > 0) {
-    HIPCHK(hipMemcpy2DAsync(h->d_stage_v, pit, vin_a_host, col, col, (size_t)h->host.qdw, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpy2DAsync(h->d_stage_hv, pit, vin_b_host, col, col, (size_t)h->host.qdw, hipMemcpyHostToDevice, h->stream));
-  }
-  HIPCHK(hipStreamSynchronize(h->stream));
-  h->h2d_bytes += 2 * (int64_t)(col * h->host.qdw);
+  rc = slab_from_host(h, vin_a_host, h->d_stage_v);
+  if (rc) return rc;
+  rc = slab_from_host(h, vin_b_host, h->d_stage_hv);
+  if (rc) return rc;
   return hxv_lanczos_tridiag_pair(h, h->d_stage_v, h->d_stage_hv, nlanc, alanc_a, blanc_a, alanc_b, blanc_b, threshold, nsteps_a, nsteps_b);
 }
 
@@ -1107,13 +1109,7 @@ int hxv_lanczos_eigh_host(hxv_handle* h, int32_t nitermax, double threshold, dou
   if (rc) return rc;
   rc = hxv_lanczos_eigh(h, nitermax, threshold, egs, vect_host ? h->d_stage_hv : nullptr, niter);
   if (rc) return rc;
-  if (vect_host) {
-    const size_t col = (size_t)h->host.dimup * sizeof(double2), pit = (size_t)h->host.pitch * sizeof(double2);
-    if (h->host.qdw > 0)
-      HIPCHK(hipMemcpy2DAsync(vect_host, col, h->d_stage_hv, pit, col, (size_t)h->host.qdw, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    h->d2h_bytes += (int64_t)(col * h->host.qdw);
-  }
+  if (vect_host) return slab_to_host(h, h->d_stage_hv, vect_host);
   return HXV_OK;
 }
 
@@ -1180,11 +1176,17 @@ int hxv_apply_ladder_axpy(hxv_handle* from, hxv_handle* to, int32_t orbital, int
   //    (deterministic, no negotiation), packs, exchanges once, and assembles.
   if (!accumulate) HIPCHK(hipMemsetAsync(d_out, 0, (size_t)b.pitch * std::max(b.qdw, 1) * sizeof(double2), st));  // pad rows = 0
   if (spin == 0 || !split) {
-    const uint32_t* mf = spin == 0 ? from->dev.diag.map_up : from->dev.diag.map_dw;
+    // spin up with a device row order (SectorHost::up_perm): the source row is looked up in the source sector's SORTED reference map and sent
+    // through its permutation; `to`'s map is by device row already; both basis signs ride along.  A dw operator keeps the row, and the two
+    // sectors -- same nup, same model -- have the same row order: nothing to do.
+    const uint32_t* mf = spin == 0 ? (a.row_order() ? from->dev.map_up_ref : from->dev.diag.map_up) : from->dev.diag.map_dw;
     const uint32_t* mt = spin == 0 ? to->dev.diag.map_up : to->dev.diag.map_dw + b.dw0;  // (dw: the local target columns)
     if (spin == 0 && a.qdw != b.qdw) return fail(HXV_ERR_STATE, "hxv_apply_ladder: the DimDw splits of the two sectors differ");
+    if (spin == 1 && (a.row_order() != b.row_order() || (a.row_order() && a.up_pos != b.up_pos)))
+      return fail(HXV_ERR_STATE, "hxv_apply_ladder: the two sectors store their rows in different orders (HXV_ROW_ORDER changed between the opens?)");
     hipError_t e = launch_ladder(mf, spin == 0 ? a.dimup : a.dimdw, mt, spin == 0 ? b.dimup : b.dimdw, a.pitch, b.dimup, b.pitch, b.qdw,
-                                 orbital, spin, create ? 1 : 0, (const double2*)d_psi, (double2*)d_out, st, coef, accumulate ? 1 : 0);
+                                 orbital, spin, create ? 1 : 0, (const double2*)d_psi, (double2*)d_out, st, coef, accumulate ? 1 : 0,
+                                 spin == 0 ? from->dev.up_perm : nullptr, spin == 0 ? from->dev.up_sign : nullptr, spin == 0 ? to->dev.up_sign : nullptr);
     if (e != hipSuccess) return fail(HXV_ERR_HIP, std::string("ladder kernel: ") + hipGetErrorString(e));
   } else {
     const int P = b.nranks, r = b.rank;
@@ -1307,7 +1309,7 @@ int hxv_time_lanczos(hxv_handle* h, void* d_work3, int32_t nrep, float* ms_per_i
   if (real)
     launch_init_real(h, (double*)lz.b.w, 0x1234ull, h->stream);
   else
-    hipLaunchKernelGGL(lz_init, dim3(g), dim3(256), 0, h->stream, n, lz.b.w, 0x1234ull, h->host.dimup, h->host.pitch, 0);
+    hipLaunchKernelGGL(lz_init, dim3(g), dim3(256), 0, h->stream, n, lz.b.w, 0x1234ull, h->host.dimup, h->host.pitch, 0, h->dev.up_iperm, h->dev.up_sign);
   (void)nfull;
   HIPCHK(hipMemsetAsync(h->d_scalars, 0, 8 * sizeof(double), h->stream));
   hipLaunchKernelGGL(lz_nrm, dim3(g), dim3(256), 0, h->stream, n, lz.b.w, h->d_partials + RED_BLOCKS);

@@ -175,7 +175,122 @@ void apply_hops(const std::vector<uint32_t>& map, const std::vector<Hop>& hops_i
   }
 }
 
+// ---- device row order (SectorHost::up_perm) ----------------------------------------------------------------------------------------
+// The orbital -> bit assignment: the high orbitals of pass A's default prefix blocks stay where the reference has them; the LOW orbitals are
+// sorted by the number of hops that tie them to a high orbital, least tied first (stable: ties keep the reference's order).  A low orbital
+// at bit L-1-d hops into a high one from 2^d runs of consecutive rows per block pair (d = 0: one run, a half block), so the tied orbitals
+// want the top low bits.  C3 (2x2 + 3 replicas, L = 12): high = replica 3, tied = the four cluster sites -> bits 8..11, replicas 1, 2 -> 0..7.
+// C4 (BHZ): the reference's numbering is already sorted this way -> no row order.
+std::string make_row_order(SectorHost& s, const std::vector<Hop>& hops_up, int ns) {
+  // (test hooks: HXV_ROW_ORDER_MIN_DIMUP lowers the size below which the reference's order is kept [2048: one block or two, nothing to gain];
+  //  HXV_ROW_ORDER_BITS chooses the order for that many block bits instead of the default plan's -- the suite sets the handle's "tile_bits_up"
+  //  to the same value -- so that small sectors exercise the row order against the oracle)
+  const char* emin = std::getenv("HXV_ROW_ORDER_MIN_DIMUP");
+  const char* ebits = std::getenv("HXV_ROW_ORDER_BITS");
+  if (!row_order_enabled() || s.dimup < (emin ? std::atoi(emin) : 2048) || ns > 24) return "";
+  if (s.nd.active && s.nd_up.empty()) return "";  // (the table-free spH0nd kernel searches the sorted reference basis)
+  std::vector<cplx> amps;
+  for (const Hop& h : hops_up) {
+    const cplx a = (h.t.real() < 0 || (h.t.real() == 0 && h.t.imag() < 0)) ? -h.t : h.t;
+    if (std::find(amps.begin(), amps.end(), a) == amps.end()) amps.push_back(a);
+  }
+  const int L = ebits ? std::atoi(ebits) : default_lowbits_up(ns, s.nup, (int)amps.size());
+  if (L <= 0 || L >= ns) return "";  // one block: nothing leaves it
+  std::vector<int> deg(ns, 0);
+  for (const Hop& h : hops_up) {
+    if (h.a >= L && h.b < L) deg[h.b]++;
+    if (h.b >= L && h.a < L) deg[h.a]++;
+  }
+  std::vector<int> low(L);
+  for (int o = 0; o < L; ++o) low[o] = o;
+  std::stable_sort(low.begin(), low.end(), [&](int x, int y) { return deg[x] < deg[y]; });
+  std::vector<int32_t> pos(ns);
+  bool ident = true;
+  for (int b = 0; b < L; ++b) {
+    pos[low[b]] = b;
+    ident = ident && low[b] == b;
+  }
+  for (int o = L; o < ns; ++o) pos[o] = o;
+  if (ident) return "";
+  const int dim = s.dimup;
+  // device configurations: relabel every reference configuration, sort
+  std::vector<uint32_t> key_of(dim);
+  for (int i = 0; i < dim; ++i) {
+    uint32_t m = s.map_up[i], x = 0;
+    while (m) {
+      const int o = __builtin_ctz(m);
+      m &= m - 1;
+      x |= 1u << pos[o];
+    }
+    key_of[i] = x;
+  }
+  std::vector<int32_t> iperm(dim);
+  for (int i = 0; i < dim; ++i) iperm[i] = i;
+  std::sort(iperm.begin(), iperm.end(), [&](int32_t a, int32_t b) { return key_of[a] < key_of[b]; });
+  s.up_pos = pos;
+  s.up_iperm = iperm;
+  s.up_perm.assign(dim, 0);
+  s.key_up.resize(dim);
+  s.map_up_dev.resize(dim);
+  s.a_up_dev.resize(dim);
+  s.up_sign.assign(dim, 0);
+  // sign of a basis state: parity of the pairs of occupied orbitals whose order the relabelling reverses
+  std::vector<std::pair<int, int>> inv;
+  for (int a = 0; a < ns; ++a)
+    for (int b = a + 1; b < ns; ++b)
+      if (pos[a] > pos[b]) inv.push_back({a, b});
+  for (int d = 0; d < dim; ++d) {
+    const int i = iperm[d];
+    s.up_perm[i] = d;
+    s.key_up[d] = key_of[i];
+    s.map_up_dev[d] = s.map_up[i];
+    s.a_up_dev[d] = s.a_up[i];
+    const uint32_t m = s.map_up[i];
+    int par = 0;
+    for (const auto& pr : inv) par ^= (int)((m >> pr.first) & (m >> pr.second) & 1u);
+    s.up_sign[d] = (uint8_t)par;
+  }
+  // H_up between device rows = H written with the relabelled orbitals on the sorted device configurations
+  std::vector<Hop> hd(hops_up);
+  for (Hop& h : hd) {
+    h.a = pos[h.a];
+    h.b = pos[h.b];
+  }
+  apply_hops(s.key_up, hd, ns, s.up_dev);
+  std::string e = build_ell(s.up_dev);
+  if (!e.empty()) return "H_up in device row order: " + e;
+  // the spH0nd move tables: rows and targets relabelled, signs carried over
+  if (!s.nd_up.empty()) {
+    const size_t nq = s.nd_up.size() / (size_t)dim;
+    s.nd_up_dev.assign(s.nd_up.size(), ND_INVALID);
+    for (size_t q = 0; q < nq; ++q)
+      for (int i = 0; i < dim; ++i) {
+        const uint32_t w = s.nd_up[q * dim + i];
+        if (w == ND_INVALID) continue;
+        const int j = (int)(w & 0x7FFFFFFFu), di = s.up_perm[i], dj = s.up_perm[j];
+        const uint32_t sg = (w >> 31) ^ s.up_sign[di] ^ s.up_sign[dj];
+        s.nd_up_dev[q * dim + di] = (uint32_t)dj | (sg << 31);
+      }
+  }
+  return "";
+}
+
 }  // namespace
+
+bool row_order_enabled() {
+  const char* e = std::getenv("HXV_ROW_ORDER");
+  return !(e && e[0] == '0');
+}
+// what the sector-image cache must know of the environment: an image holds the tables of ONE device row order
+std::string row_order_env_key() {
+  std::string k = row_order_enabled() ? "R1" : "R0";
+  for (const char* n : {"HXV_ROW_ORDER_MIN_DIMUP", "HXV_ROW_ORDER_BITS"}) {
+    const char* v = std::getenv(n);
+    k += "|";
+    if (v) k += v;
+  }
+  return k;
+}
 
 void dw_split(int dimdw, int rank, int nranks, int& qdw, int& dw0) {
   // ED_HAMILTONIAN.f90:93-105
@@ -368,28 +483,6 @@ std::string build_sector_from_model(const hxv_model& m, int nup, int ndw, int ra
   if (!e.empty()) return e;
   e = one_body(mv, m.nspin - 1, hops_dw, eps_dw);            // spin index Nspin   (H_dw.f90:14)
   if (!e.empty()) return e;
-  {
-    // TIMING EXPERIMENT (HXV_EXPERIMENTS=1 only; results are those of a relabelled model): orbital -> bit assignment of one spin's
-    // hops, "HXV_EXP_UP_ORDER=p0,p1,..." = bit of orbital 0, 1, ...  (scripts/bitorder_ab.py; LABNOTES round 6)
-    auto relabel = [&](const char* name, std::vector<Hop>& hops) {
-      const char* x = std::getenv("HXV_EXPERIMENTS");
-      const char* v = std::getenv(name);
-      if (!x || std::string(x) != "1" || !v) return;
-      std::vector<int> pos;
-      for (const char* p = v; *p;) {
-        pos.push_back(std::atoi(p));
-        while (*p && *p != ',') ++p;
-        if (*p == ',') ++p;
-      }
-      if ((int)pos.size() != ns) return;
-      for (Hop& h : hops) {
-        h.a = pos[h.a];
-        h.b = pos[h.b];
-      }
-    };
-    relabel("HXV_EXP_UP_ORDER", hops_up);
-    relabel("HXV_EXP_DW_ORDER", hops_dw);
-  }
   if (panel_rows > 0) {
     // dw-only row panel [panel_rows x DimDw] of the vector (all-to-all exchange): the up index is just a row
     // count here -- no basis, no H_up, no diagonal
@@ -414,10 +507,16 @@ std::string build_sector_from_model(const hxv_model& m, int nup, int ndw, int ra
       return true;
     };
     const bool twin = panel_rows == 0 && nup == ndw && same_hops();
-    std::thread th;
-    if (panel_rows == 0 && !twin) th = std::thread([&] { apply_hops(s.map_up, hops_up, ns, s.up); });
-    apply_hops(s.map_dw, hops_dw, ns, s.dw);
-    if (th.joinable()) th.join();
+    GuardedThread th;   // (joins on every path; its exceptions come back as an error string)
+    if (panel_rows == 0 && !twin) th.run([&] { apply_hops(s.map_up, hops_up, ns, s.up); });
+    try {
+      apply_hops(s.map_dw, hops_dw, ns, s.dw);
+    } catch (const std::exception& ex) {
+      th.join();
+      return std::string("building H_dw: ") + ex.what();
+    }
+    th.join();
+    if (!th.err.empty()) return "building H_up: " + th.err;
     twin_spins = twin;
   }
   // (the spH0nd block reaches columns that H_dw does not: it keeps the all-gather layout)
@@ -449,10 +548,15 @@ std::string build_sector_from_model(const hxv_model& m, int nup, int ndw, int ra
   if (nranks > 1 && nranks <= s.dimup && panel_rows == 0 && default_exchange() == 2 && !(m.norb > 1 && (m.jx != 0.0 || m.jp != 0.0))) s.exchange = 2;
   {
     std::string e_up;
-    std::thread th;
-    if (!twin_spins) th = std::thread([&] { e_up = build_ell(s.up); });
-    e = build_ell(s.dw);
-    if (th.joinable()) th.join();
+    GuardedThread th;
+    if (!twin_spins) th.run([&] { e_up = build_ell(s.up); });
+    try {
+      e = build_ell(s.dw);
+    } catch (const std::exception& ex) {
+      e = std::string("building the H_dw tables: ") + ex.what();
+    }
+    th.join();
+    if (!th.err.empty()) return "building the H_up tables: " + th.err;
     if (!e_up.empty()) return e_up;
     if (!e.empty()) return e;
     if (twin_spins) s.up = s.dw;
@@ -533,6 +637,10 @@ std::string build_sector_from_model(const hxv_model& m, int nup, int ndw, int ra
   }
   for (int il = 0; il < L; ++il)
     for (int io = 0; io < O; ++io) s.cross.sitemask[il] |= 1u << mv.imp(il, io);
+  if (panel_rows == 0) {
+    e = make_row_order(s, hops_up, ns);
+    if (!e.empty()) return e;
+  }
   return "";
 }
 

@@ -1164,6 +1164,14 @@ std::vector<double2> signed_coefs(const SpinOp& op) {
 
 }  // namespace
 
+// the block bits pass A gets from the DEFAULT options (what make_tile_plan's `build` computes for the up spin): the device row order of a
+// sector is chosen for them once, when the sector is built, and does not follow later option changes (device vectors outlive those)
+int default_lowbits_up(int ns, int npart, int ncoef) {
+  const TileOptions o;
+  const int budget = o.lds_budget_kb_up * 1024 - 16 * (2 * ncoef + 1);
+  return o.force_bits_up >= 0 ? std::min(o.force_bits_up, ns) : choose_lowbits(ns, npart, o.cols_per_tile, budget, o.threads_up);
+}
+
 std::string make_tile_plan(const SectorHost& s, TilePlan& plan, const PlanUploader& up) {
   TileOptions& o = plan.opt;
   if (o.cols_per_tile != 2 && o.cols_per_tile != 4 && o.cols_per_tile != 8) return "cols_per_tile must be 2, 4 or 8";
@@ -1181,7 +1189,7 @@ std::string make_tile_plan(const SectorHost& s, TilePlan& plan, const PlanUpload
   if (o.job_cols != 1 && o.job_cols != 2) return "job_cols must be 1 or 2";
   if (o.job_groups < 1 || o.job_groups > 65536) return "job_groups must be in [1,65536]";
   if (o.job_stages < 2 || o.job_stages > 8) return "job_stages must be in [2,8]";
-  plan.ncoef_up = (int)s.up.coef.size();
+  plan.ncoef_up = (int)s.dev_up().coef.size();
   plan.ncoef_dw = (int)s.dw.coef.size();
   plan.usable = plan.ncoef_up <= TILE_MAX_COEF && plan.ncoef_dw <= TILE_MAX_COEF;
   if (!plan.usable) return "";
@@ -1213,21 +1221,27 @@ std::string make_tile_plan(const SectorHost& s, TilePlan& plan, const PlanUpload
   };
   static const std::vector<uint32_t> no_map;  // panel handles have no up basis: plain index chunks (pass A never runs)
   std::string e_up, e;
-  std::thread th([&] {
-    e_up = build(s.up, s.panel_rows > 0 ? no_map : s.map_up, s.nup, o.cols_per_tile, o.force_bits_up, o.lds_budget_kb_up, o.threads_up, nullptr, true, 0,
+  GuardedThread th;   // (an exception on either side comes back as an error string; the thread is joined on every path -- ADVICE r5)
+  th.run([&] {
+    e_up = build(s.dev_up(), s.panel_rows > 0 ? no_map : s.dev_key_up(), s.nup, o.cols_per_tile, o.force_bits_up, o.lds_budget_kb_up, o.threads_up, nullptr, true, 0,
                  plan.up, hu);
   });
   // pass B sorts by the inner count only: its outer table is read in natural column order
-  e = build(s.dw, s.map_dw, s.ndw, o.rows_per_tile, o.force_bits_dw, o.lds_budget_kb_dw, o.threads_dw, &s.vcol, false, o.sort_mode_dw ? 1 : 0, plan.dw,
-            hd);
+  try {
+    e = build(s.dw, s.map_dw, s.ndw, o.rows_per_tile, o.force_bits_dw, o.lds_budget_kb_dw, o.threads_dw, &s.vcol, false, o.sort_mode_dw ? 1 : 0, plan.dw,
+              hd);
+  } catch (const std::exception& ex) {
+    e = std::string("tile plan of H_dw: ") + ex.what();
+  }
   th.join();
+  if (!th.err.empty()) return "tile plan of H_up: " + th.err;
   if (!e_up.empty()) return e_up;
   if (!e.empty()) return e;
   e = send(hu, plan.up);
   if (!e.empty()) return e;
   e = send(hd, plan.dw);
   if (!e.empty()) return e;
-  if (up.d2(signed_coefs(s.up), &plan.d_scoef_up) != hipSuccess || up.d2(signed_coefs(s.dw), &plan.d_scoef_dw) != hipSuccess)
+  if (up.d2(signed_coefs(s.dev_up()), &plan.d_scoef_up) != hipSuccess || up.d2(signed_coefs(s.dw), &plan.d_scoef_dw) != hipSuccess)
     return "upload of coefficient tables failed";
   return "";
 }

@@ -41,13 +41,13 @@ class _Stats(C.Structure):
 # every symbol include/hxv.h declares (tests check that the library exports all of them)
 EXPORTS = [
     "hxv_create_from_model", "hxv_create_from_csr", "hxv_set_nonlocal_csr", "hxv_slab_home", "hxv_create_dw_panel", "hxv_apply_dw_panel", "hxv_apply_up_add", "hxv_destroy", "hxv_vecdim", "hxv_dims", "hxv_apply_host",
-    "hxv_apply_device", "hxv_apply_device_real", "hxv_real_vectors_available", "hxv_pitch_real", "hxv_realvec_elems", "hxv_fullvec_elems", "hxv_localvec_elems", "hxv_pitch", "hxv_time_apply", "hxv_lanczos_tridiag", "hxv_lanczos_eigh", "hxv_lanczos_tridiag_host", "hxv_lanczos_eigh_host", "hxv_lanczos_tridiag_pair", "hxv_lanczos_tridiag_pair_host", "hxv_eigh_lowest", "hxv_eigh_lowest_host", "hxv_time_lanczos", "hxv_apply_ladder", "hxv_apply_ladder_axpy", "hxv_live_handles", "hxv_get_maps",
+    "hxv_apply_device", "hxv_apply_device_real", "hxv_real_vectors_available", "hxv_pitch_real", "hxv_realvec_elems", "hxv_fullvec_elems", "hxv_localvec_elems", "hxv_pitch", "hxv_time_apply", "hxv_lanczos_tridiag", "hxv_lanczos_eigh", "hxv_lanczos_tridiag_host", "hxv_lanczos_eigh_host", "hxv_lanczos_tridiag_pair", "hxv_lanczos_tridiag_pair_host", "hxv_eigh_lowest", "hxv_eigh_lowest_host", "hxv_time_lanczos", "hxv_apply_ladder", "hxv_apply_ladder_axpy", "hxv_live_handles", "hxv_row_order", "hxv_get_maps",
     "hxv_nnz", "hxv_get_csr", "hxv_get_diag", "hxv_set_option", "hxv_get_option", "hxv_get_stats", "hxv_pool_trim", "hxv_pool_stats", "hxv_last_error",
     "hxv_version", "hxv_comm_unique_id", "hxv_comm_init", "hxv_comm_free", "hxv_apply_device_slab", "hxv_exchange_count",
     "hxv_set_exchange_default", "hxv_exchange_mode", "hxv_halo_counts", "hxv_halo_lists", "hxv_halo_plan_from_csr",
     "hxv_comm_local_create", "hxv_comm_init_local", "hxv_comm_local_destroy", "hxv_comm_local_abort", "hxv_time_apply_slab",
     "hxv_vector_alloc", "hxv_vector_alloc_many", "hxv_vector_free", "hxv_vector_from_host", "hxv_vector_to_host",
-    "hxv_sector_cache_clear", "hxv_sector_cache_stats", "hxv_comm_abort", "hxv_comm_library",
+    "hxv_sector_cache_clear", "hxv_sector_cache_stats", "hxv_comm_abort", "hxv_comm_library", "hxv_comm_cache_stats", "hxv_comm_cache_clear", "hxv_host_register", "hxv_host_unregister",
 ]
 
 _lib = None
@@ -144,6 +144,14 @@ def load_library():
     L.hxv_comm_library.restype = C.c_char_p
     L.hxv_sector_cache_clear.argtypes = []
     L.hxv_sector_cache_stats.argtypes = [pi64, pi64, pi64, pi64]
+    L.hxv_comm_cache_stats.argtypes = [pi64, pi64, pi64]
+    L.hxv_comm_cache_clear.argtypes = [pi64]
+    L.hxv_row_order.argtypes = [vp, pi32, C.POINTER(C.c_int8)]
+    L.hxv_row_order.restype = i32
+    L.hxv_host_register.argtypes = [vp, i64]
+    L.hxv_host_unregister.argtypes = [vp]
+    L.hxv_live_handles.argtypes = []
+    L.hxv_live_handles.restype = i64
     _lib = L
     return L
 
@@ -175,6 +183,33 @@ def sector_cache_stats() -> dict:
     e, b, h, m = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
     load_library().hxv_sector_cache_stats(C.byref(e), C.byref(b), C.byref(h), C.byref(m))
     return {"entries": e.value, "bytes": b.value, "hits": h.value, "misses": m.value}
+
+
+def comm_cache_stats() -> dict:
+    """The process-level RCCL communicators (include/hxv.h: one ncclCommInitRank per (library, nranks, rank, device), shared by every sector)."""
+    e, i, r = C.c_int64(), C.c_int64(), C.c_int64()
+    load_library().hxv_comm_cache_stats(C.byref(e), C.byref(i), C.byref(r))
+    return {"entries": e.value, "inits": i.value, "reuses": r.value}
+
+
+def comm_cache_clear() -> int:
+    """ncclCommDestroy of the cached communicators no sector is bound to (every rank, at the same point of the program); returns how many."""
+    n = C.c_int64()
+    load_library().hxv_comm_cache_clear(C.byref(n))
+    return n.value
+
+
+def host_register(a: np.ndarray):
+    """Page-lock a numpy array that is passed to apply_host / the *_host drivers again and again (include/hxv.h: hxv_host_register)."""
+    _chk(load_library().hxv_host_register(a.ctypes.data, a.nbytes), "hxv_host_register")
+
+
+def host_unregister(a: np.ndarray):
+    _chk(load_library().hxv_host_unregister(a.ctypes.data), "hxv_host_unregister")
+
+
+def live_handles() -> int:
+    return load_library().hxv_live_handles()
 
 
 def halo_plan_from_csr(dimdw: int, rowptr, cols, rank: int, nranks: int):
@@ -242,10 +277,14 @@ class RcclGroup:
         """A rank's thread failed outside the library: ncclCommAbort on every communicator that has joined (hxv_comm_abort), so peers
         blocked in a collective return an error.  (A rank lost BEFORE ncclCommInitRank completed cannot be helped: no communicator yet.)"""
         with self._lock:
+            self._joined = [s for s in self._joined if getattr(s, "_h", None)]   # (closed sectors leave the list)
             secs = list(self._joined)
         for s in secs:
-            if getattr(s, "_h", None):
-                load_library().hxv_comm_abort(s._h)
+            # serialised against close() of the same sector (ADVICE r5): hxv_comm_abort must not run while -- or after -- hxv_destroy frees
+            # the handle on the peer's thread; a peer blocked in a collective does not hold the lock, so the abort that wakes it never waits
+            with s._life:
+                if getattr(s, "_h", None):
+                    load_library().hxv_comm_abort(s._h)
 
     def close(self):
         pass
@@ -302,8 +341,11 @@ class HxvSector:
     build_Hv_sector leaves in ED_HAMILTONIAN_COMMON.f90:11-20 + spH0d/spH0ups/spH0dws."""
 
     def __init__(self, handle, keep=None, device_index: int = 0):
+        import threading
+
         self._h = handle
         self._keep = keep
+        self._life = threading.Lock()   # close() against RcclGroup.abort() from another rank's thread
         L = load_library()
         du, dd, q = C.c_int32(), C.c_int32(), C.c_int32()
         dim, ish = C.c_int64(), C.c_int64()
@@ -316,6 +358,23 @@ class HxvSector:
         self.localElems = L.hxv_localvec_elems(self._h)  # length of the (padded) local result / of a Lanczos vector
         self.ncolsFull = self.fullElems // self.pitch
         self.device_index = int(device_index)
+        # device row order (include/hxv.h, DEVICE ROW ORDER): d_vec[k*pitch + perm[iup]] = sign[iup] * v_ref[k*DimUp + iup]; None = the reference's
+        self.row_perm = self.row_sign = None
+        self._row_dev = {}
+        if L.hxv_row_order(self._h, None, None) == 1:
+            perm = np.zeros(self.DimUp, dtype=np.int32)
+            sign = np.zeros(self.DimUp, dtype=np.int8)
+            L.hxv_row_order(self._h, _p(perm, C.c_int32), _p(sign, C.c_int8))
+            self.row_perm, self.row_sign = perm, sign
+
+    def _row_tables(self, device, dtype):
+        """(perm as an index tensor, sign as a tensor of `dtype`) on `device`, cached."""
+        import torch
+
+        key = (str(device), dtype)
+        if key not in self._row_dev:
+            self._row_dev[key] = (torch.from_numpy(self.row_perm.astype(np.int64)).to(device), torch.from_numpy(self.row_sign.astype(np.float64)).to(device=device, dtype=dtype))
+        return self._row_dev[key]
 
     # -- constructors ---------------------------------------------------------------------
     @staticmethod
@@ -416,9 +475,13 @@ class HxvSector:
         return torch.device("cuda", self.device_index)
 
     def close(self):
-        if getattr(self, "_h", None):
-            load_library().hxv_destroy(self._h)
-            self._h = None
+        life = getattr(self, "_life", None)
+        if life is None:
+            return
+        with life:
+            if getattr(self, "_h", None):
+                load_library().hxv_destroy(self._h)
+                self._h = None
 
     def __del__(self):
         try:
@@ -441,6 +504,13 @@ class HxvSector:
         """contiguous [ncols x DimUp] torch vector -> padded device layout [ncols x pitch] (pads zero)."""
         import torch
 
+        if self.row_perm is not None:
+            # device row order: reference row i of every column goes to device row perm[i], with the sign of its basis vector
+            ncols = x.numel() // self.DimUp if ncols is None else ncols
+            perm, sign = self._row_tables(x.device, x.dtype)
+            out = torch.zeros(ncols, self.pitch, dtype=x.dtype, device=x.device)
+            out[:, perm] = x.view(ncols, self.DimUp) * sign
+            return out.view(-1)
         if self.pitch == self.DimUp:
             return x
         ncols = x.numel() // self.DimUp if ncols is None else ncols
@@ -449,6 +519,10 @@ class HxvSector:
         return out
 
     def unpad(self, x):
+        """padded device layout -> contiguous vector in the reference's order (the inverse of pad)."""
+        if self.row_perm is not None:
+            perm, sign = self._row_tables(x.device, x.dtype)
+            return (x.view(-1, self.pitch)[:, perm] * sign).contiguous().view(-1)
         if self.pitch == self.DimUp:
             return x
         return x.view(-1, self.pitch)[:, : self.DimUp].contiguous().view(-1)
@@ -573,11 +647,20 @@ class HxvSector:
 
         pr = load_library().hxv_pitch_real(self._h)
         out = torch.zeros(self.DimDw, pr, dtype=torch.float64, device=x.device)
-        out[:, : self.DimUp] = x.view(self.DimDw, self.DimUp)
+        if self.row_perm is not None:
+            perm, sign = self._row_tables(x.device, torch.float64)
+            out[:, perm] = x.view(self.DimDw, self.DimUp) * sign
+        else:
+            out[:, : self.DimUp] = x.view(self.DimDw, self.DimUp)
         return out.view(-1)
 
     def unpad_real(self, x):
+        import torch
+
         pr = load_library().hxv_pitch_real(self._h)
+        if self.row_perm is not None:
+            perm, sign = self._row_tables(x.device, torch.float64)
+            return (x.view(self.DimDw, pr)[:, perm] * sign).reshape(-1)
         return x.view(self.DimDw, pr)[:, : self.DimUp].reshape(-1)
 
     def apply_device_real(self, v, hv=None, stream=None):
@@ -604,7 +687,10 @@ class HxvSector:
         V = v.reshape(self.DimDw, self.DimUp)
         for r in range(nranks):
             q, c0 = dw_split(self.DimDw, r, nranks)
-            out[r * cmax: r * cmax + q, : self.DimUp] = V[c0: c0 + q]
+            if self.row_perm is not None:
+                out[r * cmax: r * cmax + q][:, self.row_perm] = V[c0: c0 + q] * self.row_sign
+            else:
+                out[r * cmax: r * cmax + q, : self.DimUp] = V[c0: c0 + q]
         return out.reshape(-1)
 
     def time_apply(self, v_full, hv_local, nrep: int) -> float:
@@ -757,6 +843,27 @@ class HxvSector:
         ms = C.c_float()
         _chk(load_library().hxv_time_lanczos(self._h, work.data_ptr(), nrep, C.byref(ms)), "hxv_time_lanczos")
         return ms.value
+
+    # -- host <-> device copies of a local vector (include/hxv.h: hxv_vector_from_host / _to_host; the device buffer is a torch tensor here)
+    def vector_from_host(self, v: np.ndarray):
+        """this rank's slab in the reference's host layout -> a device vector in the padded device layout (device row order included)."""
+        import torch
+
+        v = np.ascontiguousarray(v, dtype=np.complex128)
+        assert v.size == self.vecDim
+        d = torch.zeros(self.localElems, dtype=torch.complex128, device=self._dev())
+        torch.cuda.synchronize()
+        _chk(load_library().hxv_vector_from_host(self._h, v.ctypes.data, d.data_ptr()), "hxv_vector_from_host")
+        return d
+
+    def vector_to_host(self, d) -> np.ndarray:
+        import torch
+
+        assert d.is_cuda and d.dtype == torch.complex128 and d.numel() == self.localElems
+        out = np.empty(self.vecDim, dtype=np.complex128)
+        torch.cuda.synchronize()
+        _chk(load_library().hxv_vector_to_host(self._h, d.data_ptr(), out.ctypes.data), "hxv_vector_to_host")
+        return out
 
     # -- introspection ---------------------------------------------------------------------
     def maps(self):

@@ -91,18 +91,37 @@ int hxv_dims(const hxv_handle *h, int32_t *dimup, int32_t *dimdw, int64_t *dim, 
  * ncclAllGather of the slabs over xGMI -- once the handles share a communicator (hxv_comm_init below).
  * Pays two PCIe copies of the slab per call.                                                            */
 int hxv_apply_host(hxv_handle *h, int64_t nloc, const void *v, void *hv);
+/* The two PCIe copies ARE this call's cost (C3: 2 x 2.65 GB; the kernels between them take 4 ms): bench.py reports it as config.apply_host next
+ * to the floor the box's own H2D / D2H rates give.  Host arrays that are page-locked move by DMA at the link's rate; a host program that keeps
+ * passing the same work arrays (ED_DIAG's Lanczos vectors) registers them ONCE (hipHostRegister, ~0.1 s per GB) and unregisters them before it
+ * frees them.  Registering an array that is registered already is not an error.                                                          */
+int hxv_host_register(void *ptr, int64_t bytes);
+int hxv_host_unregister(void *ptr);
 
 /* ---- slab exchange of a split sector (MpiStatus=T side of the boundary) -------------------------------------------
  * One RCCL communicator over the nranks handles of a sector (one process per GPU).  Rank 0 draws an id, the host program
  * broadcasts its HXV_COMM_ID_BYTES bytes by its own means (the reference: MPI_Bcast over MpiComm), every rank calls
  * hxv_comm_init (collective).  Afterwards hxv_apply_host, hxv_apply_device_slab and the device Lanczos drivers work on
  * split sectors: the product all-gathers the slabs (equal counts, all-gather layout of hxv_apply_device) on the stream it
- * runs on, the drivers' dot products are ncclAllReduce sums.  hxv_destroy releases the communicator.
+ * runs on, the drivers' dot products are ncclAllReduce sums.  hxv_destroy unbinds the handle from the communicator (below).
  * RCCL is loaded at the first of these calls (dlopen), not at link time.                                            */
 #define HXV_COMM_ID_BYTES 128
 int hxv_comm_unique_id(void *id128);
 int hxv_comm_init(hxv_handle *h, const void *id128);
 int hxv_comm_free(hxv_handle *h);
+/* ONE communicator per process, not per sector.  The reference sets MpiComm once per solve (ED_VARS_GLOBAL.f90:365-380) and derives a
+ * sub-communicator only for sectors with DimDw < MpiSize (ED_HAMILTONIAN.f90:63-89), while its callers open 289 sectors per ED_DIAG sweep
+ * (ED_DIAG.f90:142-190) and 56 per Green's-function stage (ED_GF_NORMAL.f90:208-222).  hxv_comm_init therefore builds a communicator
+ * (ncclCommInitRank, a collective that costs far more than opening a sector) only the FIRST time it sees a (RCCL library, nranks, rank, device);
+ * every later call with the same key binds the handle to that communicator and does not consume the id it is given (the host may keep
+ * drawing and broadcasting ids -- 128 bytes -- or pass the first one again; every rank takes the same branch because every rank has made the
+ * same calls).  A sector with DimDw < nranks is opened by the first DimDw ranks with nranks' = DimDw: another key, built once as well.
+ * hxv_destroy / hxv_comm_free unbind; the communicators live until hxv_comm_cache_clear (every rank, at the same point of the program: the
+ * end of a solve) or the end of the process.  A communicator that was aborted (hxv_comm_abort) or failed a collective leaves the cache: the
+ * next hxv_comm_init builds a new one from its id.  Environment HXV_COMM_CACHE=0: one communicator per handle, destroyed with it.
+ * hxv_comm_cache_stats: communicators cached now, ncclCommInitRank calls made so far, hxv_comm_init calls served without one (any out NULL). */
+int hxv_comm_cache_stats(int64_t *entries, int64_t *inits, int64_t *reuses);
+int hxv_comm_cache_clear(int64_t *destroyed);
 /* A rank has failed OUTSIDE the library (its host thread / process raised before its next collective): wake this handle's rank instead of
  * leaving it inside a collective waiting for the lost peer.  RCCL communicators: ncclCommAbort -- callable from another host thread while
  * the handle's own thread blocks in a collective; that collective returns an error, the communicator is gone (later calls report a missing
@@ -138,7 +157,9 @@ int hxv_comm_local_destroy(void *group);
 int hxv_apply_device_slab(hxv_handle *h, const void *d_v_local, void *d_hv_local, void *stream);
 /* Measurement: nrep such products on the handle's own stream, timed with HIP events (collective on a split sector: every rank calls
  * it with the same nrep).  *ms_step = mean time of a whole product on this rank (exchange included), *ms_kernels = mean time of its
- * product kernels alone (both kernel regions in exchange mode 2).                                                              */
+ * product kernels alone (both kernel regions in exchange mode 2; with option "exchange_overlap" also pass A's region on the second stream,
+ * which runs BESIDE the exchange: hxv_get_option(h, "time_kernels_overlapped_us") tells that part, so the exchange's own share of a step is
+ * *ms_step - (*ms_kernels - overlapped), never negative).                                                                        */
 int hxv_time_apply_slab(hxv_handle *h, const void *d_v_local, void *d_hv_local, int32_t nrep, float *ms_step, float *ms_kernels);
 /* Where the exchange wants this rank's slab (its slot of the gather buffer): a caller that builds its vector there and hands
  * THAT pointer to hxv_apply_device_slab saves the slab copy of every product.  [qdw columns][pitch] complex elements; allocated on
@@ -191,7 +212,21 @@ int hxv_apply_device(hxv_handle *h, const void *d_v_full, void *d_hv_local, void
  * the product; the Lanczos entries require them to be ZERO in the vectors they are given (dot products
  * run over the padded arrays).  hxv_apply_host converts from/to the reference's contiguous host layout.
  *   hxv_fullvec_elems : length of d_v_full  = nranks*cmax*pitch  (all-gather layout above)
- *   hxv_localvec_elems: length of d_hv_local and of every Lanczos vector = qdw*pitch             */
+ *   hxv_localvec_elems: length of d_hv_local and of every Lanczos vector = qdw*pitch
+ * DEVICE ROW ORDER (round 6).  WITHIN a column the rows of a device vector need not follow the reference's basis order: a sector opened from a
+ * model may store the up configurations in the order they take when the orbitals are renumbered (orbital o at bit pos[o]) so that the
+ * out-of-block gathers of the product's up-hop pass run over long contiguous stretches (C3: a third fewer cache lines).
+ * Reordering creation operators changes the sign of a basis vector, hence
+ *        d_vec[k*pitch + perm[iup]] = sign[iup] * v_ref[k*DimUp + iup]              (perm, sign: hxv_row_order)
+ * Every entry point that takes or returns HOST arrays (hxv_apply_host, the *_host drivers, hxv_vector_from_host / _to_host, evecs_host) and
+ * every introspection call (hxv_get_maps / _csr / _diag) speaks the reference's order: the conversion happens at the boundary, on the device.
+ * Device vectors are self-consistent among the device entry points (product, Lanczos drivers, ladder operators between sectors); a caller
+ * that BUILDS or READS a device vector element by element uses hxv_row_order.  Columns (the dw index, the one that is split over ranks)
+ * always keep the reference's order.  hxv_row_order returns 1 when the sector has a device row order (perm[DimUp]: reference row -> device
+ * row; sign[DimUp]: +1 / -1 by reference row; either may be NULL), 0 when rows are in the reference's order (identity written), -1 on a NULL
+ * handle.  Sectors opened from stored matrices, row panels and small sectors (DimUp < 2048) keep the reference's order; environment
+ * HXV_ROW_ORDER=0 keeps it everywhere.                                                                                                 */
+int32_t hxv_row_order(const hxv_handle *h, int32_t *perm, int8_t *sign);
 int64_t hxv_fullvec_elems(const hxv_handle *h);
 int64_t hxv_localvec_elems(const hxv_handle *h);
 int32_t hxv_pitch(const hxv_handle *h);

@@ -183,8 +183,15 @@ ncclResult_t ncclGetUniqueId(ncclUniqueId* id) {
   return ncclSuccess;
 }
 
+// TEST HOOK (not an RCCL entry point): how many ncclCommInitRank / ncclCommDestroy calls this library has served since it was loaded --
+// what tests/test_gpu_ranks.py reads to show that a sweep of many sectors builds ONE communicator per rank.
+static std::atomic<long long> g_n_init{0}, g_n_destroy{0};
+long long rccl_double_comm_inits() { return g_n_init.load(); }
+long long rccl_double_comm_destroys() { return g_n_destroy.load(); }
+
 ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int rank) {
   if (!comm || nranks < 1 || rank < 0 || rank >= nranks) return ncclInvalidArgument;
+  ++g_n_init;
   const std::string key(id.internal, sizeof(id.internal));
   std::shared_ptr<World> w;
   {
@@ -222,6 +229,7 @@ ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int
 ncclResult_t ncclCommDestroy(ncclComm_t comm) {
   Comm* c = reinterpret_cast<Comm*>(comm);
   if (!c) return ncclSuccess;
+  ++g_n_destroy;
   std::shared_ptr<World> w = c->w;
   bool last;
   {

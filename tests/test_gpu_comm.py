@@ -224,3 +224,12 @@ def test_bench_n_processes_on_one_gpu_through_the_rccl_branches(built, exchange,
     assert cfg["rccl_lib"].endswith("librccl_double_mp.so") and isinstance(cfg["rccl_libs_mapped"], list)
     ex = rl["exchange_ms"]
     assert ex["min"] <= ex["this_rank"] <= ex["max"] and abs(ex["this_rank"] - (rl["slab_product_ms_on_stream"] - rl["kernel_ms"])) < 1e-3
+    # first contact records EVERY exchange: the two that were not asked for are opened, checked against the main one's
+    # product and timed in the same launch, each with its own link bound -- and one communicator per process served all three sectors
+    oth = cfg["other_exchanges"]
+    assert set(oth) == {"allgather", "halo", "alltoall"} - {exchange}
+    for name, o in oth.items():
+        assert o["ms_per_step"] > 0 and o["GBs"] > 0 and o["link_bound_ms"] > 0 and o["check_rel_err_vs_main"] <= 1e-13, (name, o)
+        assert o["exchange_ms"]["min"] <= o["exchange_ms"]["this_rank"] <= o["exchange_ms"]["max"] and o["kernel_ms"] > 0
+    assert oth.get("alltoall", cfg)["link_bound_ms"] <= oth.get("allgather", cfg)["link_bound_ms"]      # the two transposes move the least
+    assert cfg["comm_cache"]["inits"] == 1 and cfg["comm_cache"]["reuses"] >= 2                          # (rank 0's process)

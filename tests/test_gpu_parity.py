@@ -525,7 +525,10 @@ def test_c5_ns18_slab_matches_oracle_matrices(built):
         return r * cmax + (c - cfirst)
     def col(c):
         s = slot(int(c))
-        return v[s * pitch:s * pitch + du].cpu().numpy()
+        x = v[s * pitch:s * pitch + du].cpu().numpy()
+        if sec.row_perm is not None:                         # device row order (hxv.h): reference row i sits at device row perm[i], times sign[i]
+            x = x[sec.row_perm] * sec.row_sign
+        return x
     Vloc = np.stack([col(c0 + k) for k in range(q)], axis=1)  # (du, q)
     Vsrc = np.stack([col(c) for c in src], axis=1)            # (du, len(src))
     out = orc.diag().reshape((du, q), order="F") * Vloc + Hup @ Vloc + (Hdw[:, src] @ Vsrc.T).T

@@ -466,3 +466,91 @@ def test_start_vector_built_at_the_slab_home(built, transport, exchange, real_ve
         assert n == n0
         for x, y in ((a, a0), (b, b0), (aa, a0), (ba, b0), (ab, a0), (bb, b0)):
             assert np.abs(x - y).max() <= 1e-11 * max(np.abs(y).max(), 1.0)
+
+
+def _double_counters(built):
+    import ctypes
+
+    lib = ctypes.CDLL(str(built.build_rccl_double()))
+    lib.rccl_double_comm_inits.restype = ctypes.c_longlong
+    lib.rccl_double_comm_destroys.restype = ctypes.c_longlong
+    return lib
+
+
+def test_one_communicator_per_process_serves_a_sweep_of_sectors(built, monkeypatch):
+    """VERDICT r5 item 2.  The reference sets MpiComm once per solve (ED_VARS_GLOBAL.f90:365-380) while its callers open a sector around every
+    Lanczos run (ED_DIAG.f90:142-190: 289 per sweep; ED_GF_NORMAL.f90:208-222: 56 per Green's-function stage).  Two ranks through the RCCL
+    branches (tests/rccl_double): 20 sectors opened -> joined -> product + sp_lanc_eigh -> closed, then 8 Green's-function channels (ground
+    state kept, c^dagger into the N+1 sector opened and closed around each tridiagonalisation).  ONE ncclCommInitRank per rank (the double
+    counts them) although hxv_comm_init is called 29 times per rank; with HXV_COMM_CACHE=0 every hxv_comm_init builds one, and every number
+    of the sweep -- products, E0, alanc / blanc -- is bit-identical between the two."""
+    import threading
+    import torch
+    import hxv
+    from hxv import models
+
+    monkeypatch.setenv("HXV_RCCL_LIB", str(built.build_rccl_double()))
+    dbl = _double_counters(built)
+    m = models.hm_1dchain(Nlat=2, Nbath=2, eps_bath=[0.3, 0.6])   # Ns = 6
+    sectors = [(nu, nd) for nu in range(1, 6) for nd in range(1, 6)][:20]
+    chans = [(orb, spin) for spin in (0, 1) for orb in (0, 1, 3, 4)]
+    nranks = 2
+    nid = len(sectors) + 1 + len(chans)
+
+    def sweep():
+        ids = [hxv.HxvSector.comm_unique_id() for _ in range(nid)]   # what rank 0 would draw and MPI_Bcast, one per hxv_comm_init
+        bar = threading.Barrier(nranks)
+
+        def rank(r, group):
+            out = []
+            k = 0
+            for nup, ndw in sectors:
+                sec = hxv.HxvSector.from_model(m, nup, ndw, rank=r, nranks=nranks)
+                sec.comm_init(ids[k])
+                k += 1
+                v = models.deterministic_vector(sec.vecDim, offset=sec.mpiIshift)
+                hv = sec.apply_device_slab(sec.pad(torch.from_numpy(v).cuda(), sec.mpiQdw))
+                e0, _, nit = sec.lanczos_eigh(64, 1e-12, want_vector=False, native=True) if sec.Dim > 4 else (0.0, None, 0)
+                out.append((sec.unpad(hv).cpu().numpy(), e0, nit))
+                sec.close()
+                bar.wait()
+            gs = hxv.HxvSector.from_model(m, 3, 3, rank=r, nranks=nranks)
+            gs.comm_init(ids[k])
+            k += 1
+            e0, psi, _ = gs.lanczos_eigh(128, 1e-13, native=True)
+            out.append(e0)
+            for orb, spin in chans:
+                tgt = hxv.HxvSector.from_model(m, 3 + (spin == 0), 3 + (spin == 1), rank=r, nranks=nranks)
+                tgt.comm_init(ids[k])
+                k += 1
+                vv, n2 = gs.apply_ladder(tgt, orb, spin, True, psi)
+                a, b, n = tgt.lanczos_tridiag(vv, 12)
+                out.append((n2, a.copy(), b.copy(), n))
+                tgt.close()
+                bar.wait()
+            gs.close()
+            return out
+
+        return hxv.run_ranks(nranks, rank, transport="rccl")
+
+    assert hxv.comm_cache_clear() >= 0                      # (communicators earlier tests left behind)
+    lh0 = hxv.live_handles()
+    st0, i0, d0 = hxv.comm_cache_stats(), dbl.rccl_double_comm_inits(), dbl.rccl_double_comm_destroys()
+    cached = sweep()
+    st1, i1 = hxv.comm_cache_stats(), dbl.rccl_double_comm_inits()
+    assert i1 - i0 == nranks, (i0, i1)                      # ONE ncclCommInitRank per rank for 29 hxv_comm_init calls each
+    assert st1["inits"] - st0["inits"] == nranks and st1["reuses"] - st0["reuses"] == nranks * (nid - 1) and st1["entries"] == nranks
+    assert hxv.comm_cache_clear() == nranks and dbl.rccl_double_comm_destroys() - d0 == nranks and hxv.comm_cache_stats()["entries"] == 0
+    monkeypatch.setenv("HXV_COMM_CACHE", "0")
+    i2 = dbl.rccl_double_comm_inits()
+    fresh = sweep()
+    assert dbl.rccl_double_comm_inits() - i2 == nranks * nid          # the behaviour before round 6: one communicator per opened sector
+    assert hxv.comm_cache_stats()["entries"] == 0
+    for ra, rb in zip(cached, fresh):
+        for xa, xb in zip(ra, rb):
+            if isinstance(xa, tuple):
+                for ya, yb in zip(xa, xb):
+                    assert np.array_equal(np.asarray(ya), np.asarray(yb))
+            else:
+                assert xa == xb
+    assert hxv.live_handles() == lh0                        # every sector of the two sweeps was closed
