@@ -103,6 +103,90 @@ __global__ void __launch_bounds__(1024, 8) mix(const double2* __restrict__ big, 
   if (acc.x == 1.2345e300) out[b] = acc;
 }
 
+// gathers only, by per-lane LDS-DMA (global_load_lds_dwordx4: the data lands in LDS at base + 16 x lane, no staging registers)
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+template <int HB, int SL>
+__global__ void __launch_bounds__(1024, 8) gather_dma(const double2* __restrict__ small, double2* __restrict__ out, int tiles_per_wg, uint64_t big_tiles,
+                                                      uint32_t small_segs, int ng) {
+  extern __shared__ double2 lds[];
+  const int tid = threadIdx.x, b = blockIdx.x, wave = tid >> 6, lane = tid & 63;
+  const double2* __restrict__ sm = small + (uint64_t)(b & 7) * small_segs * 4;
+  double2 acc = make_double2(0.0, 0.0);
+  const uint32_t base = (uint32_t)(wave * HB * 1024);   // this wave's HB KB of the staging slab
+  for (int t = 0; t < tiles_per_wg; ++t) {
+    const uint64_t tile = ((uint64_t)b * tiles_per_wg + t) % big_tiles;
+    const uint32_t seed = (uint32_t)tile * 2654435761u;
+    for (int g0 = 0; g0 < ng; g0 += HB) {
+#pragma unroll
+      for (int k = 0; k < HB; ++k) {
+        const uint32_t h = hash32(seed + (uint32_t)(g0 + k) * 0x9E3779B9u + (uint32_t)(tid / SL) * 0x85EBCA6Bu);
+        const double2* p = sm + ((uint64_t)(h % (small_segs * 4 / SL)) * SL + (tid % SL));
+        __builtin_amdgcn_global_load_lds((glb_void_t*)p, (lds_void_t*)(base + (uint32_t)k * 1024), 16, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < HB; ++k) {
+        const double2 x = lds[(base >> 4) + k * 64 + lane];
+        acc.x += x.x;
+        acc.y += x.y;
+      }
+    }
+  }
+  if (acc.x == 1.2345e300) out[b] = acc;
+}
+
+// gathers only, 8 bytes per lane (the real-vector pass A: one double per column and row), same bytes moved: 2 x the loads
+template <int HB, int SL>
+__global__ void __launch_bounds__(1024, 8) gather_b64(const double* __restrict__ small, double2* __restrict__ out, int tiles_per_wg, uint64_t big_tiles,
+                                                      uint32_t small_dsegs, int ng) {
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const double* __restrict__ sm = small + (uint64_t)(b & 7) * small_dsegs * 8;   // (small_dsegs segments of 64 B = 8 doubles)
+  double acc = 0.0;
+  for (int t = 0; t < tiles_per_wg; ++t) {
+    const uint64_t tile = ((uint64_t)b * tiles_per_wg + t) % big_tiles;
+    const uint32_t seed = (uint32_t)tile * 2654435761u;
+    for (int g0 = 0; g0 < 2 * ng; g0 += HB) {
+      double x[HB];
+#pragma unroll
+      for (int k = 0; k < HB; ++k) {
+        const uint32_t h = hash32(seed + (uint32_t)(g0 + k) * 0x9E3779B9u + (uint32_t)(tid / SL) * 0x85EBCA6Bu);
+        x[k] = sm[(uint64_t)(h % (small_dsegs * 8 / SL)) * SL + (tid % SL)];
+      }
+#pragma unroll
+      for (int k = 0; k < HB; ++k) acc += x[k];
+    }
+  }
+  if (acc == 1.2345e300) out[b] = make_double2(acc, 0.0);
+}
+
+template <int HB, int SL>
+void sweep_forms(const double2* small, double2* out, int tiles_per_wg, uint64_t big_tiles, uint32_t small_segs, int ng) {
+  const double gb = 512.0 * tiles_per_wg * TILE * 16.0 * ng / NP;
+  hipEvent_t e0, e1;
+  CHK(hipEventCreate(&e0));
+  CHK(hipEventCreate(&e1));
+  float ms;
+  for (int form = 0; form < 2; ++form) {
+    for (int rep = 0; rep < 2; ++rep) {
+      CHK(hipEventRecord(e0, 0));
+      for (int i = 0; i < (rep ? 5 : 1); ++i) {
+        if (form == 0)
+          hipLaunchKernelGGL((gather_dma<HB, SL>), dim3(512), dim3(T), 16 * HB * 1024, 0, small, out, tiles_per_wg, big_tiles, small_segs, ng);
+        else
+          hipLaunchKernelGGL((gather_b64<HB, SL>), dim3(512), dim3(T), 0, 0, (const double*)small, out, tiles_per_wg, big_tiles, small_segs, ng);
+      }
+      CHK(hipEventRecord(e1, 0));
+      CHK(hipEventSynchronize(e1));
+      CHK(hipEventElapsedTime(&ms, e0, e1));
+    }
+    CHK(hipGetLastError());
+    ms /= 5;
+    printf("  seg %4d B HB=%d %-40s %8.3f ms   %7.1f GB/s chip  %6.1f GB/s per CU\n", SL * (form ? 8 : 16), HB,
+           form ? "gathers only, 8 B per lane (dwordx2)" : "gathers only, per-lane LDS-DMA", ms, gb / ms * 1e-6, gb / ms * 1e-6 / 256);
+  }
+}
+
 template <int MODE, int HB, int SL>
 float run(const double2* big, const double2* small, double2* out, int tiles_per_wg, uint64_t big_tiles, uint32_t small_segs, int ng, int missp, int nrep) {
   hipEvent_t e0, e1;
@@ -162,5 +246,13 @@ int main(int argc, char** argv) {
   sweep<4, 16>(big, small, out, tiles_per_wg, big_tiles, small_segs, ng, missp);
   sweep<4, 64>(big, small, out, tiles_per_wg, big_tiles, small_segs, ng, missp);
   sweep<8, 64>(big, small, out, tiles_per_wg, big_tiles, small_segs, ng, missp);
+  if (missp == 0) {
+    printf("other forms of the gather (all L2 hits):\n");
+    sweep_forms<4, 4>(small, out, tiles_per_wg, big_tiles, small_segs, ng);
+    sweep_forms<8, 4>(small, out, tiles_per_wg, big_tiles, small_segs, ng);
+    sweep_forms<4, 8>(small, out, tiles_per_wg, big_tiles, small_segs, ng);
+    sweep_forms<4, 64>(small, out, tiles_per_wg, big_tiles, small_segs, ng);
+    sweep_forms<8, 64>(small, out, tiles_per_wg, big_tiles, small_segs, ng);
+  }
   return 0;
 }
