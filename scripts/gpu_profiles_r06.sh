@@ -6,9 +6,10 @@ export TMPDIR=/tmp
 PART=${PART:-1}
 STAMP=$(python3 -c "import re;print(re.search(r'KERNELS_STAMP = \"([^\"]+)\"', open('bench.py').read()).group(1))")
 if [ "$PART" = "1" ]; then
-  # the driver-shaped bench line, then the same bench under rocprofv3 (kernel stats; no CPU baseline / other workloads / solve / host-array legs)
+  # the driver-shaped bench line, then the same bench under rocprofv3 (kernel stats of the PRODUCT alone: no CPU baseline / other workloads / solve / host-array / Lanczos legs --
+  # the real-vector product launches the complex pass-B kernel on row pairs, which would mix into its average)
   timeout -k 10 600 python bench.py --steps 100 --warmup 20 2> $R/bench_err.log > $R/bench_n1.json; cut -c1-300 $R/bench_n1.json
-  ( cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/$R/bench_trace -- python3 /root/repo/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-other-workloads --no-gf-solve --no-apply-host > /root/repo/$R/bench_trace.log 2>&1 )
+  ( cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/$R/bench_trace -- python3 /root/repo/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-other-workloads --no-gf-solve --no-apply-host --no-lanczos > /root/repo/$R/bench_trace.log 2>&1 )
   cp $R/bench_trace/*/*kernel_stats.csv $R/bench_kernel_stats.csv 2>/dev/null; tail -1 $R/bench_trace.log | cut -c1-200
   python3 scripts/make_kernel_trace.py $R/bench_kernel_stats.csv $STAMP r06_bench_n1_kernel_stats.csv > $R/kernel_trace.log 2>&1; cp profiles/kernel_trace.json $R/; head -30 $R/kernel_trace.log
 fi
