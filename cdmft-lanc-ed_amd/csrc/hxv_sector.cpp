@@ -181,21 +181,24 @@ void apply_hops(const std::vector<uint32_t>& map, const std::vector<Hop>& hops_i
 // at bit L-1-d hops into a high one from 2^d runs of consecutive rows per block pair (d = 0: one run, a half block), so the tied orbitals
 // want the top low bits.  C3 (2x2 + 3 replicas, L = 12): high = replica 3, tied = the four cluster sites -> bits 8..11, replicas 1, 2 -> 0..7.
 // C4 (BHZ): the reference's numbering is already sorted this way -> no row order.
-std::string make_row_order(SectorHost& s, const std::vector<Hop>& hops_up, int ns) {
+// Three steps, so that the one-spin matrix between device rows is built BESIDE the two reference matrices (a cold open of an Ns=16 sector stays
+// near 20 ms): plan_row_order decides the order and relabels the basis (before the matrices are built), build_row_order_matrix is the third
+// worker of the matrix build, finish_row_order carries the per-row tables over once they exist.
+void plan_row_order(SectorHost& s, const std::vector<Hop>& hops_up, int ns, bool nd_tables_ok) {
   // (test hooks: HXV_ROW_ORDER_MIN_DIMUP lowers the size below which the reference's order is kept [2048: one block or two, nothing to gain];
   //  HXV_ROW_ORDER_BITS chooses the order for that many block bits instead of the default plan's -- the suite sets the handle's "tile_bits_up"
   //  to the same value -- so that small sectors exercise the row order against the oracle)
   const char* emin = std::getenv("HXV_ROW_ORDER_MIN_DIMUP");
   const char* ebits = std::getenv("HXV_ROW_ORDER_BITS");
-  if (!row_order_enabled() || s.dimup < (emin ? std::atoi(emin) : 2048) || ns > 24) return "";
-  if (s.nd.active && s.nd_up.empty()) return "";  // (the table-free spH0nd kernel searches the sorted reference basis)
+  if (!row_order_enabled() || s.dimup < (emin ? std::atoi(emin) : 2048) || ns > 24) return;
+  if (!nd_tables_ok) return;  // (the table-free spH0nd kernel searches the sorted reference basis)
   std::vector<cplx> amps;
   for (const Hop& h : hops_up) {
     const cplx a = (h.t.real() < 0 || (h.t.real() == 0 && h.t.imag() < 0)) ? -h.t : h.t;
     if (std::find(amps.begin(), amps.end(), a) == amps.end()) amps.push_back(a);
   }
   const int L = ebits ? std::atoi(ebits) : default_lowbits_up(ns, s.nup, (int)amps.size());
-  if (L <= 0 || L >= ns) return "";  // one block: nothing leaves it
+  if (L <= 0 || L >= ns) return;  // one block: nothing leaves it
   std::vector<int> deg(ns, 0);
   for (const Hop& h : hops_up) {
     if (h.a >= L && h.b < L) deg[h.b]++;
@@ -211,7 +214,7 @@ std::string make_row_order(SectorHost& s, const std::vector<Hop>& hops_up, int n
     ident = ident && low[b] == b;
   }
   for (int o = L; o < ns; ++o) pos[o] = o;
-  if (ident) return "";
+  if (ident) return;
   const int dim = s.dimup;
   // device configurations: relabel every reference configuration, sort
   std::vector<uint32_t> key_of(dim);
@@ -232,7 +235,6 @@ std::string make_row_order(SectorHost& s, const std::vector<Hop>& hops_up, int n
   s.up_perm.assign(dim, 0);
   s.key_up.resize(dim);
   s.map_up_dev.resize(dim);
-  s.a_up_dev.resize(dim);
   s.up_sign.assign(dim, 0);
   // sign of a basis state: parity of the pairs of occupied orbitals whose order the relabelling reverses
   std::vector<std::pair<int, int>> inv;
@@ -244,21 +246,30 @@ std::string make_row_order(SectorHost& s, const std::vector<Hop>& hops_up, int n
     s.up_perm[i] = d;
     s.key_up[d] = key_of[i];
     s.map_up_dev[d] = s.map_up[i];
-    s.a_up_dev[d] = s.a_up[i];
     const uint32_t m = s.map_up[i];
     int par = 0;
     for (const auto& pr : inv) par ^= (int)((m >> pr.first) & (m >> pr.second) & 1u);
     s.up_sign[d] = (uint8_t)par;
   }
-  // H_up between device rows = H written with the relabelled orbitals on the sorted device configurations
+}
+
+// H_up between device rows = H written with the relabelled orbitals on the sorted device configurations
+std::string build_row_order_matrix(SectorHost& s, const std::vector<Hop>& hops_up, int ns) {
   std::vector<Hop> hd(hops_up);
   for (Hop& h : hd) {
-    h.a = pos[h.a];
-    h.b = pos[h.b];
+    h.a = s.up_pos[h.a];
+    h.b = s.up_pos[h.b];
   }
   apply_hops(s.key_up, hd, ns, s.up_dev);
   std::string e = build_ell(s.up_dev);
-  if (!e.empty()) return "H_up in device row order: " + e;
+  return e.empty() ? e : "H_up in device row order: " + e;
+}
+
+// the per-row tables of the diagonal and of the spH0nd block by device row (they are built in the reference's order first)
+void finish_row_order(SectorHost& s) {
+  const int dim = s.dimup;
+  s.a_up_dev.resize(dim);
+  for (int d = 0; d < dim; ++d) s.a_up_dev[d] = s.a_up[s.up_iperm[d]];
   // the spH0nd move tables: rows and targets relabelled, signs carried over
   if (!s.nd_up.empty()) {
     const size_t nq = s.nd_up.size() / (size_t)dim;
@@ -272,7 +283,6 @@ std::string make_row_order(SectorHost& s, const std::vector<Hop>& hops_up, int n
         s.nd_up_dev[q * dim + di] = (uint32_t)dj | (sg << 31);
       }
   }
-  return "";
 }
 
 }  // namespace
@@ -507,16 +517,28 @@ std::string build_sector_from_model(const hxv_model& m, int nup, int ndw, int ra
       return true;
     };
     const bool twin = panel_rows == 0 && nup == ndw && same_hops();
-    GuardedThread th;   // (joins on every path; its exceptions come back as an error string)
+    // the device row order is decided before the matrices are built, so that H_up between device rows is the third worker of this build
+    if (panel_rows == 0) {
+      const bool nd_on = m.norb > 1 && (m.jx != 0.0 || m.jp != 0.0);
+      const bool nd_tables = (int64_t)m.nlat * m.norb * m.norb * (int64_t)std::max(s.dimup, s.dimdw) <= (int64_t)32 << 20;
+      plan_row_order(s, hops_up, ns, !nd_on || nd_tables);
+    }
+    GuardedThread th, th_dev;   // (join on every path; their exceptions come back as error strings)
+    std::string e_dev;
     if (panel_rows == 0 && !twin) th.run([&] { apply_hops(s.map_up, hops_up, ns, s.up); });
+    if (s.row_order()) th_dev.run([&] { e_dev = build_row_order_matrix(s, hops_up, ns); });
     try {
       apply_hops(s.map_dw, hops_dw, ns, s.dw);
     } catch (const std::exception& ex) {
       th.join();
+      th_dev.join();
       return std::string("building H_dw: ") + ex.what();
     }
     th.join();
+    th_dev.join();
     if (!th.err.empty()) return "building H_up: " + th.err;
+    if (!th_dev.err.empty()) return "building H_up between device rows: " + th_dev.err;
+    if (!e_dev.empty()) return e_dev;
     twin_spins = twin;
   }
   // (the spH0nd block reaches columns that H_dw does not: it keeps the all-gather layout)
@@ -637,10 +659,7 @@ std::string build_sector_from_model(const hxv_model& m, int nup, int ndw, int ra
   }
   for (int il = 0; il < L; ++il)
     for (int io = 0; io < O; ++io) s.cross.sitemask[il] |= 1u << mv.imp(il, io);
-  if (panel_rows == 0) {
-    e = make_row_order(s, hops_up, ns);
-    if (!e.empty()) return e;
-  }
+  if (s.row_order()) finish_row_order(s);
   return "";
 }
 

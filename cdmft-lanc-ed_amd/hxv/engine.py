@@ -501,7 +501,10 @@ class HxvSector:
 
     # -- padded device layout helpers -------------------------------------------------------
     def pad(self, x, ncols=None):
-        """contiguous [ncols x DimUp] torch vector -> padded device layout [ncols x pitch] (pads zero)."""
+        """contiguous [ncols x DimUp] torch vector in the REFERENCE's order -> device layout [ncols x pitch] (pads zero; with a device row
+        order -- include/hxv.h -- row i of every column goes to row perm[i] with the sign of its basis vector).  The convenience forms of
+        apply_device / lanczos_tridiag / apply_ladder recognise a contiguous vector by its LENGTH; where DimUp is a multiple of 8 the two
+        layouts are equally long and the vector is taken as a device vector: call pad / unpad explicitly there."""
         import torch
 
         if self.row_perm is not None:

@@ -194,3 +194,51 @@ def test_headline_sector_takes_the_row_order_by_itself(built):
     assert sec.get_option("bh_up_x100") == 213 and sec.get_option("rs_up_x100") == 400
     sec.close()
     hxv.sector_cache_clear()
+
+
+@pytest.mark.parametrize("bits", [3, 5, 7, 10])
+@pytest.mark.parametrize("nup,ndw", [(4, 6), (7, 5)])
+def test_row_order_for_other_block_sizes_and_fillings(built, monkeypatch, bits, nup, ndw):
+    """The order depends on which orbitals are high (the block bits) and on the filling: products through both vector surfaces and one ladder
+    operator against the oracle / the definition for a spread of them (Ns = 12 star geometry, Nspin = 1; complex amplitudes via a twisted bath)."""
+    import torch
+    import hxv
+    from hxv import models
+    from oracle.oracle import OracleSector
+
+    monkeypatch.setenv("HXV_ROW_ORDER_MIN_DIMUP", "16")
+    monkeypatch.setenv("HXV_ROW_ORDER_BITS", str(bits))
+    hxv.sector_cache_clear()
+    m = models.hm_2dsquare(Nbath=2, xmu=-0.3)
+    m.Hbath[0, 1, 0, 0, 0, 0, 1] *= np.exp(0.4j)       # a complex hop and its conjugate in replica 2: complex H, Hermitian
+    m.Hbath[1, 0, 0, 0, 0, 0, 1] *= np.exp(-0.4j)
+    sec = _open(m, nup, ndw, bits)
+    orc = OracleSector(m, nup, ndw)
+    v = models.deterministic_vector(sec.Dim)
+    v /= np.linalg.norm(v)
+    ref = orc.spMatVec_main(v)
+    assert _rel(sec.apply_host(v), ref) < TOL
+    assert _rel(sec.unpad(sec.apply_device(sec.pad(torch.from_numpy(v).cuda()))).cpu().numpy(), ref) < TOL
+    if sec.row_perm is not None:
+        assert sorted(sec.row_perm.tolist()) == list(range(sec.DimUp))
+    # c_{2,up} into the sector below: through pad / unpad the reference's result
+    tgt = _open(m, nup - 1, ndw, bits)
+    # (native form on both sides: where DimUp is a multiple of 8 -- (7,5): 792 -- a contiguous vector has the length of a device vector and
+    #  the mirror's convenience form cannot tell them apart; pad / unpad say which is meant)
+    out = torch.zeros(tgt.localElems, dtype=torch.complex128, device="cuda")
+    out, n2 = sec.apply_ladder(tgt, 2, 0, False, sec.pad(torch.from_numpy(v).cuda()), out=out)
+    got = tgt.unpad(out).cpu().numpy()
+    mua, _ = sec.maps()
+    mub, _ = tgt.maps()
+    ia = {int(x): k for k, x in enumerate(mua)}
+    V = v.reshape(sec.DimDw, sec.DimUp)
+    E = np.zeros((tgt.DimDw, tgt.DimUp), dtype=np.complex128)
+    for k, mt in enumerate(mub.tolist()):
+        if mt & 4:
+            continue
+        mf = mt | 4
+        E[:, k] = (-1.0 if bin(mf & 3).count("1") & 1 else 1.0) * V[:, ia[mf]]
+    assert np.abs(got - E.reshape(-1)).max() < 1e-14
+    sec.close()
+    tgt.close()
+    hxv.sector_cache_clear()
