@@ -253,16 +253,15 @@ void plan_row_order(SectorHost& s, const std::vector<Hop>& hops_up, int ns, bool
   }
 }
 
-// H_up between device rows = H written with the relabelled orbitals on the sorted device configurations
-std::string build_row_order_matrix(SectorHost& s, const std::vector<Hop>& hops_up, int ns) {
+// H_up between device rows = H written with the relabelled orbitals on the sorted device configurations (its ELL tables are built with the
+// other two matrices' in the next phase of the build)
+void build_row_order_matrix(SectorHost& s, const std::vector<Hop>& hops_up, int ns) {
   std::vector<Hop> hd(hops_up);
   for (Hop& h : hd) {
     h.a = s.up_pos[h.a];
     h.b = s.up_pos[h.b];
   }
   apply_hops(s.key_up, hd, ns, s.up_dev);
-  std::string e = build_ell(s.up_dev);
-  return e.empty() ? e : "H_up in device row order: " + e;
 }
 
 // the per-row tables of the diagonal and of the spH0nd block by device row (they are built in the reference's order first)
@@ -524,9 +523,8 @@ std::string build_sector_from_model(const hxv_model& m, int nup, int ndw, int ra
       plan_row_order(s, hops_up, ns, !nd_on || nd_tables);
     }
     GuardedThread th, th_dev;   // (join on every path; their exceptions come back as error strings)
-    std::string e_dev;
     if (panel_rows == 0 && !twin) th.run([&] { apply_hops(s.map_up, hops_up, ns, s.up); });
-    if (s.row_order()) th_dev.run([&] { e_dev = build_row_order_matrix(s, hops_up, ns); });
+    if (s.row_order()) th_dev.run([&] { build_row_order_matrix(s, hops_up, ns); });
     try {
       apply_hops(s.map_dw, hops_dw, ns, s.dw);
     } catch (const std::exception& ex) {
@@ -538,7 +536,6 @@ std::string build_sector_from_model(const hxv_model& m, int nup, int ndw, int ra
     th_dev.join();
     if (!th.err.empty()) return "building H_up: " + th.err;
     if (!th_dev.err.empty()) return "building H_up between device rows: " + th_dev.err;
-    if (!e_dev.empty()) return e_dev;
     twin_spins = twin;
   }
   // (the spH0nd block reaches columns that H_dw does not: it keeps the all-gather layout)
@@ -569,16 +566,20 @@ std::string build_sector_from_model(const hxv_model& m, int nup, int ndw, int ra
   // (its row panels need a row for every rank: tiny sectors keep the all-gather)
   if (nranks > 1 && nranks <= s.dimup && panel_rows == 0 && default_exchange() == 2 && !(m.norb > 1 && (m.jx != 0.0 || m.jp != 0.0))) s.exchange = 2;
   {
-    std::string e_up;
-    GuardedThread th;
+    std::string e_up, e_dev;
+    GuardedThread th, th_dev;
     if (!twin_spins) th.run([&] { e_up = build_ell(s.up); });
+    if (s.row_order()) th_dev.run([&] { e_dev = build_ell(s.up_dev); });
     try {
       e = build_ell(s.dw);
     } catch (const std::exception& ex) {
       e = std::string("building the H_dw tables: ") + ex.what();
     }
     th.join();
+    th_dev.join();
     if (!th.err.empty()) return "building the H_up tables: " + th.err;
+    if (!th_dev.err.empty()) return "building the tables of H_up between device rows: " + th_dev.err;
+    if (!e_dev.empty()) return "H_up in device row order: " + e_dev;
     if (!e_up.empty()) return e_up;
     if (!e.empty()) return e;
     if (twin_spins) s.up = s.dw;
