@@ -51,6 +51,7 @@ __device__ __forceinline__ double2 load_stream(const double2* p) {
   dbl2_t x = __builtin_nontemporal_load(reinterpret_cast<const dbl2_t*>(p));
   return make_double2(x.x, x.y);
 }
+__device__ __forceinline__ double load_stream(const double* p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ void store_stream(double2* p, double2 a) {
   dbl2_t x;
   x.x = a.x;
