@@ -118,6 +118,7 @@ struct ProcComm {
   bool cached = false;            // lives in g_comms until hxv_comm_cache_clear (else: owned by the one handle that made it)
   std::atomic<int> users{0};      // handles bound to it
   std::atomic<int> aborted{0};
+  std::atomic<int> failed{0};     // a collective on it returned an error: torn down with ncclCommAbort (ncclCommDestroy may wait for the lost peer)
 };
 struct CommCache {
   std::mutex mu;
@@ -135,13 +136,19 @@ bool comm_cache_on() {
 ProcComm* pc(const hxv_handle* h) { return static_cast<ProcComm*>(h->comm_shared); }
 void proc_comm_destroy(ProcComm* p) {
   if (!p) return;
-  if (p->c && !p->aborted) (void)p->api->CommDestroy(p->c);  // (ncclCommAbort has freed an aborted communicator)
+  if (p->c && !p->aborted) {  // (ncclCommAbort has freed an aborted communicator)
+    if (p->failed && p->api->CommAbort)
+      (void)p->api->CommAbort(p->c);
+    else
+      (void)p->api->CommDestroy(p->c);
+  }
   delete p;
 }
 // A collective on the handle's communicator has FAILED (a peer aborted, a link went down): the communicator must not serve the next sector.
 // It leaves the cache (the next hxv_comm_init builds a new one from its id); the handles bound to it keep it until they are closed.
 int comm_failed(hxv_handle* h, const char* what, ncclResult_t e) {
   if (ProcComm* p = pc(h)) {
+    p->failed = 1;
     std::lock_guard<std::mutex> lk(comm_cache().mu);
     auto& all = comm_cache().all;
     all.erase(std::remove(all.begin(), all.end(), p), all.end());
