@@ -3,7 +3,9 @@
   (1) numbers the survey recorded from the reference itself,
   (2) the literature value of the 4-site Hubbard ring,
   (3) an independent second-quantised construction (Jordan-Wigner on the full Fock space),
-  (4) internal consistency: sparse == dense-Kronecker == MPI-emulated product."""
+  (4) internal consistency: sparse == dense-Kronecker == MPI-emulated product,
+  (5) closed forms (round 6): the Hubbard dimer's four levels, and the free-fermion limit -- the lowest level of a sector = the sum of the
+      lowest one-body levels of each spin, the one-body matrices assembled straight from the model arrays (real and complex models)."""
 import itertools
 import json
 from pathlib import Path
@@ -192,3 +194,58 @@ def test_fullsize_fixture_first_step_against_the_oracle():
     hv -= alpha * v
     beta = np.sqrt(np.vdot(hv, hv).real)
     assert abs(alpha - g["alanc"][0]) < 1e-11 * abs(alpha) and abs(beta - g["blanc"][1]) < 1e-11 * beta
+
+
+def test_hubbard_dimer_closed_form():
+    """Analytic pin (textbook): two sites, two electrons, Sz = 0: E0 = (U - sqrt(U^2 + 16 t^2)) / 2; the sector's four levels are
+    {E0, 0, U, (U + sqrt(U^2 + 16 t^2)) / 2}.  No bath, hfmode off: nothing but H_up, H_dw and U n_up n_dw of the reference's construction."""
+    for U, t in ((4.0, 1.0), (1.3, 0.37), (0.0, 0.5)):
+        s = OracleSector(models.hm_1dchain(Nlat=2, Nbath=0, ts=t, U=U, hfmode=False), 1, 1)
+        ev = np.linalg.eigvalsh(s.dense())
+        r = np.sqrt(U * U + 16 * t * t)
+        assert np.allclose(ev, sorted([(U - r) / 2, 0.0, U, (U + r) / 2]), atol=1e-13), (U, t, ev)
+
+
+@pytest.mark.parametrize("name", ["chain_bath", "star", "bhz"])
+def test_free_fermion_limit_against_the_one_body_spectrum(name):
+    """Analytic pin: without interaction the lowest level of sector (nup, ndw) is the sum of the nup lowest levels of the up one-body matrix
+    plus the ndw lowest of the dw one -- a statement about the ONE-BODY matrices (impHloc, the replicas' blocks, the hybridisation), assembled
+    here straight from the model arrays, that every fermionic sign of the reference's c / c^dagger (ED_SETUP.f90:807-833) must get right as
+    soon as two particles of a spin can exchange.  Complex amplitudes included (BHZ)."""
+    if name == "chain_bath":
+        m, sectors = models.hm_1dchain(Nlat=2, Nbath=2, U=0.0, hfmode=False, eps_bath=[0.3, -0.2]), [(3, 3), (2, 4), (1, 5)]
+    elif name == "star":
+        m, sectors = models.hm_2dsquare(Nbath=1, U=0.0, hfmode=False, xmu=0.15), [(4, 4), (3, 5)]
+    else:
+        m, sectors = models.bhz_2d(Nbath=0, U=0.0, hfmode=False), [(4, 4), (3, 5), (2, 2)]
+    L, O, B, S = m.Nlat, m.Norb, m.Nbath, m.Nspin
+    nimp, ns = L * O, L * O * (B + 1)
+
+    def one_body(spin):
+        s = spin if S > 1 else 0
+        h = np.zeros((ns, ns), dtype=np.complex128)
+        for il in range(L):
+            for jl in range(L):
+                for io in range(O):
+                    for jo in range(O):
+                        a, b = io + il * O, jo + jl * O                      # ED_SETUP.f90:563-568
+                        h[a, b] += m.impHloc[il, jl, s, s, io, jo]
+                        for ib in range(B):
+                            x = m.Hbath[il, jl, s, s, io, jo, ib]
+                            h[nimp + a + ib * nimp, nimp + b + ib * nimp] += x.real if a == b else x   # bath_diag = DREAL(...), :71
+        for ib in range(B):
+            for il in range(L):
+                for io in range(O):
+                    a = io + il * O
+                    h[a, nimp + a + ib * nimp] += m.Vbath[il, s, io, ib]
+                    h[nimp + a + ib * nimp, a] += m.Vbath[il, s, io, ib]
+        for a in range(nimp):
+            h[a, a] -= m.xmu                                                   # H_local.f90:22-28
+        assert np.abs(h - h.conj().T).max() == 0.0
+        return np.linalg.eigvalsh(h)
+
+    eu, ed = one_body(0), one_body(S - 1)
+    for nup, ndw in sectors:
+        s = OracleSector(m, nup, ndw)
+        e0 = np.linalg.eigvalsh(s.dense())[0]
+        assert abs(e0 - (eu[:nup].sum() + ed[:ndw].sum())) < 1e-12, (name, nup, ndw)
