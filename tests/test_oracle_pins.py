@@ -5,7 +5,8 @@
   (3) an independent second-quantised construction (Jordan-Wigner on the full Fock space),
   (4) internal consistency: sparse == dense-Kronecker == MPI-emulated product,
   (5) closed forms (round 6): the Hubbard dimer's four levels, and the free-fermion limit -- the lowest level of a sector = the sum of the
-      lowest one-body levels of each spin, the one-body matrices assembled straight from the model arrays (real and complex models)."""
+      lowest one-body levels of each spin, the one-body matrices assembled straight from the model arrays (real and complex models); the
+      two-orbital atom with the Kanamori terms (U +- Jp, Ust +- Jx, Ust - Jh): the interaction part incl. the spH0nd block."""
 import itertools
 import json
 from pathlib import Path
@@ -249,3 +250,22 @@ def test_free_fermion_limit_against_the_one_body_spectrum(name):
         s = OracleSector(m, nup, ndw)
         e0 = np.linalg.eigvalsh(s.dense())[0]
         assert abs(e0 - (eu[:nup].sum() + ed[:ndw].sum())) < 1e-12, (name, nup, ndw)
+
+
+def test_two_orbital_atom_kanamori_levels():
+    """Analytic pin of the interaction terms incl. the spH0nd block (sparse/H_local.f90:21-93, H_non_local.f90:23-98): ONE site, two orbitals, no
+    hopping.  Two electrons, Sz = 0: the doubly occupied orbitals {U_a, U_b} are coupled by the pair hopping Jp, the two inter-orbital
+    opposite-spin states {Ust, Ust} by the spin exchange Jx -> levels U +- Jp (equal U) and Ust +- Jx; Sz = +-1: Ust - Jh."""
+    U, Ust, Jh, Jx, Jp = 3.0, 1.9, 0.45, 0.31, 0.27
+    h = np.zeros((1, 1, 2, 2, 2, 2), dtype=np.complex128, order="F")
+    hb = np.zeros((1, 1, 2, 2, 2, 2, 0), dtype=np.complex128, order="F")
+    v = np.zeros((1, 2, 2, 0), order="F")
+    m = models.Model(1, 2, 2, 0, h, hb, v, Uloc=np.array([U, U]), Ust=Ust, Jh=Jh, Jx=Jx, Jp=Jp, hfmode=False, name="two_orbital_atom")
+    ev = np.linalg.eigvalsh(OracleSector(m, 1, 1).dense())
+    assert np.allclose(ev, sorted([U - Jp, U + Jp, Ust - Jx, Ust + Jx]), atol=1e-13), ev
+    for nup, ndw in ((2, 0), (0, 2)):
+        ev = np.linalg.eigvalsh(OracleSector(m, nup, ndw).dense())
+        assert np.allclose(ev, [Ust - Jh], atol=1e-13), ev
+    # without Jx / Jp the four Sz = 0 states are uncoupled
+    m0 = models.Model(1, 2, 2, 0, h, hb, v, Uloc=np.array([U, U]), Ust=Ust, Jh=Jh, hfmode=False, name="two_orbital_atom_dd")
+    assert np.allclose(np.linalg.eigvalsh(OracleSector(m0, 1, 1).dense()), sorted([U, U, Ust, Ust]), atol=1e-13)
