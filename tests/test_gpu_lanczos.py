@@ -866,3 +866,50 @@ def test_eigh_lowest_large_krylov_basis(built, neig, ncv, real_vectors, fused):
     ev_all, _, nconv_all, _ = sec.eigh_lowest(neig, ncv, 512, 0.0, want_vectors=False)
     assert nconv_all == neig and np.abs(ev_all - ev).max() < 1e-10
     sec.close()
+
+
+@pytest.mark.parametrize("site,spin", [(0, 0), (1, 1)])
+def test_impurity_green_function_free_fermion_closed_form(built, site, spin):
+    """Row N1 against a CLOSED FORM, no oracle in the loop: without interaction the impurity Green's function of the ground state is the one-body
+    resolvent, G_ii(i w_n) = [(i w_n - h)^-1]_ii, h assembled straight from the model arrays.  Engine only: ground state (hxv_lanczos_eigh),
+    c^dagger / c on the device (hxv_apply_ladder), hxv_lanczos_tridiag, the consumer's continued-fraction assembly (ED_GF_NORMAL.f90:915-975)."""
+    import torch
+    import hxv
+    from hxv import models
+
+    m, N = models.hm_1dchain(Nlat=2, Nbath=2, eps_bath=[0.25, -0.4], U=0.0, hfmode=False, xmu=0.1), 3
+    nimp, ns = 2, 6
+    h = np.zeros((ns, ns))
+    for il in range(2):
+        for jl in range(2):
+            h[il, jl] += m.impHloc[il, jl, 0, 0, 0, 0].real
+            for ib in range(2):
+                h[nimp + il + ib * nimp, nimp + jl + ib * nimp] += m.Hbath[il, jl, 0, 0, 0, 0, ib].real
+    for ib in range(2):
+        for il in range(2):
+            h[il, nimp + il + ib * nimp] += m.Vbath[il, 0, 0, ib]
+            h[nimp + il + ib * nimp, il] += m.Vbath[il, 0, 0, ib]
+    for a in range(nimp):
+        h[a, a] -= m.xmu
+    eps, phi = np.linalg.eigh(h)
+    assert eps[N] - eps[N - 1] > 1e-3                           # closed shell: the ground state of (3,3) is unique
+    beta, Lmats = 50.0, 64
+    wm = np.pi / beta * (2 * np.arange(1, Lmats + 1) - 1)
+    Gexact = (phi[site, :] ** 2 / (1j * wm[:, None] - eps[None, :])).sum(axis=1)
+    gs = hxv.HxvSector.from_model(m, N, N)
+    e0, psi, _ = gs.lanczos_eigh(nitermax=512, threshold=1e-14, native=True)
+    assert abs(e0 - 2 * eps[:N].sum()) < 1e-10
+    G = np.zeros(Lmats, dtype=complex)
+    for create in (True, False):
+        d = 1 if create else -1
+        sec = hxv.HxvSector.from_model(m, N + d * (spin == 0), N + d * (spin == 1))
+        vv, norm2 = gs.apply_ladder(sec, site, spin, create, psi, out=torch.zeros(sec.localElems, dtype=torch.complex128, device="cuda"))
+        a, b, n = sec.lanczos_tridiag(vv, min(sec.Dim, 200), threshold=1e-12)
+        a, b = a[:n], b[:n]
+        ev, Z = np.linalg.eigh(np.diag(a) + np.diag(b[1:], 1) + np.diag(b[1:], -1))
+        sign = 1.0 if create else -1.0
+        for j in range(n):
+            G += norm2 * Z[0, j] ** 2 / (1j * wm - sign * (ev[j] - e0))
+        sec.close()
+    gs.close()
+    assert np.abs(G - Gexact).max() <= 1e-9, np.abs(G - Gexact).max()
