@@ -142,3 +142,51 @@ def test_ground_state_energy_at_headline_size_on_four_ranks(built, monkeypatch, 
         assert abs(e0 - g["E0"]) <= 1e-10, (e0, g["E0"], nit)
         assert real == 1                                       # (H is real: the slabs on the links are real)
     assert abs(sum(n2 for _, n2, _, _ in res) - 1.0) < 1e-10
+
+
+def _one_body_levels(m, spin):
+    """eigenvalues of the one-body matrix of one spin, assembled straight from the model arrays (the reference's orbital numbering,
+    ED_SETUP.f90:367-375,563-568; bath diagonal = its real part, ED_HAMILTONIAN_SPARSE_HxV.f90:71; -xmu on the impurity, H_local.f90:22-28)"""
+    L, O, B, S = m.Nlat, m.Norb, m.Nbath, m.Nspin
+    nimp, ns = L * O, L * O * (B + 1)
+    s = spin if S > 1 else 0
+    h = np.zeros((ns, ns), dtype=np.complex128)
+    for il in range(L):
+        for jl in range(L):
+            for io in range(O):
+                for jo in range(O):
+                    a, b = io + il * O, jo + jl * O
+                    h[a, b] += m.impHloc[il, jl, s, s, io, jo]
+                    for ib in range(B):
+                        x = m.Hbath[il, jl, s, s, io, jo, ib]
+                        h[nimp + a + ib * nimp, nimp + b + ib * nimp] += x.real if a == b else x
+    for ib in range(B):
+        for il in range(L):
+            for io in range(O):
+                a = io + il * O
+                h[a, nimp + a + ib * nimp] += m.Vbath[il, s, io, ib]
+                h[nimp + a + ib * nimp, a] += m.Vbath[il, s, io, ib]
+    for a in range(nimp):
+        h[a, a] -= m.xmu
+    return np.linalg.eigvalsh(h)
+
+
+@pytest.mark.parametrize("name", ["C3", "C4"])
+def test_free_fermion_ground_state_at_headline_size_closed_form(built, name):
+    """A CLOSED FORM at Dim = 165 636 900, no oracle and no fixture in the loop: without interaction the lowest level of sector (8,8) is the sum
+    of the 8 lowest one-body levels of each spin (both models are closed shells there).  The engine's product at full size -- every fermionic
+    sign of 1.7e8 x 30 matrix elements, the device row order included -- must reproduce it through hxv_lanczos_eigh: 1e-10."""
+    import hxv
+    from hxv import models
+
+    m = {"C3": lambda: models.hm_2dsquare(U=0.0, hfmode=False), "C4": lambda: models.bhz_2d(Nbath=1, U=0.0, hfmode=False)}[name]()
+    eu, ed = _one_body_levels(m, 0), _one_body_levels(m, m.Nspin - 1)
+    assert eu[8] - eu[7] > 0.1 and ed[8] - ed[7] > 0.1            # closed shells: a unique, gapped ground state
+    exact = eu[:8].sum() + ed[:8].sum()
+    hxv.pool_trim()
+    sec = hxv.HxvSector.from_model(m, 8, 8)
+    assert sec.Dim == 165636900
+    e0, _, nit = sec.lanczos_eigh(600, 1e-13, want_vector=False)
+    assert abs(e0 - exact) < 1e-10, (name, e0, exact, nit)
+    sec.close()
+    hxv.pool_trim()
