@@ -171,21 +171,27 @@ def _one_body_levels(m, spin):
     return np.linalg.eigvalsh(h)
 
 
-@pytest.mark.parametrize("name", ["C3", "C4"])
+@pytest.mark.parametrize("name", ["C3", "C4", "C5"])
 def test_free_fermion_ground_state_at_headline_size_closed_form(built, name):
     """A CLOSED FORM at Dim = 165 636 900, no oracle and no fixture in the loop: without interaction the lowest level of sector (8,8) is the sum
     of the 8 lowest one-body levels of each spin (both models are closed shells there).  The engine's product at full size -- every fermionic
     sign of 1.7e8 x 30 matrix elements, the device row order included -- must reproduce it through hxv_lanczos_eigh: 1e-10."""
+    import torch
     import hxv
     from hxv import models
 
-    m = {"C3": lambda: models.hm_2dsquare(U=0.0, hfmode=False), "C4": lambda: models.bhz_2d(Nbath=1, U=0.0, hfmode=False)}[name]()
+    m = {"C3": lambda: models.hm_2dsquare(U=0.0, hfmode=False), "C4": lambda: models.bhz_2d(Nbath=1, U=0.0, hfmode=False),
+         "C5": lambda: models.hm_ring(6, 2, U=0.0, hfmode=False)}[name]()                       # C5: Ns = 18, sector (9,9), Dim = 2 363 904 400
+    n = 9 if name == "C5" else 8
     eu, ed = _one_body_levels(m, 0), _one_body_levels(m, m.Nspin - 1)
-    assert eu[8] - eu[7] > 0.1 and ed[8] - ed[7] > 0.1            # closed shells: a unique, gapped ground state
-    exact = eu[:8].sum() + ed[:8].sum()
+    assert eu[n] - eu[n - 1] > 0.1 and ed[n] - ed[n - 1] > 0.1    # closed shells: a unique, gapped ground state
+    exact = eu[:n].sum() + ed[:n].sum()
+    torch.cuda.empty_cache()
     hxv.pool_trim()
-    sec = hxv.HxvSector.from_model(m, 8, 8)
-    assert sec.Dim == 165636900
+    if name == "C5" and torch.cuda.mem_get_info()[0] < 200e9:
+        pytest.skip("needs ~160 GB of free HBM")
+    sec = hxv.HxvSector.from_model(m, n, n)
+    assert sec.Dim == (2363904400 if name == "C5" else 165636900)
     e0, _, nit = sec.lanczos_eigh(600, 1e-13, want_vector=False)
     assert abs(e0 - exact) < 1e-10, (name, e0, exact, nit)
     sec.close()
