@@ -219,31 +219,12 @@ def test_free_fermion_limit_against_the_one_body_spectrum(name):
         m, sectors = models.hm_2dsquare(Nbath=1, U=0.0, hfmode=False, xmu=0.15), [(4, 4), (3, 5)]
     else:
         m, sectors = models.bhz_2d(Nbath=0, U=0.0, hfmode=False), [(4, 4), (3, 5), (2, 2)]
-    L, O, B, S = m.Nlat, m.Norb, m.Nbath, m.Nspin
-    nimp, ns = L * O, L * O * (B + 1)
+    from onebody import one_body_matrix
+
+    S = m.Nspin
 
     def one_body(spin):
-        s = spin if S > 1 else 0
-        h = np.zeros((ns, ns), dtype=np.complex128)
-        for il in range(L):
-            for jl in range(L):
-                for io in range(O):
-                    for jo in range(O):
-                        a, b = io + il * O, jo + jl * O                      # ED_SETUP.f90:563-568
-                        h[a, b] += m.impHloc[il, jl, s, s, io, jo]
-                        for ib in range(B):
-                            x = m.Hbath[il, jl, s, s, io, jo, ib]
-                            h[nimp + a + ib * nimp, nimp + b + ib * nimp] += x.real if a == b else x   # bath_diag = DREAL(...), :71
-        for ib in range(B):
-            for il in range(L):
-                for io in range(O):
-                    a = io + il * O
-                    h[a, nimp + a + ib * nimp] += m.Vbath[il, s, io, ib]
-                    h[nimp + a + ib * nimp, a] += m.Vbath[il, s, io, ib]
-        for a in range(nimp):
-            h[a, a] -= m.xmu                                                   # H_local.f90:22-28
-        assert np.abs(h - h.conj().T).max() == 0.0
-        return np.linalg.eigvalsh(h)
+        return np.linalg.eigvalsh(one_body_matrix(m, spin))
 
     eu, ed = one_body(0), one_body(S - 1)
     for nup, ndw in sectors:
@@ -269,3 +250,23 @@ def test_two_orbital_atom_kanamori_levels():
     # without Jx / Jp the four Sz = 0 states are uncoupled
     m0 = models.Model(1, 2, 2, 0, h, hb, v, Uloc=np.array([U, U]), Ust=Ust, Jh=Jh, hfmode=False, name="two_orbital_atom_dd")
     assert np.allclose(np.linalg.eigvalsh(OracleSector(m0, 1, 1).dense()), sorted([U, U, Ust, Ust]), atol=1e-13)
+
+
+@pytest.mark.parametrize("case", ["chain", "bhz_44", "bhz_35", "star_excited"])
+def test_product_on_exact_slater_determinants(case):
+    """Closed form for the PRODUCT (spMatVec_main, ED_HAMILTONIAN_SPARSE_HxV.f90:167-227): without interaction every Slater determinant of
+    one-body eigenstates is an eigenvector of the sector Hamiltonian with eigenvalue = the sum of its levels (tests/onebody.py).  Ground and
+    excited determinants, real and complex amplitudes, unequal fillings: |H v - E v| at rounding level."""
+    from onebody import slater_vector
+
+    if case == "chain":
+        m, (nu, nd), lu, ld = models.hm_1dchain(Nlat=2, Nbath=2, U=0.0, hfmode=False, eps_bath=[0.3, -0.2], xmu=0.1), (3, 3), (0, 1, 2), (0, 2, 4)
+    elif case == "bhz_44":
+        m, (nu, nd), lu, ld = models.bhz_2d(Nbath=0, U=0.0, hfmode=False), (4, 4), (0, 1, 2, 3), (0, 1, 3, 6)
+    elif case == "bhz_35":
+        m, (nu, nd), lu, ld = models.bhz_2d(Nbath=0, U=0.0, hfmode=False), (3, 5), (0, 1, 5), (0, 1, 2, 3, 7)
+    else:
+        m, (nu, nd), lu, ld = models.hm_2dsquare(Nbath=1, U=0.0, hfmode=False, xmu=-0.2), (4, 3), (0, 2, 3, 7), (1, 4, 5)
+    orc = OracleSector(m, nu, nd)
+    v, E = slater_vector(m, orc.map_up(), orc.map_dw(), lu, ld)
+    assert np.linalg.norm(orc.spMatVec_main(v) - E * v) < 1e-13
