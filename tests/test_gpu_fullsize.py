@@ -208,3 +208,26 @@ def test_product_on_an_exact_slater_determinant_at_headline_size(built, name, le
     del hv, dv
     torch.cuda.empty_cache()
     hxv.pool_trim()
+
+
+def test_spin_flip_symmetry_at_full_size_with_interaction(built):
+    """A size-independent property WITH interaction (U = 2): for Nspin = 1 the model is symmetric under up <-> dw, so sectors (9,8) and (8,9) of
+    C3 (Dim = 147 232 800) have the same spectrum -- but the engine treats the two spins differently (up hops: pass A on the device row order;
+    dw hops: pass B on column segments), so the two runs exchange the roles of the passes.  Lowest two levels (hxv_eigh_lowest) to 1e-10."""
+    import torch
+    import hxv
+    from hxv import models
+
+    m = models.hm_2dsquare()
+    out = []
+    for nup, ndw in ((9, 8), (8, 9)):
+        torch.cuda.empty_cache()
+        hxv.pool_trim()
+        sec = hxv.HxvSector.from_model(m, nup, ndw)
+        assert sec.Dim == 147232800
+        ev, _, nc, _ = sec.eigh_lowest(2, 20, want_vectors=False)
+        assert nc == 2
+        out.append(ev)
+        sec.close()
+    hxv.pool_trim()
+    assert np.abs(out[0] - out[1]).max() < 1e-10, out
