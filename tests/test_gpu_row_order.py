@@ -101,6 +101,21 @@ def test_product_in_device_row_order_matches_the_oracle(built, row_order, name):
         assert np.linalg.norm(orc.spMatVec_main(xk) - ev[k] * xk) < 1e-6
     e0h, xh, _ = sec.lanczos_eigh_host(600, 1e-13)
     assert abs(e0h - e0) < 1e-10 and np.linalg.norm(orc.spMatVec_main(xh) - e0h * xh) < 1e-6
+    # the host-array forms of the other two drivers (what the Fortran glue's gpu_sp_eigh / gpu_sp_lanc_tridiag_pair forward to): eig_basis(:, k)
+    # comes back in the reference's order, the two real start vectors go in in it
+    evh, Xh, nch, _ = sec.eigh_lowest_host(2, 20)
+    assert nch == 2 and np.abs(evh - ev).max() < 1e-9
+    for k in range(2):
+        xk = np.ascontiguousarray(Xh[:, k])          # eig_basis(:, k), Fortran shape (Dim, neigen)
+        assert np.linalg.norm(orc.spMatVec_main(xk) - evh[k] * xk) < 1e-6
+    if sec.real_vectors_available:
+        va = np.real(v).astype(np.complex128)
+        vb = np.real(np.roll(v, 7)).astype(np.complex128)
+        (aa, ba, na), (ab, bb, nb) = sec.lanczos_tridiag_pair_host(va / np.linalg.norm(va), vb / np.linalg.norm(vb), 16)
+        a_o, b_o = orc.lanc_tridiag(va / np.linalg.norm(va), 16)
+        a_p, b_p = orc.lanc_tridiag(vb / np.linalg.norm(vb), 16)
+        assert np.abs(aa[:8] - a_o[:8]).max() < 1e-10 and np.abs(ab[:8] - a_p[:8]).max() < 1e-10
+        assert np.abs(ba[:8] - b_o[:8]).max() < 1e-10 and np.abs(bb[:8] - b_p[:8]).max() < 1e-10
     a, b, n = sec.lanczos_tridiag(sec.pad(torch.from_numpy(v).cuda()), 20)
     ao, bo = orc.lanc_tridiag(v, 20)
     assert np.abs(a[:10] - ao[:10]).max() < 1e-10 and np.abs(b[:10] - bo[:10]).max() < 1e-10
