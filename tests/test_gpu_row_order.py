@@ -257,3 +257,58 @@ def test_row_order_for_other_block_sizes_and_fillings(built, monkeypatch, bits, 
     sec.close()
     tgt.close()
     hxv.sector_cache_clear()
+
+
+@pytest.mark.parametrize("exchange", ["allgather", "halo", "alltoall"])
+def test_row_order_on_split_sectors(built, row_order, exchange, monkeypatch):
+    """The device row order with the DimDw split (three thread ranks through the RCCL branches -- the process's communicator serves the three
+    sectors a rank holds at once --, all three exchanges): rows are permuted the same way on every rank, columns
+    keep the reference's order and split (ED_HAMILTONIAN.f90:93-105).  Every rank's slab of the product against the oracle's, one Lanczos
+    run against the unsplit sector, and both ladder operators (up: local; dw: one column exchange) against the unsplit result."""
+    import torch
+    import hxv
+    from hxv import models
+    from oracle.oracle import OracleSector
+
+    monkeypatch.setenv("HXV_RCCL_LIB", str(built.build_rccl_double()))
+    m, (nup, ndw), P = models.hm_2dsquare(Nbath=2, xmu=0.1), (6, 5), 3
+    orc = OracleSector(m, nup, ndw)
+    v = models.deterministic_vector(orc.Dim)
+    v /= np.linalg.norm(v)
+    ref = orc.spMatVec_main(v)
+    full = _open(m, nup, ndw, row_order)
+    assert full.row_perm is not None
+    a_ref, b_ref, _ = full.lanczos_tridiag(full.pad(torch.from_numpy(v).cuda()), 12)
+    tup, tdw = _open(m, nup + 1, ndw, row_order), _open(m, nup, ndw + 1, row_order)
+    lad_up = tup.unpad(full.apply_ladder(tup, 1, 0, True, full.pad(torch.from_numpy(v).cuda()), out=torch.zeros(tup.localElems, dtype=torch.complex128, device="cuda"))[0]).cpu().numpy()
+    lad_dw = tdw.unpad(full.apply_ladder(tdw, 3, 1, True, full.pad(torch.from_numpy(v).cuda()), out=torch.zeros(tdw.localElems, dtype=torch.complex128, device="cuda"))[0]).cpu().numpy()
+    for s in (full, tup, tdw):
+        s.close()
+
+    def rank(r, group):
+        hxv.set_exchange_default(exchange)
+        try:
+            sec = hxv.HxvSector.from_model(m, nup, ndw, rank=r, nranks=P)
+            su = hxv.HxvSector.from_model(m, nup + 1, ndw, rank=r, nranks=P)
+            sd = hxv.HxvSector.from_model(m, nup, ndw + 1, rank=r, nranks=P)
+        finally:
+            hxv.set_exchange_default("allgather")
+        for s in (sec, su, sd):
+            s.set_option("tile_bits_up", row_order)
+            group.join(s)
+        assert sec.row_perm is not None
+        lo, hi = sec.mpiIshift, sec.mpiIshift + sec.vecDim
+        slab = sec.pad(torch.from_numpy(v[lo:hi].copy()).cuda(), sec.mpiQdw)
+        hv = sec.unpad(sec.apply_device_slab(slab)).cpu().numpy()
+        a, b, _ = sec.lanczos_tridiag(slab, 12)
+        ou = su.unpad(sec.apply_ladder(su, 1, 0, True, slab, out=torch.zeros(su.localElems, dtype=torch.complex128, device="cuda"))[0]).cpu().numpy()
+        od = sd.unpad(sec.apply_ladder(sd, 3, 1, True, slab, out=torch.zeros(sd.localElems, dtype=torch.complex128, device="cuda"))[0]).cpu().numpy()
+        out = (lo, hi, hv, a, b, (su.mpiIshift, su.vecDim, ou), (sd.mpiIshift, sd.vecDim, od))
+        for s in (sec, su, sd):
+            s.close()
+        return out
+
+    for lo, hi, hv, a, b, (ulo, un, ou), (dlo, dn, od) in hxv.run_ranks(P, rank, transport="rccl"):
+        assert _rel(hv, ref[lo:hi]) < TOL
+        assert np.abs(a[:8] - a_ref[:8]).max() < 1e-10 and np.abs(b[:8] - b_ref[:8]).max() < 1e-10
+        assert np.abs(ou - lad_up[ulo:ulo + un]).max() < 1e-14 and np.abs(od - lad_dw[dlo:dlo + dn]).max() < 1e-14
