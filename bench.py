@@ -746,6 +746,12 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     if multi:
+        # every rank at the same point: close the sector, destroy the process's RCCL communicator (hxv_comm_cache_clear), then torch's
+        try:
+            sec.close()
+            hxv.comm_cache_clear()
+        except Exception:  # noqa: BLE001 (the line is out: never fail on the way down)
+            pass
         dist.destroy_process_group()
 
 
