@@ -31,7 +31,9 @@ struct DevTiles {
   const uint32_t* rs_base; // [nslots] first gather slot of the slot's source block (table words are relative to it; 0: absolute words)
   const uint32_t* rs_neg;  // [nslots] 1: the (shared) table holds this slot's coefficients with the opposite sign
   int nblocks, nscoef;
-  int debug;  // timing experiments only: 1 skip out-of-block hops, 2 skip in-block hops, 4 skip the hv read-modify-write (pass B)
+  int debug;  // timing experiments only: 1 skip out-of-block hops, 2 skip in-block hops, 8 plain instead of streaming hv stores (pass A),
+              // 32 natural block order, 64 no packed row-slot words, 256 skip the block hops only, 512 skip the row slots only (round 6's
+              // phase budget: profiles/r06_phase_ablate_c3.log)
   int pair_rows;  // pass B: the two row groups that share 128-byte lines run back to back, block by block (large sectors)
   const uint32_t* order;  // [nblocks] blocks by decreasing size (= grouped by table class), or null: pass B visits a row group's blocks in this order
   int p16_bits;           // ell16 words: (coefficient index << p16_bits) | offset, two per 32-bit word
