@@ -20,10 +20,6 @@
 #ifndef HXV_PAIR_LDS
 #define HXV_PAIR_LDS 1  // (0: A/B builds only -- the real-vector pass A with one 8-byte LDS element per column)
 #endif
-// A/B builds only (scripts/lib_ab.sh): non-temporal loads for the once-read streams -- pass B's tile (1), pass A's tile (2), pass A's wt (4)
-#ifndef HXV_NT_LOADS
-#define HXV_NT_LOADS 0
-#endif
 
 namespace hxv {
 
@@ -89,7 +85,7 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
 #pragma unroll
     for (int cc = 0; cc < C; ++cc) {
       const VT* __restrict__ src = vcol0 + (int64_t)min(cc, nc - 1) * s.pitch + r0;
-      for (int r = threadIdx.x; r < n; r += T) lds[cc * n + r] = (HXV_NT_LOADS & 2) ? load_stream(&src[r]) : src[r];
+      for (int r = threadIdx.x; r < n; r += T) lds[cc * n + r] = src[r];
     }
   }
   for (int q = threadIdx.x; q < t.nscoef; q += T) lcoef[q] = Coef<REAL>::from(t.scoef[q]);
@@ -150,7 +146,7 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_up(DevSector s, DevTiles t, 
         const int dR = (s.dimup + Rp - 1) & ~(Rp - 1);
         const VT* __restrict__ wrow = wt + ((int64_t)(c0 / wcl) * dR + (row & ~(Rp - 1))) * wcl + (int64_t)(c0 % wcl) * Rp + (row & (Rp - 1));
 #pragma unroll
-        for (int cc = 0; cc < C; ++cc) acc[cc] = (HXV_NT_LOADS & 4) ? load_stream(&wrow[min(cc, nc - 1) * Rp]) : wrow[min(cc, nc - 1) * Rp];
+        for (int cc = 0; cc < C; ++cc) acc[cc] = wrow[min(cc, nc - 1) * Rp];
       } else if (wt) {
         const VT* __restrict__ wrow = wt + ((int64_t)(c0 / wc) * s.dimup + r0 + p) * wc + (c0 % wc);
 #pragma unroll
@@ -446,7 +442,7 @@ __global__ void __launch_bounds__(1024, 8) hxv_pass_dw(DevSector s, DevTiles t, 
     const char* __restrict__ src = vrows + (int64_t)cb0 * pitchb;
     VT x[NP];
 #pragma unroll
-    for (int it = 0; it < NP; ++it) x[it] = (HXV_NT_LOADS & 1) ? load_stream(reinterpret_cast<const VT*>(src + voff(it))) : *reinterpret_cast<const VT*>(src + voff(it));
+    for (int it = 0; it < NP; ++it) x[it] = *reinterpret_cast<const VT*>(src + voff(it));
 #pragma unroll
     for (int it = 0; it < NP; ++it) {
       if ((tid >> LR) + it * cstep < n) lds_st<VT>(tq + it * T * VB, x[it]);
