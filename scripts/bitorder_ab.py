@@ -1,6 +1,11 @@
 """Same-box A/B of the orbital -> bit assignment of a spin's basis (TIMING ONLY: the relabelled model is another
 Hamiltonian with the same hop graph, the device layout it implies is not converted at the boundaries).  WORKLOAD=C3|C4|C5.
-usage: bitorder_ab.py "name:up=p0,p1,...;dw=p0,p1,..." ...   (pos lists = bit of orbital 0, 1, ...; omitted spin = reference order)"""
+usage: bitorder_ab.py "name:up=p0,p1,...;dw=p0,p1,..." ...   (pos lists = bit of orbital 0, 1, ...; omitted spin = reference order)
+
+HISTORY: the `HXV_EXP_UP_ORDER` / `HXV_EXP_DW_ORDER` hooks this script sets lived in hxv_sector.cpp at commit d4f54db only (they relabelled the
+hops before the tables were built); the log it produced is profiles/r06_bitorder_c3.log.  The up-spin result became the engine's device row
+order (commit e2da8cd; `HXV_ROW_ORDER=0|1`, tests/test_gpu_row_order.py), which converts at the boundaries and replaced the hooks; on later
+commits this script times the shipped order only (the env variables are ignored) -- use HXV_ROW_ORDER=0/1 for the up-spin A/B."""
 import os, sys
 os.environ["HXV_EXPERIMENTS"] = "1"
 os.environ["HXV_SECTOR_CACHE"] = "0"
