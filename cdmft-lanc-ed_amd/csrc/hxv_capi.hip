@@ -75,31 +75,31 @@ int prepare_image(SectorImage& im) {
   auto pd = std::make_shared<SectorImage::Pending>();
   TableArena& ar = pd->ar;
   const SpinOp& sup = s.dev_up();   // (H_up between DEVICE rows: SectorHost::up_perm)
-  ar.add(sup.ell, &pd->ell_up);
-  ar.add(translate_ell_src(s.dw.ell, s.vcol), &pd->ell_dw);
-  ar.add(s.vcol, &pd->vcol);
+  (void)ar.add(sup.ell, &pd->ell_up);
+  (void)ar.add(translate_ell_src(s.dw.ell, s.vcol), &pd->ell_dw);
+  (void)ar.add(s.vcol, &pd->vcol);
   std::vector<double2> cu(sup.coef.size()), cd(s.dw.coef.size());
   for (size_t i = 0; i < cu.size(); ++i) cu[i] = make_double2(sup.coef[i].real(), sup.coef[i].imag());
   for (size_t i = 0; i < cd.size(); ++i) cd[i] = make_double2(s.dw.coef[i].real(), s.dw.coef[i].imag());
-  ar.add(cu, &pd->coef_up);
-  ar.add(cd, &pd->coef_dw);
+  (void)ar.add(cu, &pd->coef_up);
+  (void)ar.add(cd, &pd->coef_dw);
   if (s.separable_diag) {
-    ar.add(s.dev_map_up(), &pd->map_up);
-    ar.add(s.map_dw, &pd->map_dw);
-    ar.add(s.dev_a_up(), &pd->a_up);
-    ar.add(s.a_dw, &pd->a_dw);
+    (void)ar.add(s.dev_map_up(), &pd->map_up);
+    (void)ar.add(s.map_dw, &pd->map_dw);
+    (void)ar.add(s.dev_a_up(), &pd->a_up);
+    (void)ar.add(s.a_dw, &pd->a_dw);
   } else {
-    ar.add(s.diag_stored, &pd->stored);
+    (void)ar.add(s.diag_stored, &pd->stored);
   }
   if (!s.nd_up.empty()) {
-    ar.add(s.dev_nd_up(), &pd->ndu);
-    ar.add(s.nd_dw, &pd->ndd);
+    (void)ar.add(s.dev_nd_up(), &pd->ndu);
+    (void)ar.add(s.nd_dw, &pd->ndd);
   }
   if (s.row_order()) {
-    ar.add(s.map_up, &pd->map_up_ref);
-    ar.add(s.up_perm, &pd->up_perm);
-    ar.add(s.up_iperm, &pd->up_iperm);
-    ar.add(s.up_sign, &pd->up_sign);
+    (void)ar.add(s.map_up, &pd->map_up_ref);
+    (void)ar.add(s.up_perm, &pd->up_perm);
+    (void)ar.add(s.up_iperm, &pd->up_iperm);
+    (void)ar.add(s.up_sign, &pd->up_sign);
   }
   PlanUploader pu{[&ar](const std::vector<uint32_t>& v, uint32_t** p) { return ar.add(v, p); },
                   [&ar](const std::vector<double2>& v, double2** p) { return ar.add(v, p); }};

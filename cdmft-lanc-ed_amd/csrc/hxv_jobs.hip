@@ -82,6 +82,9 @@ struct JobUp {
 constexpr int JOB_WAVES = 16, JOB_LOADER = JOB_WAVES - 1, JOB_MAX_STAGES = 8;
 
 // LZ: 0 plain product, 1 Lanczos epilogue, 2 PAIRED epilogue (real H: Re and Im are two independent real Lanczos vectors, hxv_tiles.hpp)
+// (LDS-DMA destinations are byte offsets: see the note on the host pass's pointer width in hxv_tile_dev.hpp)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wint-to-void-pointer-cast"
 template <int C, bool REALC, bool NORB1, int LZ, int KIN, int KO, typename VT>
 __global__ void __launch_bounds__(1024) hxv_up_job(DevSector s, DevTiles t, JobUp jb, LzEpilogue lz) {
   using CT = typename Coef<REALC>::type;
@@ -415,6 +418,7 @@ __global__ void __launch_bounds__(1024) hxv_up_job(DevSector s, DevTiles t, JobU
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
+#pragma clang diagnostic pop
 namespace {
 
 hipError_t allow_lds(const void* kern, int bytes) {

@@ -67,6 +67,9 @@ constexpr uint32_t TILE_OFF_MASK = (1u << TILE_COEF_SHIFT) - 1u;
 
 // LDS by byte offset (a kernel's dynamic LDS starts at 0 when it declares no static LDS): addressing through the
 // extern __shared__ symbol costs one vector add per access that the compiler cannot fold.
+// (the HOST pass of hipcc sees 64-bit LDS pointers and warns about the 32-bit offsets; the device pass, the only one that runs them, has 32-bit ones)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wint-to-pointer-cast"
 template <typename X>
 __device__ __forceinline__ X lds_ld(uint32_t off) { return *(__attribute__((address_space(3))) const X*)(off); }
 template <typename X>
@@ -83,6 +86,7 @@ __device__ __forceinline__ void lds_st<double2>(uint32_t off, double2 a) {
   x.y = a.y;
   *(__attribute__((address_space(3))) dbl2_t*)(off) = x;
 }
+#pragma clang diagnostic pop
 // (a << SH) + b in one instruction (the compiler turns (x & m) << SH into shift, mask, add)
 template <int SH>
 __device__ __forceinline__ uint32_t shl_add(uint32_t a, uint32_t b) {
